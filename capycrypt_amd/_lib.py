@@ -1,0 +1,104 @@
+"""ctypes binding of libcapyhip.so (the C ABI declared in include/capyhip.h).
+
+There is no CPU fallback: if the HIP library is missing or a call fails, this raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcapyhip.so")
+
+u8p = C.POINTER(C.c_uint8)
+u64p = C.POINTER(C.c_uint64)
+i32p = C.POINTER(C.c_int32)
+vp = C.c_void_p
+sz = C.c_size_t
+u64 = C.c_uint64
+
+CAPY_OK = 0
+CAPY_ERR_UNSUPPORTED_SECPARAM = -1
+CAPY_ERR_ARG = -2
+CAPY_ERR_HIP = -3
+CAPY_ERR_UNSUPPORTED = -4
+
+# every symbol include/capyhip.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "capy_last_error": (C.c_char_p, []),
+    "capy_version": (C.c_char_p, []),
+    "capy_device_count": (C.c_int, []),
+    "capy_set_device": (C.c_int, [C.c_int]),
+    "capy_device_synchronize": (C.c_int, []),
+    "capy_sha3_batch": (C.c_int, [C.c_int, sz, vp, vp, vp]),
+    "capy_sha3_batch_dev": (C.c_int, [C.c_int, sz, vp, vp, u64, u64, vp, vp]),
+    "capy_cshake_batch": (C.c_int, [C.c_int, sz, vp, vp, sz, vp, sz, vp, sz, vp]),
+    "capy_kmac_xof_batch": (C.c_int, [C.c_int, sz, vp, sz, vp, vp, sz, vp, sz, vp]),
+    "capy_kmac_xof_batch_dev": (C.c_int, [C.c_int, sz, vp, sz, u64, vp, vp, u64, u64, sz, vp, sz, vp, u64, vp]),
+    "capy_sha3_encrypt_batch": (C.c_int, [C.c_int, sz, vp, sz, vp, vp, vp, vp]),
+    "capy_sha3_decrypt_batch": (C.c_int, [C.c_int, sz, vp, sz, vp, vp, vp, vp, vp]),
+    "capy_sha3_encrypt_batch_dev": (C.c_int, [C.c_int, sz, vp, sz, vp, vp, vp, u64, u64, vp, vp]),
+    "capy_sha3_decrypt_batch_dev": (C.c_int, [C.c_int, sz, vp, sz, vp, vp, vp, u64, u64, vp, vp, vp]),
+    "capy_ed448_scalarmul_batch": (C.c_int, [sz, vp, vp, vp]),
+    "capy_ed448_scalarmul_batch_dev": (C.c_int, [sz, vp, vp, vp, vp]),
+    "capy_ed448_basemul_batch": (C.c_int, [sz, vp, vp]),
+    "capy_ed448_basemul_batch_dev": (C.c_int, [sz, vp, vp, vp]),
+    "capy_ed448_add_batch": (C.c_int, [sz, vp, vp, vp]),
+    "capy_ed448_double_scalarmul_batch": (C.c_int, [sz, vp, vp, vp, vp]),
+    "capy_keypair_batch": (C.c_int, [C.c_int, sz, vp, sz, vp]),
+    "capy_schnorr_sign_batch": (C.c_int, [C.c_int, sz, vp, sz, vp, vp, vp, vp]),
+    "capy_schnorr_verify_batch": (C.c_int, [C.c_int, sz, vp, vp, vp, vp, vp, vp]),
+    "capy_key_encrypt_batch": (C.c_int, [C.c_int, sz, vp, vp, vp, vp, vp, vp]),
+    "capy_key_decrypt_batch": (C.c_int, [C.c_int, sz, vp, sz, vp, vp, vp, vp, vp]),
+    "capy_fill_random_dev": (C.c_int, [vp, u64, u64, vp]),
+    "capy_keccak_valu_probe_dev": (C.c_int, [u64, C.c_uint32, vp, vp]),
+}
+
+_lib = None
+
+
+class CapyHipError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__("libcapyhip error %d: %s" % (code, text))
+        self.code = code
+
+
+def lib():
+    """Load libcapyhip.so (loudly: no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). capycrypt_amd has no CPU fallback." % LIB_PATH
+            )
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)  # AttributeError if the library does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc):
+    if rc != CAPY_OK:
+        raise CapyHipError(rc, lib().capy_last_error().decode("utf-8", "replace"))
+
+
+def buf(b):
+    """bytes-like -> ctypes array (copy). Empty input gives a 1-byte dummy so the pointer is valid."""
+    b = bytes(b)
+    return (C.c_uint8 * max(1, len(b))).from_buffer_copy(b if b else b"\0")
+
+
+def pack(msgs):
+    """list of bytes-like -> (tightly packed ctypes buffer, offsets ctypes array[n+1])."""
+    offs = [0]
+    chunks = []
+    pos = 0
+    for m in msgs:
+        m = bytes(m)
+        chunks.append(m)
+        pos += len(m)
+        offs.append(pos)
+    data = b"".join(chunks)
+    return buf(data), (C.c_uint64 * len(offs))(*offs)

@@ -1,0 +1,118 @@
+// keccak_dev.h — keccak-f[1600] for one sponge per lane on gfx950 (CDNA4).
+//
+// Replaces the reference's keccakf_1600 (/root/reference/src/sha3/keccakf.rs:8-423).
+// The 25 x u64 state lives in 50 VGPRs as (lo, hi) 32-bit halves.  Per round:
+//   theta  column parity with v_bitop3_b32 (3-input XOR, truth table 0x96)      20 ops
+//          rol1(C) with v_alignbit_b32                                          10 ops
+//          A ^= C[x-1] ^ rol1(C[x+1]) as one bitop3 per half                    50 ops
+//   rho    two v_alignbit_b32 per lane (rotations are compile-time constants)   48 ops
+//   pi     register renaming (free)
+//   chi    a ^ (~b & c) as one v_bitop3_b32 (truth table 0xD2) per half         50 ops
+//   iota   2 ops
+// = 180 VALU ops / round, 4320 / permutation, no cross-lane traffic, no LDS.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace capy {
+
+__device__ __constant__ const uint32_t KECCAK_RC32[48] = {
+    0x00000001u, 0x00000000u, 0x00008082u, 0x00000000u, 0x0000808Au, 0x80000000u, 0x80008000u, 0x80000000u,
+    0x0000808Bu, 0x00000000u, 0x80000001u, 0x00000000u, 0x80008081u, 0x80000000u, 0x00008009u, 0x80000000u,
+    0x0000008Au, 0x00000000u, 0x00000088u, 0x00000000u, 0x80008009u, 0x00000000u, 0x8000000Au, 0x00000000u,
+    0x8000808Bu, 0x00000000u, 0x0000008Bu, 0x80000000u, 0x00008089u, 0x80000000u, 0x00008003u, 0x80000000u,
+    0x00008002u, 0x80000000u, 0x00000080u, 0x80000000u, 0x0000800Au, 0x00000000u, 0x8000000Au, 0x80000000u,
+    0x80008081u, 0x80000000u, 0x00008080u, 0x80000000u, 0x80000001u, 0x00000000u, 0x80008008u, 0x80000000u};
+
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c)
+{
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+}
+// a ^ (~b & c)
+__device__ __forceinline__ uint32_t chi3(uint32_t a, uint32_t b, uint32_t c)
+{
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0xD2);
+}
+
+struct KState {
+    uint32_t lo[25];
+    uint32_t hi[25];
+};
+
+// 64-bit rotate-left by a compile-time amount on (lo, hi) halves.
+template <int R>
+__device__ __forceinline__ void rol64c(uint32_t lo, uint32_t hi, uint32_t &olo, uint32_t &ohi)
+{
+    if constexpr (R == 0) {
+        olo = lo;
+        ohi = hi;
+    } else if constexpr (R == 32) {
+        olo = hi;
+        ohi = lo;
+    } else if constexpr (R < 32) {
+        olo = __builtin_amdgcn_alignbit(lo, hi, 32 - R);
+        ohi = __builtin_amdgcn_alignbit(hi, lo, 32 - R);
+    } else {
+        olo = __builtin_amdgcn_alignbit(hi, lo, 64 - R);
+        ohi = __builtin_amdgcn_alignbit(lo, hi, 64 - R);
+    }
+}
+
+// rho offsets indexed [x + 5y] (FIPS 202 table 2)
+#define CAPY_RHO(i)                                                                                          \
+    ((i) == 0 ? 0 : (i) == 1 ? 1 : (i) == 2 ? 62 : (i) == 3 ? 28 : (i) == 4 ? 27 : (i) == 5 ? 36 : (i) == 6 ? 44 \
+     : (i) == 7 ? 6 : (i) == 8 ? 55 : (i) == 9 ? 20 : (i) == 10 ? 3 : (i) == 11 ? 10 : (i) == 12 ? 43        \
+     : (i) == 13 ? 25 : (i) == 14 ? 39 : (i) == 15 ? 41 : (i) == 16 ? 45 : (i) == 17 ? 15 : (i) == 18 ? 21    \
+     : (i) == 19 ? 8 : (i) == 20 ? 18 : (i) == 21 ? 2 : (i) == 22 ? 61 : (i) == 23 ? 56 : 14)
+
+template <int I>
+__device__ __forceinline__ void rho_pi_one(const KState &e, KState &b)
+{
+    constexpr int x = I % 5, y = I / 5;
+    constexpr int dst = y + 5 * ((2 * x + 3 * y) % 5);
+    rol64c<CAPY_RHO(I)>(e.lo[I], e.hi[I], b.lo[dst], b.hi[dst]);
+}
+
+template <int... Is>
+__device__ __forceinline__ void rho_pi_all(const KState &e, KState &b, std::integer_sequence<int, Is...>)
+{
+    (rho_pi_one<Is>(e, b), ...);
+}
+
+__device__ __forceinline__ void keccak_round(KState &a, uint32_t rc_lo, uint32_t rc_hi)
+{
+    uint32_t cl[5], ch[5], rl[5], rh[5];
+#pragma unroll
+    for (int x = 0; x < 5; x++) {
+        cl[x] = xor3(xor3(a.lo[x], a.lo[x + 5], a.lo[x + 10]), a.lo[x + 15], a.lo[x + 20]);
+        ch[x] = xor3(xor3(a.hi[x], a.hi[x + 5], a.hi[x + 10]), a.hi[x + 15], a.hi[x + 20]);
+    }
+#pragma unroll
+    for (int x = 0; x < 5; x++) rol64c<1>(cl[x], ch[x], rl[x], rh[x]);
+    KState e, b;
+#pragma unroll
+    for (int y = 0; y < 5; y++)
+#pragma unroll
+        for (int x = 0; x < 5; x++) {
+            e.lo[x + 5 * y] = xor3(a.lo[x + 5 * y], cl[(x + 4) % 5], rl[(x + 1) % 5]);
+            e.hi[x + 5 * y] = xor3(a.hi[x + 5 * y], ch[(x + 4) % 5], rh[(x + 1) % 5]);
+        }
+    rho_pi_all(e, b, std::make_integer_sequence<int, 25>{});
+#pragma unroll
+    for (int y = 0; y < 5; y++)
+#pragma unroll
+        for (int x = 0; x < 5; x++) {
+            a.lo[x + 5 * y] = chi3(b.lo[x + 5 * y], b.lo[(x + 1) % 5 + 5 * y], b.lo[(x + 2) % 5 + 5 * y]);
+            a.hi[x + 5 * y] = chi3(b.hi[x + 5 * y], b.hi[(x + 1) % 5 + 5 * y], b.hi[(x + 2) % 5 + 5 * y]);
+        }
+    a.lo[0] ^= rc_lo;
+    a.hi[0] ^= rc_hi;
+}
+
+__device__ __forceinline__ void keccakf1600(KState &a)
+{
+#pragma unroll 2
+    for (int r = 0; r < 24; r++) keccak_round(a, KECCAK_RC32[2 * r], KECCAK_RC32[2 * r + 1]);
+}
+
+}  // namespace capy

@@ -1,0 +1,670 @@
+// sponge.hip — launchers and C-ABI entry points of the batched sponge path (SHA3 / cSHAKE / KMACXOF /
+// sha3_encrypt / sha3_decrypt).  Host code here only frames the call (SP 800-185 prefixes, exactly
+// as the reference builds them) and launches kernels; there is NO CPU fallback for the data path.
+#include <string.h>
+#include <algorithm>
+#include "common.h"
+#include "sponge_kernels.h"
+
+namespace capy {
+
+// ------------------------------------------------------------------ error plumbing
+static thread_local std::string g_err;
+void set_error(const std::string &msg) { g_err = msg; }
+int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+
+// ------------------------------------------------------------------ workspace
+namespace {
+struct WsEntry {
+    int device;
+    hipStream_t stream;
+    void *ptr[WS_NSLOTS];
+    size_t cap[WS_NSLOTS];
+};
+thread_local std::vector<WsEntry> g_ws;
+}  // namespace
+
+void *workspace(hipStream_t stream, WsSlot slot, size_t bytes)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    WsEntry *e = nullptr;
+    for (auto &w : g_ws)
+        if (w.device == dev && w.stream == stream) e = &w;
+    if (!e) {
+        g_ws.push_back(WsEntry{dev, stream, {}, {}});
+        e = &g_ws.back();
+    }
+    if (bytes == 0) bytes = 8;
+    if (e->cap[slot] < bytes) {
+        if (e->ptr[slot]) (void)hipFree(e->ptr[slot]);  // synchronises outstanding work first
+        size_t cap = bytes + bytes / 4 + 256;
+        e->ptr[slot] = nullptr;
+        e->cap[slot] = 0;
+        if (hipMalloc(&e->ptr[slot], cap) != hipSuccess) return nullptr;
+        e->cap[slot] = cap;
+    }
+    return e->ptr[slot];
+}
+
+#define CAPY_WS(var, type, stream, slot, bytes)                                      \
+    type var = reinterpret_cast<type>(capy::workspace(stream, slot, bytes));          \
+    if (!var) return capy::fail(CAPY_ERR_HIP, "workspace allocation failed")
+
+// ------------------------------------------------------------------ host keccak for the shared prefix block(s)
+// (one or two permutations per API call: the batch-shared bytepad(encode_string(N)||encode_string(S), w))
+static void host_keccakf(uint64_t a[25])
+{
+    static const uint64_t rc[24] = {
+        0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808AULL, 0x8000000080008000ULL,
+        0x000000000000808BULL, 0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL,
+        0x000000000000008AULL, 0x0000000000000088ULL, 0x0000000080008009ULL, 0x000000008000000AULL,
+        0x000000008000808BULL, 0x800000000000008BULL, 0x8000000000008089ULL, 0x8000000000008003ULL,
+        0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800AULL, 0x800000008000000AULL,
+        0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+    static const int rot[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
+    for (int r = 0; r < 24; r++) {
+        uint64_t c[5], b[25];
+        for (int x = 0; x < 5; x++) c[x] = a[x] ^ a[x + 5] ^ a[x + 10] ^ a[x + 15] ^ a[x + 20];
+        for (int i = 0; i < 25; i++) {
+            int x = i % 5, y = i / 5;
+            uint64_t c1 = c[(x + 1) % 5];
+            uint64_t e = a[i] ^ c[(x + 4) % 5] ^ ((c1 << 1) | (c1 >> 63));
+            int s = rot[i];
+            b[y + 5 * ((2 * x + 3 * y) % 5)] = s ? (e << s) | (e >> (64 - s)) : e;
+        }
+        for (int i = 0; i < 25; i++) {
+            int x = i % 5, y5 = i - x;
+            a[i] = b[i] ^ (~b[(x + 1) % 5 + y5] & b[(x + 2) % 5 + y5]);
+        }
+        a[0] ^= rc[r];
+    }
+}
+
+// ------------------------------------------------------------------ SP 800-185 framing (reference forms)
+static void left_encode(uint64_t v, std::vector<uint8_t> &out)
+{ // src/sha3/aux_functions.rs:34-49
+    if (v == 0) {
+        out.push_back(1);
+        out.push_back(0);
+        return;
+    }
+    int nbytes = 0;
+    for (uint64_t t = v; t; t >>= 8) nbytes++;
+    out.push_back((uint8_t)nbytes);
+    for (int i = nbytes - 1; i >= 0; i--) out.push_back((uint8_t)(v >> (8 * i)));
+}
+
+static void encode_string(const uint8_t *s, size_t len, std::vector<uint8_t> &out)
+{ // src/sha3/aux_functions.rs:24-28
+    left_encode((uint64_t)len * 8, out);
+    out.insert(out.end(), s, s + len);
+}
+
+// bytepad as the reference writes it: always appends w - len%w zeros (a full w when aligned),
+// src/sha3/aux_functions.rs:11-18
+static std::vector<uint8_t> byte_pad(const std::vector<uint8_t> &x, uint32_t w)
+{
+    std::vector<uint8_t> z;
+    left_encode(w, z);
+    z.insert(z.end(), x.begin(), x.end());
+    size_t padlen = w - (z.size() % w);
+    z.insert(z.end(), padlen, 0);
+    return z;
+}
+
+struct Framing {
+    int rw;             // absorb words per block
+    uint32_t stride;    // reference `r`
+    uint32_t sq_words;  // squeeze words per block
+};
+
+static Framing sha3_framing(int d)
+{ // Capacity::from_bit_length(d) = 2d, src/sha3/constants.rs:38-45 ; Rate::from(&d), shake_functions.rs:31
+    uint32_t r = (1600 - 2 * d) / 8;
+    return {(int)(r / 8), r, (uint32_t)((1600 - d) / 64)};
+}
+static Framing cshake_framing(int d)
+{ // capacity = d, shake_functions.rs:63 ; bytes_to_state takes (r*8)/64 words per block, sponge.rs:52
+    uint32_t r = (1600 - d) / 8;
+    return {(int)(r / 8), r, (uint32_t)((1600 - d) / 64)};
+}
+
+// Fold the batch-shared cSHAKE prefix bytepad(encode_string(N) || encode_string(S), w) into p:
+// either as init_state (whole blocks) or as raw prefix bytes `pre_host` (D224: r = 172, 168 consumed).
+static void cshake_prefix(int d, const uint8_t *fn, size_t fn_len, const uint8_t *cs, size_t cs_len,
+                          const Framing &f, SpongeParams &p, std::vector<uint8_t> &pre_host)
+{
+    std::vector<uint8_t> enc;
+    encode_string(fn, fn_len, enc);
+    encode_string(cs, cs_len, enc);
+    std::vector<uint8_t> pre = byte_pad(enc, (uint32_t)((1600 - d) / 8));
+    memset(p.init_state, 0, sizeof p.init_state);
+    const uint32_t rb = f.rw * 8;
+    if (f.stride == rb) {
+        for (size_t off = 0; off < pre.size(); off += rb) {
+            for (int w = 0; w < f.rw; w++) {
+                uint64_t v = 0;
+                for (int j = 0; j < 8; j++) v |= (uint64_t)pre[off + 8 * w + j] << (8 * j);
+                p.init_state[w] ^= v;
+            }
+            host_keccakf(p.init_state);
+        }
+        p.pre = nullptr;
+        p.pre_len = 0;
+    } else {
+        pre_host = pre;
+        p.pre_len = (uint32_t)pre.size();
+    }
+}
+
+// per-item KMAC head = bytepad(encode_string(K), w) = left_encode(w) || left_encode(8|K|) || K || zeros
+static void kmac_head(int d, size_t key_len, SpongeParams &p)
+{
+    const uint32_t w = (1600 - d) / 8;
+    std::vector<uint8_t> hdr;
+    left_encode(w, hdr);
+    left_encode((uint64_t)key_len * 8, hdr);
+    p.hdr_len = (uint32_t)hdr.size();
+    hdr.resize(16, 0);
+    p.hdr0 = p.hdr1 = 0;
+    for (int j = 0; j < 8; j++) {
+        p.hdr0 |= (uint64_t)hdr[j] << (8 * j);
+        p.hdr1 |= (uint64_t)hdr[8 + j] << (8 * j);
+    }
+    size_t z = p.hdr_len + key_len;
+    p.head_len = (uint32_t)(z + (w - z % w));
+    p.key_len = (uint32_t)key_len;
+}
+
+static int launch_sponge(int rw, const SpongeParams &p, hipStream_t s)
+{
+    if (p.n == 0) return CAPY_OK;
+    dim3 grid((unsigned)((p.n + 63) / 64)), block(64);
+    switch (rw) {
+    case 9: hipLaunchKernelGGL(sponge_kernel<9>, grid, block, 0, s, p); break;
+    case 13: hipLaunchKernelGGL(sponge_kernel<13>, grid, block, 0, s, p); break;
+    case 17: hipLaunchKernelGGL(sponge_kernel<17>, grid, block, 0, s, p); break;
+    case 18: hipLaunchKernelGGL(sponge_kernel<18>, grid, block, 0, s, p); break;
+    case 19: hipLaunchKernelGGL(sponge_kernel<19>, grid, block, 0, s, p); break;
+    case 21: hipLaunchKernelGGL(sponge_kernel<21>, grid, block, 0, s, p); break;
+    default: return fail(CAPY_ERR_ARG, "internal: unsupported rate");
+    }
+    CAPY_HIP(hipGetLastError());
+    return CAPY_OK;
+}
+
+// where the per-item message bytes live on the device
+struct MsgView {
+    const uint8_t *msgs = nullptr;
+    const uint64_t *offsets = nullptr;  // n+1 starts (or null: uniform)
+    const uint64_t *lens = nullptr;     // optional n lengths (re-packed batches)
+    uint64_t uniform_len = 0, msg_stride = 0;
+};
+
+static void body_args(SpongeParams &p, const MsgView &m)
+{
+    p.msgs = m.msgs;
+    p.offsets = m.offsets;
+    p.lens = m.lens;
+    p.uniform_len = m.uniform_len;
+    p.msg_stride = m.msg_stride;
+}
+
+// Stage the (D224-only) raw prefix bytes with the stream-ordered allocator, launch, release.
+static int launch_with_pre(int rw, SpongeParams &p, const std::vector<uint8_t> &pre_host, hipStream_t s)
+{
+    if (!pre_host.empty()) {
+        // the slot may still be read by an earlier launch on this stream: drain it before overwriting
+        CAPY_HIP(hipStreamSynchronize(s));
+        CAPY_WS(pre_dev, uint8_t *, s, WS_PRE, pre_host.size());
+        CAPY_HIP(hipMemcpy(pre_dev, pre_host.data(), pre_host.size(), hipMemcpyHostToDevice));
+        p.pre = pre_dev;
+    }
+    return launch_sponge(rw, p, s);
+}
+
+// A KMACXOF launch in all its forms (kmac_xof, shake_functions.rs:79-89): digest-style output
+// (out_mode 0) or in-place keystream XOR over the message buffer (out_mode 1, X = ""), optional mask.
+static int kmac_launch(int d, size_t n, const uint8_t *keys, size_t key_len, uint64_t key_stride, const MsgView &m,
+                       bool absorb_body, const uint8_t *custom, size_t custom_len, int out_mode, uint8_t *outs,
+                       uint64_t out_stride, size_t out_len, const int32_t *mask, hipStream_t s)
+{
+    if (!valid_d(d)) return fail(CAPY_ERR_UNSUPPORTED_SECPARAM, "unsupported security parameter");
+    if (key_len > (1u << 20)) return fail(CAPY_ERR_ARG, "key too long");
+    Framing f = cshake_framing(d);
+    SpongeParams p;
+    memset(&p, 0, sizeof p);
+    std::vector<uint8_t> pre_host;
+    cshake_prefix(d, (const uint8_t *)"KMAC", 4, custom, custom_len, f, p, pre_host);
+    kmac_head(d, key_len, p);
+    p.keys = keys;
+    p.key_stride = key_stride;
+    body_args(p, m);
+    p.absorb_body = absorb_body ? 1 : 0;
+    p.suffix = 0x040100ULL;  // right_encode(0) = 00 01 (shake_functions.rs:86), then cSHAKE suffix 0x04 (:57)
+    p.suffix_len = 3;
+    p.stride_bytes = f.stride;
+    p.out_mode = out_mode;
+    p.sq_words = f.sq_words;
+    p.out = outs;
+    p.out_stride = out_stride;
+    p.out_len = (uint32_t)out_len;
+    p.mask = mask;
+    p.n = n;
+    return launch_with_pre(f.rw, p, pre_host, s);
+}
+
+// SHA3-d (shake, shake_functions.rs:24-32)
+static int sha3_launch(int d, size_t n, const MsgView &m, uint8_t *digests, uint64_t out_stride, hipStream_t s)
+{
+    if (!valid_d(d)) return fail(CAPY_ERR_UNSUPPORTED_SECPARAM, "unsupported security parameter");
+    Framing f = sha3_framing(d);
+    SpongeParams p;
+    memset(&p, 0, sizeof p);
+    body_args(p, m);
+    p.absorb_body = 1;
+    p.suffix = 0x06;
+    p.suffix_len = 1;
+    p.sha3_suffix_rule = 1;  // shake_functions.rs:25-29
+    p.fips_pad = 0;          // sponge.rs:13: pad only when unaligned
+    p.stride_bytes = f.stride;
+    p.out_mode = 0;
+    p.sq_words = f.sq_words;
+    p.out = digests;
+    p.out_stride = out_stride;
+    p.out_len = (uint32_t)(d / 8);
+    p.n = n;
+    return launch_sponge(f.rw, p, s);
+}
+
+// cSHAKE (cshake, shake_functions.rs:49-64): N, S shared by the batch, no per-item head
+static int cshake_launch(int d, size_t n, const MsgView &m, size_t l_bits, const uint8_t *fn, size_t fn_len,
+                         const uint8_t *cs, size_t cs_len, uint8_t *outs, uint64_t out_stride, hipStream_t s)
+{
+    if (!valid_d(d)) return fail(CAPY_ERR_UNSUPPORTED_SECPARAM, "unsupported security parameter");
+    if (fn_len == 0 && cs_len == 0)
+        return fail(CAPY_ERR_UNSUPPORTED, "cshake with empty N and S (shake_functions.rs:59-61) is not exposed");
+    Framing f = cshake_framing(d);
+    SpongeParams p;
+    memset(&p, 0, sizeof p);
+    std::vector<uint8_t> pre_host;
+    cshake_prefix(d, fn, fn_len, cs, cs_len, f, p, pre_host);
+    body_args(p, m);
+    p.absorb_body = 1;
+    p.suffix = 0x04;
+    p.suffix_len = 1;
+    p.stride_bytes = f.stride;
+    p.out_mode = 0;
+    p.sq_words = f.sq_words;
+    p.out = outs;
+    p.out_stride = out_stride;
+    p.out_len = (uint32_t)(l_bits / 8);
+    p.n = n;
+    return launch_with_pre(f.rw, p, pre_host, s);
+}
+
+// device-side tag compare for decrypt: status[i] = tags match ? OK : FAIL
+__global__ void tag_compare_kernel(const uint8_t *a, const uint8_t *b, uint32_t tag_len, uint64_t a_stride,
+                                   uint64_t b_stride, int32_t *status, uint64_t n)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t diff = 0;
+    for (uint32_t j = 0; j < tag_len; j++) diff |= a[i * a_stride + j] ^ b[i * b_stride + j];
+    status[i] = diff ? CAPY_ITEM_FAIL : CAPY_ITEM_OK;
+}
+
+// dst[i] = a[i] || b[i]  (z || pw of sha3_encrypt, encryptable.rs:33-34)
+__global__ void concat_rows_kernel(uint8_t *dst, const uint8_t *a, uint32_t a_len, const uint8_t *b, uint32_t b_len,
+                                   uint64_t n)
+{
+    const uint64_t row = a_len + b_len;
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < n * row; i += stride) {
+        uint64_t r = i / row, c = i - r * row;
+        dst[i] = c < a_len ? a[r * a_len + c] : b[r * b_len + (c - a_len)];
+    }
+}
+
+// SplitMix64 counter-mode fill (harness PRNG)
+__global__ void fill_random_kernel(uint64_t *dst, uint64_t nwords, uint64_t seed)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < nwords; i += stride) {
+        uint64_t z = seed + (i + 1) * 0x9E3779B97F4A7C15ULL;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+        dst[i] = z ^ (z >> 31);
+    }
+}
+
+// VALU ceiling probe: `iters` dependent keccak-f[1600] per lane, nothing else.
+__global__ __launch_bounds__(64) void keccak_probe_kernel(uint64_t n_states, uint32_t iters, uint64_t *checksum)
+{
+    uint64_t id = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+    KState a;
+#pragma unroll
+    for (int i = 0; i < 25; i++) {
+        a.lo[i] = (uint32_t)(id * 25 + i);
+        a.hi[i] = (uint32_t)((id * 25 + i) * 0x9E3779B9u);
+    }
+    for (uint32_t it = 0; it < iters; it++) keccakf1600(a);
+    uint32_t x = 0, y = 0;
+#pragma unroll
+    for (int i = 0; i < 25; i++) {
+        x ^= a.lo[i];
+        y ^= a.hi[i];
+    }
+    if (id < n_states && x == 0x12345678u && y == 0x9abcdef0u)  // practically never: keeps the work alive
+        atomicXor((unsigned long long *)checksum, ((uint64_t)y << 32) | x);
+}
+
+// sha3_encrypt / sha3_decrypt on device buffers (src/sha3/encryptable.rs:29-83)
+static int sha3_crypt_dev(bool encrypt, int d, size_t n, const uint8_t *pws, size_t pw_len, const uint8_t *zs,
+                          const MsgView &m, uint8_t *tags, int32_t *status, hipStream_t s)
+{
+    if (!valid_d(d)) return fail(CAPY_ERR_UNSUPPORTED_SECPARAM, "unsupported security parameter");
+    if (n == 0) return CAPY_OK;
+    // z || pw per item (:33-34), then ke||ka = kmac_xof(z||pw, "", 1024, "S") (:36-37)
+    const size_t zk = 512 + pw_len;
+    CAPY_WS(zpw, uint8_t *, s, WS_ZPW, n * zk);
+    CAPY_WS(keka, uint8_t *, s, WS_KEKA, n * 128);
+    {
+        uint64_t tot = (uint64_t)n * zk;
+        unsigned blocks = (unsigned)std::min<uint64_t>((tot + 255) / 256, 8192);
+        hipLaunchKernelGGL(concat_rows_kernel, dim3(blocks), dim3(256), 0, s, zpw, zs, 512u, pws, (uint32_t)pw_len,
+                           (uint64_t)n);
+    }
+    MsgView none;
+    int rc = kmac_launch(d, n, zpw, zk, zk, none, true, (const uint8_t *)"S", 1, 0, keka, 128, 128, nullptr, s);
+    auto keystream = [&](const int32_t *mask) {  // msg ^= kmac_xof(ke, "", |msg|, "SKE")
+        return kmac_launch(d, n, keka, 64, 128, m, false, (const uint8_t *)"SKE", 3, 1, nullptr, 0, 0, mask, s);
+    };
+    auto tag = [&](uint8_t *out) {  // kmac_xof(ka, msg, 512, "SKA")
+        return kmac_launch(d, n, keka + 64, 64, 128, m, true, (const uint8_t *)"SKA", 3, 0, out, 64, 64, nullptr, s);
+    };
+    if (rc == CAPY_OK) {
+        if (encrypt) {
+            rc = tag(tags);  // tag over the plaintext first (:39), then keystream XOR (:41-42)
+            if (rc == CAPY_OK) rc = keystream(nullptr);
+        } else {
+            CAPY_WS(tag2, uint8_t *, s, WS_TAG2, n * 64);
+            rc = keystream(nullptr);  // ciphertext -> candidate plaintext (:71-73)
+            if (rc == CAPY_OK) rc = tag(tag2);
+            if (rc == CAPY_OK) {
+                hipLaunchKernelGGL(tag_compare_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, tags, tag2,
+                                   64u, (uint64_t)64, (uint64_t)64, status, (uint64_t)n);
+                rc = keystream(status);  // restore the ciphertext where the tag did not match (:80)
+            }
+        }
+    }
+    return rc;
+}
+
+// ------------------------------------------------------------------ PackedBatch
+int PackedBatch::upload(size_t n, const uint8_t *host_msgs, const uint64_t *host_offsets)
+{
+    h_starts.assign(n + 1, 0);
+    h_lens.assign(n ? n : 1, 0);
+    bool aligned = true;
+    for (size_t i = 0; i < n; i++) {
+        if (host_offsets[i + 1] < host_offsets[i]) return fail(CAPY_ERR_ARG, "offsets must be non-decreasing");
+        if ((host_offsets[i] - host_offsets[0]) & 7) aligned = false;
+        h_lens[i] = host_offsets[i + 1] - host_offsets[i];
+    }
+    repacked = !aligned;
+    std::vector<uint8_t> staging;
+    const uint8_t *src = host_msgs ? host_msgs + (n ? host_offsets[0] : 0) : nullptr;
+    if (aligned) {
+        for (size_t i = 0; i <= n; i++) h_starts[i] = host_offsets[i] - host_offsets[0];
+        total = h_starts[n];
+    } else {
+        uint64_t pos = 0;
+        for (size_t i = 0; i < n; i++) {
+            h_starts[i] = pos;
+            pos = (pos + h_lens[i] + 15) & ~15ULL;
+        }
+        h_starts[n] = pos;
+        total = pos;
+        staging.assign(total + 16, 0);
+        for (size_t i = 0; i < n; i++)
+            if (h_lens[i]) memcpy(staging.data() + h_starts[i], host_msgs + host_offsets[i], h_lens[i]);
+        src = staging.data();
+    }
+    CAPY_HIP(msgs.alloc(total + 16));
+    CAPY_HIP(starts.alloc((n + 1) * 8));
+    CAPY_HIP(lens.alloc((n ? n : 1) * 8));
+    if (total) CAPY_HIP(hipMemcpy(msgs.p, src, total, hipMemcpyHostToDevice));
+    CAPY_HIP(hipMemcpy(starts.p, h_starts.data(), (n + 1) * 8, hipMemcpyHostToDevice));
+    CAPY_HIP(hipMemcpy(lens.p, h_lens.data(), (n ? n : 1) * 8, hipMemcpyHostToDevice));
+    return CAPY_OK;
+}
+
+int PackedBatch::download(size_t n, uint8_t *host_msgs, const uint64_t *host_offsets) const
+{
+    if (!n || !total) return CAPY_OK;
+    if (!repacked) {
+        CAPY_HIP(hipMemcpy(host_msgs + host_offsets[0], msgs.p, total, hipMemcpyDeviceToHost));
+        return CAPY_OK;
+    }
+    std::vector<uint8_t> staging(total);
+    CAPY_HIP(hipMemcpy(staging.data(), msgs.p, total, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; i++)
+        if (h_lens[i]) memcpy(host_msgs + host_offsets[i], staging.data() + h_starts[i], h_lens[i]);
+    return CAPY_OK;
+}
+
+static MsgView view_of(const PackedBatch &b)
+{
+    MsgView m;
+    m.msgs = b.msgs.as<uint8_t>();
+    m.offsets = b.starts.as<uint64_t>();
+    m.lens = b.lens.as<uint64_t>();
+    return m;
+}
+
+static MsgView view_dev(const uint8_t *msgs, const uint64_t *offsets, uint64_t uniform_len, uint64_t msg_stride)
+{
+    MsgView m;
+    m.msgs = msgs;
+    m.offsets = offsets;
+    m.uniform_len = uniform_len;
+    m.msg_stride = msg_stride;
+    return m;
+}
+
+}  // namespace capy
+
+using namespace capy;
+
+extern "C" {
+
+const char *capy_last_error(void) { return capy::g_err.c_str(); }
+const char *capy_version(void) { return "capyhip 0.1 (gfx950)"; }
+
+int capy_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int capy_set_device(int device)
+{
+    CAPY_HIP(hipSetDevice(device));
+    return CAPY_OK;
+}
+
+int capy_device_synchronize(void)
+{
+    CAPY_HIP(hipDeviceSynchronize());
+    return CAPY_OK;
+}
+
+// ---------------------------------------------------------------- SHA3
+int capy_sha3_batch_dev(int d, size_t n, const uint8_t *msgs, const uint64_t *offsets, uint64_t uniform_len,
+                        uint64_t msg_stride, uint8_t *digests, void *stream)
+{
+    return sha3_launch(d, n, view_dev(msgs, offsets, uniform_len, msg_stride), digests, (uint64_t)(d / 8),
+                       (hipStream_t)stream);
+}
+
+int capy_sha3_batch(int d, size_t n, const uint8_t *msgs, const uint64_t *offsets, uint8_t *digests)
+{
+    if (!valid_d(d)) return fail(CAPY_ERR_UNSUPPORTED_SECPARAM, "unsupported security parameter");
+    if (n == 0) return CAPY_OK;
+    if (!offsets || !digests) return fail(CAPY_ERR_ARG, "null argument");
+    PackedBatch b;
+    int rc = b.upload(n, msgs, offsets);
+    if (rc) return rc;
+    DevBuf out;
+    const size_t dl = d / 8;
+    CAPY_HIP(out.alloc(n * dl));
+    rc = sha3_launch(d, n, view_of(b), out.as<uint8_t>(), dl, nullptr);
+    if (rc) return rc;
+    CAPY_HIP(hipMemcpy(digests, out.p, n * dl, hipMemcpyDeviceToHost));
+    return CAPY_OK;
+}
+
+// ---------------------------------------------------------------- cSHAKE / KMACXOF
+int capy_cshake_batch(int d, size_t n, const uint8_t *xs, const uint64_t *offsets, size_t l_bits,
+                      const uint8_t *fn_name, size_t fn_len, const uint8_t *custom, size_t custom_len, uint8_t *outs)
+{
+    if (!valid_d(d)) return fail(CAPY_ERR_UNSUPPORTED_SECPARAM, "unsupported security parameter");
+    if (n == 0) return CAPY_OK;
+    if (!offsets || !outs) return fail(CAPY_ERR_ARG, "null argument");
+    PackedBatch b;
+    int rc = b.upload(n, xs, offsets);
+    if (rc) return rc;
+    const size_t ol = l_bits / 8, os = (ol + 7) & ~(size_t)7;
+    DevBuf out;
+    CAPY_HIP(out.alloc(n * os));
+    rc = cshake_launch(d, n, view_of(b), l_bits, fn_name, fn_len, custom, custom_len, out.as<uint8_t>(), os, nullptr);
+    if (rc) return rc;
+    if (ol) CAPY_HIP(hipMemcpy2D(outs, ol, out.p, os, ol, n, hipMemcpyDeviceToHost));
+    return CAPY_OK;
+}
+
+int capy_kmac_xof_batch_dev(int d, size_t n, const uint8_t *keys, size_t key_len, uint64_t key_stride,
+                            const uint8_t *xs, const uint64_t *offsets, uint64_t uniform_len, uint64_t msg_stride,
+                            size_t l_bits, const uint8_t *custom, size_t custom_len, uint8_t *outs,
+                            uint64_t out_stride, void *stream)
+{
+    return kmac_launch(d, n, keys, key_len, key_stride, view_dev(xs, offsets, uniform_len, msg_stride), true, custom,
+                       custom_len, 0, outs, out_stride, l_bits / 8, nullptr, (hipStream_t)stream);
+}
+
+int capy_kmac_xof_batch(int d, size_t n, const uint8_t *keys, size_t key_len, const uint8_t *xs,
+                        const uint64_t *offsets, size_t l_bits, const uint8_t *custom, size_t custom_len, uint8_t *outs)
+{
+    if (!valid_d(d)) return fail(CAPY_ERR_UNSUPPORTED_SECPARAM, "unsupported security parameter");
+    if (n == 0) return CAPY_OK;
+    if (!outs) return fail(CAPY_ERR_ARG, "null argument");
+    std::vector<uint64_t> zero_off;
+    if (!offsets) {  // every x_i empty
+        zero_off.assign(n + 1, 0);
+        offsets = zero_off.data();
+    }
+    PackedBatch b;
+    int rc = b.upload(n, xs, offsets);
+    if (rc) return rc;
+    DevBuf k, out;
+    CAPY_HIP(k.alloc(n * key_len));
+    if (key_len) CAPY_HIP(hipMemcpy(k.p, keys, n * key_len, hipMemcpyHostToDevice));
+    const size_t ol = l_bits / 8, os = (ol + 7) & ~(size_t)7;
+    CAPY_HIP(out.alloc(n * os));
+    rc = kmac_launch(d, n, k.as<uint8_t>(), key_len, key_len, view_of(b), true, custom, custom_len, 0,
+                     out.as<uint8_t>(), os, ol, nullptr, nullptr);
+    if (rc) return rc;
+    if (ol) CAPY_HIP(hipMemcpy2D(outs, ol, out.p, os, ol, n, hipMemcpyDeviceToHost));
+    return CAPY_OK;
+}
+
+// ---------------------------------------------------------------- sha3_encrypt / sha3_decrypt
+int capy_sha3_encrypt_batch_dev(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint8_t *zs, uint8_t *msgs,
+                                const uint64_t *offsets, uint64_t uniform_len, uint64_t msg_stride, uint8_t *tags,
+                                void *stream)
+{
+    return sha3_crypt_dev(true, d, n, pws, pw_len, zs, view_dev(msgs, offsets, uniform_len, msg_stride), tags, nullptr,
+                          (hipStream_t)stream);
+}
+
+int capy_sha3_decrypt_batch_dev(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint8_t *zs, uint8_t *msgs,
+                                const uint64_t *offsets, uint64_t uniform_len, uint64_t msg_stride,
+                                const uint8_t *tags, int32_t *status, void *stream)
+{
+    return sha3_crypt_dev(false, d, n, pws, pw_len, zs, view_dev(msgs, offsets, uniform_len, msg_stride),
+                          const_cast<uint8_t *>(tags), status, (hipStream_t)stream);
+}
+
+static int sha3_crypt_host(bool encrypt, int d, size_t n, const uint8_t *pws, size_t pw_len, const uint8_t *zs,
+                           uint8_t *msgs, const uint64_t *offsets, uint8_t *tags, int32_t *status)
+{
+    if (!valid_d(d)) return fail(CAPY_ERR_UNSUPPORTED_SECPARAM, "unsupported security parameter");
+    if (n == 0) return CAPY_OK;
+    if (!offsets || !zs || !tags) return fail(CAPY_ERR_ARG, "null argument");
+    PackedBatch b;
+    int rc = b.upload(n, msgs, offsets);
+    if (rc) return rc;
+    DevBuf dpw, dz, dtag, dst;
+    CAPY_HIP(dpw.alloc(n * pw_len));
+    CAPY_HIP(dz.alloc(n * 512));
+    CAPY_HIP(dtag.alloc(n * 64));
+    CAPY_HIP(dst.alloc(n * 4));
+    if (pw_len) CAPY_HIP(hipMemcpy(dpw.p, pws, n * pw_len, hipMemcpyHostToDevice));
+    CAPY_HIP(hipMemcpy(dz.p, zs, n * 512, hipMemcpyHostToDevice));
+    if (!encrypt) CAPY_HIP(hipMemcpy(dtag.p, tags, n * 64, hipMemcpyHostToDevice));
+    rc = sha3_crypt_dev(encrypt, d, n, dpw.as<uint8_t>(), pw_len, dz.as<uint8_t>(), view_of(b), dtag.as<uint8_t>(),
+                        dst.as<int32_t>(), nullptr);
+    if (rc) return rc;
+    CAPY_HIP(hipStreamSynchronize(nullptr));
+    rc = b.download(n, msgs, offsets);
+    if (rc) return rc;
+    if (encrypt)
+        CAPY_HIP(hipMemcpy(tags, dtag.p, n * 64, hipMemcpyDeviceToHost));
+    else
+        CAPY_HIP(hipMemcpy(status, dst.p, n * 4, hipMemcpyDeviceToHost));
+    return CAPY_OK;
+}
+
+int capy_sha3_encrypt_batch(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint8_t *zs, uint8_t *msgs,
+                            const uint64_t *offsets, uint8_t *tags)
+{
+    return sha3_crypt_host(true, d, n, pws, pw_len, zs, msgs, offsets, tags, nullptr);
+}
+
+int capy_sha3_decrypt_batch(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint8_t *zs, uint8_t *msgs,
+                            const uint64_t *offsets, const uint8_t *tags, int32_t *status)
+{
+    if (!status) return fail(CAPY_ERR_ARG, "null status");
+    return sha3_crypt_host(false, d, n, pws, pw_len, zs, msgs, offsets, const_cast<uint8_t *>(tags), status);
+}
+
+// ---------------------------------------------------------------- measurement helpers
+int capy_fill_random_dev(uint8_t *dst, uint64_t nbytes, uint64_t seed, void *stream)
+{
+    if (((uintptr_t)dst & 7) || (nbytes & 7)) return fail(CAPY_ERR_ARG, "dst and nbytes must be multiples of 8");
+    if (!nbytes) return CAPY_OK;
+    hipLaunchKernelGGL(fill_random_kernel, dim3(4096), dim3(256), 0, (hipStream_t)stream, (uint64_t *)dst, nbytes / 8,
+                       seed);
+    CAPY_HIP(hipGetLastError());
+    return CAPY_OK;
+}
+
+int capy_keccak_valu_probe_dev(uint64_t n_states, uint32_t iters, uint64_t *checksum_dev, void *stream)
+{
+    if (!n_states) return CAPY_OK;
+    hipLaunchKernelGGL(keccak_probe_kernel, dim3((unsigned)((n_states + 63) / 64)), dim3(64), 0, (hipStream_t)stream,
+                       n_states, iters, checksum_dev);
+    CAPY_HIP(hipGetLastError());
+    return CAPY_OK;
+}
+
+}  // extern "C"

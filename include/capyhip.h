@@ -1,0 +1,138 @@
+/*
+ * capyhip.h — C ABI of libcapyhip.so: the MI355X (gfx950) batched crypto core that stands in for
+ * capyCRYPT's sponge and Ed448 hot path.  Plain pointers and sizes only; no torch / C++ types.
+ *
+ * The reference (Rust, /root/reference) has no FFI today: its seams are the Rust functions and
+ * traits cited on each entry point below.  A batch of 1 equals the reference's scalar call.
+ * The Rust-side binding a maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   d            security parameter 224 | 256 | 384 | 512        (SecParam, src/lib.rs:111-135)
+ *   msgs/offsets n messages packed in one buffer; message i is msgs[offsets[i] .. offsets[i+1]).
+ *                offsets has n+1 entries.  Start offsets that are multiples of 8 take the fast path.
+ *   scalars      56-byte BIG-endian, unreduced                   (src/sha3/aux_functions.rs:102-110)
+ *   points       affine (x, y), 2 x 56-byte little-endian canonical field elements (x first)
+ *   return       0 = ok, <0 = CAPY_ERR_*; capy_last_error() gives the text (thread local)
+ *   *_dev        same operation on buffers already resident in device memory, enqueued on `stream`
+ *                (a hipStream_t passed as void*, NULL = default stream), no host synchronisation.
+ *                Device message buffers must be 8-byte aligned; out buffers 8-byte aligned.
+ * All entry points are thread safe; no pointer is retained after return.  Randomness (nonces) is
+ * always an input so results are reproducible.
+ */
+#ifndef CAPYHIP_H
+#define CAPYHIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CAPY_OK 0
+#define CAPY_ERR_UNSUPPORTED_SECPARAM (-1) /* OperationError::UnsupportedSecurityParameter, src/lib.rs:10 */
+#define CAPY_ERR_ARG (-2)
+#define CAPY_ERR_HIP (-3)
+#define CAPY_ERR_UNSUPPORTED (-4)
+
+/* per-item status codes written by the *_decrypt / verify entry points */
+#define CAPY_ITEM_OK 0
+#define CAPY_ITEM_FAIL 1 /* SHA3DecryptionFailure / KeyDecryptionError / SignatureVerificationFailure */
+
+const char *capy_last_error(void);
+const char *capy_version(void);
+int capy_device_count(void);
+int capy_set_device(int device); /* device used by the calling thread's subsequent calls */
+int capy_device_synchronize(void);
+
+/* ------------------------------------------------------------------ sponge (src/sha3) */
+
+/* SHA3-d of n messages.  digests: n * d/8 bytes.
+ * Replaces shake(), src/sha3/shake_functions.rs:24-32, as called by
+ * SpongeHashable::compute_sha3_hash, src/sha3/hashable.rs:19-21 (bit-exact incl. its suffix rule). */
+int capy_sha3_batch(int d, size_t n, const uint8_t *msgs, const uint64_t *offsets, uint8_t *digests);
+int capy_sha3_batch_dev(int d, size_t n, const uint8_t *msgs, const uint64_t *offsets, uint64_t uniform_len,
+                        uint64_t msg_stride, uint8_t *digests, void *stream);
+
+/* cSHAKE: out_i = cshake(x_i, l_bits, N, S, d).  outs: n * l_bits/8 bytes.
+ * Replaces cshake(), src/sha3/shake_functions.rs:49-64 (capacity = d).  N = S = "" is rejected with
+ * CAPY_ERR_UNSUPPORTED (crate-internal corner, :59-61, unreachable through kmac_xof). */
+int capy_cshake_batch(int d, size_t n, const uint8_t *xs, const uint64_t *offsets, size_t l_bits,
+                      const uint8_t *fn_name, size_t fn_len, const uint8_t *custom, size_t custom_len,
+                      uint8_t *outs);
+
+/* KMACXOF: out_i = kmac_xof(key_i, x_i, l_bits, S, d); keys are n fixed-length keys of key_len bytes.
+ * Replaces kmac_xof(), src/sha3/shake_functions.rs:79-89 (pub), and
+ * SpongeHashable::compute_tagged_hash, src/sha3/hashable.rs:33-35 (l_bits = d). */
+int capy_kmac_xof_batch(int d, size_t n, const uint8_t *keys, size_t key_len, const uint8_t *xs,
+                        const uint64_t *offsets, size_t l_bits, const uint8_t *custom, size_t custom_len,
+                        uint8_t *outs);
+/* device form: keys at keys + i*key_stride; x_i via offsets or (uniform_len, msg_stride); x may be NULL
+ * with uniform_len = 0; outs at outs + i*out_stride (out_stride multiple of 8). */
+int capy_kmac_xof_batch_dev(int d, size_t n, const uint8_t *keys, size_t key_len, uint64_t key_stride,
+                            const uint8_t *xs, const uint64_t *offsets, uint64_t uniform_len,
+                            uint64_t msg_stride, size_t l_bits, const uint8_t *custom, size_t custom_len,
+                            uint8_t *outs, uint64_t out_stride, void *stream);
+
+/* SpongeEncryptable::sha3_encrypt, src/sha3/encryptable.rs:29-45.
+ * pws: n passwords of pw_len bytes; zs: n caller-supplied 512-byte nonces (the reference draws them
+ * from thread_rng, :31); msgs transformed in place to ciphertext; tags: n * 64 bytes. */
+int capy_sha3_encrypt_batch(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint8_t *zs,
+                            uint8_t *msgs, const uint64_t *offsets, uint8_t *tags);
+/* SpongeEncryptable::sha3_decrypt, src/sha3/encryptable.rs:58-83.  status[i] = CAPY_ITEM_OK and msg i
+ * holds the plaintext, or CAPY_ITEM_FAIL and msg i is restored to the ciphertext (:77-82). */
+int capy_sha3_decrypt_batch(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint8_t *zs,
+                            uint8_t *msgs, const uint64_t *offsets, const uint8_t *tags, int32_t *status);
+int capy_sha3_encrypt_batch_dev(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint8_t *zs,
+                                uint8_t *msgs, const uint64_t *offsets, uint64_t uniform_len,
+                                uint64_t msg_stride, uint8_t *tags, void *stream);
+int capy_sha3_decrypt_batch_dev(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint8_t *zs,
+                                uint8_t *msgs, const uint64_t *offsets, uint64_t uniform_len,
+                                uint64_t msg_stride, const uint8_t *tags, int32_t *status, void *stream);
+
+/* ------------------------------------------------------------------ Ed448 (tiny_ed448_goldilocks boundary) */
+
+/* out_i = [scalar_i] P_i  — `ExtendedPoint * Scalar` followed by to_affine()
+ * (call sites src/ecc/encryptable.rs:37,78; src/ecc/signable.rs:77). */
+int capy_ed448_scalarmul_batch(size_t n, const uint8_t *scalars_be, const uint8_t *points_xy, uint8_t *out_xy);
+int capy_ed448_scalarmul_batch_dev(size_t n, const uint8_t *scalars_be, const uint8_t *points_xy,
+                                   uint8_t *out_xy, void *stream);
+/* out_i = [scalar_i] G — `ExtendedPoint::generator() * Scalar`
+ * (src/ecc/keypair.rs:44, src/ecc/signable.rs:48,77, src/ecc/encryptable.rs:38). */
+int capy_ed448_basemul_batch(size_t n, const uint8_t *scalars_be, uint8_t *out_xy);
+int capy_ed448_basemul_batch_dev(size_t n, const uint8_t *scalars_be, uint8_t *out_xy, void *stream);
+/* out_i = P_i + Q_i — `ExtendedPoint + ExtendedPoint` (src/ecc/signable.rs:77) */
+int capy_ed448_add_batch(size_t n, const uint8_t *p_xy, const uint8_t *q_xy, uint8_t *out_xy);
+/* out_i = [a_i] G + [b_i] P_i in one pass (the shape of verify, src/ecc/signable.rs:77) */
+int capy_ed448_double_scalarmul_batch(size_t n, const uint8_t *a_be, const uint8_t *b_be,
+                                      const uint8_t *points_xy, uint8_t *out_xy);
+
+/* ------------------------------------------------------------------ src/ecc protocols */
+
+/* KeyPair::new, src/ecc/keypair.rs:41-51: pub_i = [4 * KMAC(pw_i,"",448,"SK",d) mod r] G */
+int capy_keypair_batch(int d, size_t n, const uint8_t *pws, size_t pw_len, uint8_t *pub_xy);
+/* Signable::sign, src/ecc/signable.rs:40-57.  h: n*56 bytes, z_be: n*56 bytes (big-endian scalar). */
+int capy_schnorr_sign_batch(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint8_t *msgs,
+                            const uint64_t *offsets, uint8_t *h, uint8_t *z_be);
+/* Signable::verify, src/ecc/signable.rs:72-86.  status[i] = CAPY_ITEM_OK | CAPY_ITEM_FAIL */
+int capy_schnorr_verify_batch(int d, size_t n, const uint8_t *pub_xy, const uint8_t *msgs,
+                              const uint64_t *offsets, const uint8_t *h, const uint8_t *z_be, int32_t *status);
+/* KeyEncryptable::key_encrypt, src/ecc/encryptable.rs:34-50.  k_rand: n caller-supplied 56-byte
+ * nonces (:36).  msgs -> ciphertext in place; z_xy: n*112 (asym_nonce); tags: n*56. */
+int capy_key_encrypt_batch(int d, size_t n, const uint8_t *pub_xy, const uint8_t *k_rand, uint8_t *msgs,
+                           const uint64_t *offsets, uint8_t *z_xy, uint8_t *tags);
+/* KeyEncryptable::key_decrypt, src/ecc/encryptable.rs:72-94 (restore-on-failure, :88-93). */
+int capy_key_decrypt_batch(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint8_t *z_xy,
+                           uint8_t *msgs, const uint64_t *offsets, const uint8_t *tags, int32_t *status);
+
+/* ------------------------------------------------------------------ measurement helpers */
+
+/* Fill a device buffer with the harness PRNG (SplitMix64 counter mode, seed + 8-byte word index). */
+int capy_fill_random_dev(uint8_t *dst, uint64_t nbytes, uint64_t seed, void *stream);
+/* Run `iters` back-to-back keccak-f[1600] on n lane-resident states (VALU ceiling probe); returns the
+ * XOR of all state words through *checksum_dev (8 bytes, device) so the work is not elided. */
+int capy_keccak_valu_probe_dev(uint64_t n_states, uint32_t iters, uint64_t *checksum_dev, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
