@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the hot path (BASELINE.json): GiB/s of SHA3-256 over batched
+5 MiB messages on N MI355X, plus Ed448 variable-base scalar-mults/s as secondary fields.
+
+  python bench.py --gpus N --steps K --warmup W
+For N > 1 the driver launches this file through torch.distributed.run (one rank per GPU, RCCL only
+for the timing barrier / max-reduce: the data path has no collective).
+
+A "step" = one pass of capy_sha3_batch_dev over this rank's batch of `--batch` x 5 MiB messages
+already resident in HBM (weak scaling: per-GPU work is fixed).  Inputs are synthetic (SplitMix64).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MSG_BYTES = 5242880  # benches/benchmark_sha3.rs:17
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+# VALU ceiling for keccak-f on gfx950: 4354 VALU lane-ops per 136-byte block,
+# 256 CU x 128 lanes/clk x 2.4 GHz = 78.6e12 lane-ops/s  ->  2.46 TB/s of absorbed message.
+VALU_CEIL_GBS = 78.6432e12 / 4354.0 * 136.0 / 1e9
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("CAPY_BENCH_BATCH", "32768")),
+                    help="5 MiB messages per GPU per step")
+    ap.add_argument("--ed448-pairs", type=int, default=1 << 18, help="(scalar, point) pairs per GPU (0 = skip)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(seconds):
+    """The oracle's scalar C SHA3-256 (a port of the reference algorithm; the Rust reference cannot
+    be built here) timed on one host core over a bounded sample of the same workload."""
+    import random
+
+    from oracle import oracle as O
+
+    lib = O.lib()
+    rng = random.Random(0xCA9C0001)
+    msg = rng.randbytes(MSG_BYTES)
+    buf = (C.c_uint8 * MSG_BYTES).from_buffer_copy(msg)
+    out = (C.c_uint8 * 32)()
+    n = 0
+    t0 = time.perf_counter()
+    while True:
+        lib.oracle_sha3(buf, C.c_size_t(MSG_BYTES), 256, 1, out, None, None)
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= seconds:
+            break
+    import hashlib
+
+    assert bytes(out) == hashlib.sha3_256(msg).digest()
+    return {
+        "value": n * MSG_BYTES / 2**30 / el,
+        "unit": "GiB/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": "%d x 5 MiB SHA3-256 on 1 host thread (%.1f s); host has %d cpus" % (n, el, os.cpu_count()),
+    }
+
+
+def cpu_baseline_ed448(seconds):
+    import random
+
+    from oracle import oracle as O
+
+    rng = random.Random(0xCA9C0004)
+    g = O.ed448_generator()
+    n = 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        O.ed448_scalarmul(rng.randbytes(56), g)
+        n += 1
+    return n / (time.perf_counter() - t0)
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world and world == 1 and a.gpus > 1:
+        print("bench.py: --gpus %d needs torch.distributed.run with %d ranks" % (a.gpus, a.gpus), file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from capycrypt_amd import _lib
+
+    lib = _lib.lib()
+    _lib.check(lib.capy_set_device(local_rank))
+    stream = torch.cuda.current_stream()
+    sp = C.c_void_p(stream.cuda_stream)
+
+    # ---- synthetic inputs resident in HBM
+    B = a.batch
+    free, _total = torch.cuda.mem_get_info()
+    while B > 64 and B * MSG_BYTES > free - (12 << 30):
+        B //= 2
+    msgs = torch.empty(B * MSG_BYTES, dtype=torch.uint8, device=dev)
+    digests = torch.empty(B * 32, dtype=torch.uint8, device=dev)
+    _lib.check(lib.capy_fill_random_dev(msgs.data_ptr(), B * MSG_BYTES, 0xCA9C0001 + rank, sp))
+    torch.cuda.synchronize()
+
+    def step():
+        _lib.check(lib.capy_sha3_batch_dev(256, B, msgs.data_ptr(), None, MSG_BYTES, MSG_BYTES, digests.data_ptr(), sp))
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    t0 = time.perf_counter()
+    for e0, e1 in evs:
+        e0.record(stream)
+        step()
+        e1.record(stream)
+    barrier()
+    el = time.perf_counter() - t0
+    kern_ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / max(1, a.steps)
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+
+    # spot-check parity of the timed outputs (first, middle, last message) against hashlib (FIPS 202 ==
+    # the reference for d=256 at every length)
+    import hashlib
+
+    dig = digests.cpu().numpy().tobytes()
+    for i in sorted({0, B // 2, B - 1}):
+        m = msgs[i * MSG_BYTES:(i + 1) * MSG_BYTES].cpu().numpy().tobytes()
+        assert dig[32 * i:32 * i + 32] == hashlib.sha3_256(m).digest(), "digest %d mismatch" % i
+
+    # ---- secondary: Ed448 variable-base scalar mults (config 4)
+    ed = None
+    if a.ed448_pairs:
+        n = a.ed448_pairs
+        sc = torch.empty(n * 56, dtype=torch.uint8, device=dev)
+        _lib.check(lib.capy_fill_random_dev(sc.data_ptr(), n * 56, 0xCA9C0004 + rank, sp))
+        # valid subgroup points: P_i = [t_i]G by the fixed-base kernel
+        tsc = torch.empty(n * 56, dtype=torch.uint8, device=dev)
+        _lib.check(lib.capy_fill_random_dev(tsc.data_ptr(), n * 56, 0xCA9C1004 + rank, sp))
+        pts = torch.empty(n * 112, dtype=torch.uint8, device=dev)
+        out = torch.empty(n * 112, dtype=torch.uint8, device=dev)
+        rc = lib.capy_ed448_basemul_batch_dev(n, tsc.data_ptr(), pts.data_ptr(), sp)
+        if rc == 0:
+            _lib.check(lib.capy_ed448_scalarmul_batch_dev(n, sc.data_ptr(), pts.data_ptr(), out.data_ptr(), sp))
+            barrier()
+            reps = 3
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t1 = time.perf_counter()
+            e0.record(stream)
+            for _ in range(reps):
+                _lib.check(lib.capy_ed448_scalarmul_batch_dev(n, sc.data_ptr(), pts.data_ptr(), out.data_ptr(), sp))
+            e1.record(stream)
+            barrier()
+            eel = time.perf_counter() - t1
+            if world > 1:
+                t = torch.tensor([eel], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                eel = float(t.item())
+            ed = {"pairs_per_gpu": n, "scalar_mults_per_s": world * n * reps / eel,
+                  "kernel_ms": e0.elapsed_time(e1) / reps}
+            if rank == 0:
+                from oracle import oracle as O
+
+                s_h = sc[:56 * 4].cpu().numpy().tobytes()
+                p_h = pts[:112 * 4].cpu().numpy().tobytes()
+                o_h = out[:112 * 4].cpu().numpy().tobytes()
+                for i in range(4):
+                    assert O.ed448_scalarmul(s_h[56 * i:56 * i + 56], p_h[112 * i:112 * i + 112]) == \
+                        o_h[112 * i:112 * i + 112], "ed448 mismatch"
+
+    if rank == 0:
+        total_bytes = world * B * MSG_BYTES * a.steps
+        value = total_bytes / 2**30 / el
+        algo_bytes = B * MSG_BYTES + B * 32  # read every message once + 32-byte digests
+        achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
+        res = {
+            "metric": "GiB/s SHA3-256 (5MB msgs)",
+            "value": value,
+            "unit": "GiB/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": el / a.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u64",
+            "data": "synthetic",
+            "config": {"workload": "sha3_256_batch: %d x 5 MiB messages per GPU, resident in HBM" % B,
+                       "batch_per_gpu": B, "msg_bytes": MSG_BYTES, "parallelism": "batch-sharded x%d, no collective" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "sponge_kernel<17>", "kernel_ms": kern_ms,
+                         "valu_ceiling_GBs": VALU_CEIL_GBS, "frac_of_valu_ceiling": achieved / VALU_CEIL_GBS},
+        }
+        if ed:
+            res["ed448_scalar_mults_per_s"] = ed["scalar_mults_per_s"]
+            res["ed448"] = ed
+        if not a.no_cpu_baseline and world == 1:
+            res["cpu_baseline"] = cpu_baseline(a.cpu_seconds)
+            if ed:
+                res["ed448"]["cpu_port_scalar_mults_per_s_1thread"] = cpu_baseline_ed448(min(5.0, a.cpu_seconds))
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
