@@ -1,17 +1,471 @@
-// TEMPORARY: Ed448 entry points not built yet (replaced by the real kernels next).
+// ed448.hip — Ed448 kernels, their C-ABI entry points, and the src/ecc protocol glue
+// (KeyPair::new, Signable, KeyEncryptable) composed from the sponge and curve kernels on device buffers.
+// No CPU fallback: every scalar multiplication, KMAC and mod-r operation of the data path runs on the GPU.
+#include <string.h>
+#include <mutex>
 #include "common.h"
-using namespace capy;
-#define NI return fail(CAPY_ERR_UNSUPPORTED, "ed448 path not built yet")
-extern "C" {
-int capy_ed448_scalarmul_batch(size_t, const uint8_t *, const uint8_t *, uint8_t *) { NI; }
-int capy_ed448_scalarmul_batch_dev(size_t, const uint8_t *, const uint8_t *, uint8_t *, void *) { NI; }
-int capy_ed448_basemul_batch(size_t, const uint8_t *, uint8_t *) { NI; }
-int capy_ed448_basemul_batch_dev(size_t, const uint8_t *, uint8_t *, void *) { NI; }
-int capy_ed448_add_batch(size_t, const uint8_t *, const uint8_t *, uint8_t *) { NI; }
-int capy_ed448_double_scalarmul_batch(size_t, const uint8_t *, const uint8_t *, const uint8_t *, uint8_t *) { NI; }
-int capy_keypair_batch(int, size_t, const uint8_t *, size_t, uint8_t *) { NI; }
-int capy_schnorr_sign_batch(int, size_t, const uint8_t *, size_t, const uint8_t *, const uint64_t *, uint8_t *, uint8_t *) { NI; }
-int capy_schnorr_verify_batch(int, size_t, const uint8_t *, const uint8_t *, const uint64_t *, const uint8_t *, const uint8_t *, int32_t *) { NI; }
-int capy_key_encrypt_batch(int, size_t, const uint8_t *, const uint8_t *, uint8_t *, const uint64_t *, uint8_t *, uint8_t *) { NI; }
-int capy_key_decrypt_batch(int, size_t, const uint8_t *, size_t, const uint8_t *, uint8_t *, const uint64_t *, const uint8_t *, int32_t *) { NI; }
+#include "ed448_algo.h"
+#include "sponge_host.h"
+
+namespace capy {
+
+#define CAPY_WS(var, type, stream, slot, bytes)                                 \
+    type var = reinterpret_cast<type>(capy::workspace(stream, slot, bytes));     \
+    if (!var) return capy::fail(CAPY_ERR_HIP, "workspace allocation failed")
+
+// ------------------------------------------------------------------ kernels (one item per lane)
+__global__ __launch_bounds__(64) void vb_kernel(uint64_t n, const uint8_t *scalars_be, uint64_t scalar_stride,
+                                                const uint8_t *points_xy, uint64_t point_stride, uint8_t *out_xy,
+                                                uint32_t *table_ws)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    const Pt P = pt_from_affine_bytes(points_xy + i * point_stride);
+    const Pt r = vb_scalarmul(scalars_be + i * scalar_stride, P, table_ws + i * VB_TABLE_DWORDS);
+    pt_to_affine_bytes(out_xy + i * 112, r);
 }
+
+__global__ __launch_bounds__(64) void fb_kernel(uint64_t n, const uint8_t *scalars_be, uint8_t *out_xy,
+                                                const uint32_t *gtab)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    pt_to_affine_bytes(out_xy + i * 112, fb_scalarmul(scalars_be + i * 56, gtab));
+}
+
+__global__ __launch_bounds__(64) void dsm_kernel(uint64_t n, const uint8_t *a_be, const uint8_t *b_be,
+                                                 const uint8_t *points_xy, uint8_t *out_xy, uint32_t *table_ws,
+                                                 const uint32_t *gtab)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    const Pt P = pt_from_affine_bytes(points_xy + i * 112);
+    const Pt r = double_scalarmul(a_be + i * 56, b_be + i * 56, P, table_ws + i * VB_TABLE_DWORDS, gtab);
+    pt_to_affine_bytes(out_xy + i * 112, r);
+}
+
+__global__ __launch_bounds__(64) void add_kernel(uint64_t n, const uint8_t *p_xy, const uint8_t *q_xy, uint8_t *out_xy)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    pt_to_affine_bytes(out_xy + i * 112, pt_add(pt_from_affine_bytes(p_xy + i * 112), pt_from_affine_bytes(q_xy + i * 112)));
+}
+
+// affine (x, y) -> fixed-base table entry (x, y, d*x*y) in limbs
+__global__ void gtab_pack_kernel(uint32_t n, const uint8_t *xy, uint32_t *gtab)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Fe x = fe_from_bytes(xy + (uint64_t)i * 112), y = fe_from_bytes(xy + (uint64_t)i * 112 + 56);
+    uint32_t *e = gtab + (uint64_t)i * FB_ENTRY_DWORDS;
+    store_fe(e, x);
+    store_fe(e + 16, y);
+    store_fe(e + 32, fe_mul_d(fe_mul(x, y)));
+}
+
+// out = 4 * in mod r  (56-byte BE in/out)   — `bytes_to_scalar(..).mul_mod(&Scalar::from(4))`
+__global__ void sc_mul4_kernel(uint64_t n, const uint8_t *in, uint8_t *out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t a[14], r[14];
+    sc_from_be(a, in + i * 56);
+    sc_mul4_mod(r, a);
+    sc_to_be(out + i * 56, r);
+}
+
+// z = k - h*s mod r   (src/ecc/signable.rs:54)
+__global__ void sc_sign_z_kernel(uint64_t n, const uint8_t *k_be, const uint8_t *h_be, const uint8_t *s_be, uint8_t *z_be)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t k[14], h[14], s[14], hs[14], z[14];
+    sc_from_be(k, k_be + i * 56);
+    sc_from_be(h, h_be + i * 56);
+    sc_from_be(s, s_be + i * 56);
+    sc_mul_mod(hs, h, s);
+    sc_sub_mod(z, k, hs);
+    sc_to_be(z_be + i * 56, z);
+}
+
+// ------------------------------------------------------------------ launchers
+static inline dim3 grid64(size_t n) { return dim3((unsigned)((n + 63) / 64)); }
+
+static int vb_launch(size_t n, const uint8_t *scalars, uint64_t scalar_stride, const uint8_t *points,
+                     uint64_t point_stride, uint8_t *out, hipStream_t s)
+{
+    if (!n) return CAPY_OK;
+    CAPY_WS(tab, uint32_t *, s, WS_TABLE, n * VB_TABLE_DWORDS * 4);
+    hipLaunchKernelGGL(vb_kernel, grid64(n), dim3(64), 0, s, (uint64_t)n, scalars, scalar_stride, points, point_stride,
+                       out, tab);
+    CAPY_HIP(hipGetLastError());
+    return CAPY_OK;
+}
+
+// The shared fixed-base table: row i, entry j = (j * 16^i mod r) * G, affine cached.  Built once per
+// device by running the variable-base kernel on G itself, then packed into limbs.
+static std::mutex g_gtab_mu;
+static uint32_t *g_gtab[64] = {nullptr};
+
+static const uint8_t G_XY[112] = {
+    0x5e, 0xc0, 0x0c, 0xc7, 0x2b, 0xa8, 0x26, 0x26, 0x8e, 0x93, 0x00, 0x8b, 0xe1, 0x80, 0x3b, 0x43, 0x11, 0x65, 0xb6,
+    0x2a, 0xf7, 0x1a, 0xae, 0x12, 0x64, 0xa4, 0xd3, 0xa3, 0x24, 0xe3, 0x6d, 0xea, 0x67, 0x17, 0x0f, 0x47, 0x70, 0x65,
+    0x14, 0x9e, 0xda, 0x36, 0xbf, 0x22, 0xa6, 0x15, 0x1d, 0x22, 0xed, 0x0d, 0xed, 0x6b, 0xc6, 0x70, 0x19, 0x4f,
+    0x14, 0xfa, 0x30, 0xf2, 0x5b, 0x79, 0x08, 0x98, 0xad, 0xc8, 0xd7, 0x4e, 0x2c, 0x13, 0xbd, 0xfd, 0xc4, 0x39, 0x7c,
+    0xe6, 0x1c, 0xff, 0xd3, 0x3a, 0xd7, 0xc2, 0xa0, 0x05, 0x1e, 0x9c, 0x78, 0x87, 0x40, 0x98, 0xa3, 0x6c, 0x73, 0x73,
+    0xea, 0x4b, 0x62, 0xc7, 0xc9, 0x56, 0x37, 0x20, 0x76, 0x88, 0x24, 0xbc, 0xb6, 0x6e, 0x71, 0x46, 0x3f, 0x69};
+
+static int ensure_gtab(const uint32_t **out)
+{
+    int dev = 0;
+    CAPY_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return fail(CAPY_ERR_ARG, "device index out of range");
+    std::lock_guard<std::mutex> lk(g_gtab_mu);
+    if (!g_gtab[dev]) {
+        const size_t n = FB_ROWS * 9;
+        std::vector<uint8_t> sc(n * 56), pts(n * 112);
+        uint32_t pw[14] = {1};  // 16^row mod r
+        for (int row = 0; row < FB_ROWS; row++) {
+            uint32_t acc[14] = {0};
+            for (int j = 0; j < 9; j++) {
+                sc_to_be(sc.data() + (size_t)(row * 9 + j) * 56, acc);
+                memcpy(pts.data() + (size_t)(row * 9 + j) * 112, G_XY, 112);
+                sc_add_mod(acc, pw);
+            }
+            for (int d = 0; d < 4; d++) sc_dbl_mod(pw);
+        }
+        DevBuf dsc, dpts, dout, dtab;
+        CAPY_HIP(dsc.alloc(sc.size()));
+        CAPY_HIP(dpts.alloc(pts.size()));
+        CAPY_HIP(dout.alloc(n * 112));
+        CAPY_HIP(dtab.alloc(n * VB_TABLE_DWORDS * 4));
+        CAPY_HIP(hipMemcpy(dsc.p, sc.data(), sc.size(), hipMemcpyHostToDevice));
+        CAPY_HIP(hipMemcpy(dpts.p, pts.data(), pts.size(), hipMemcpyHostToDevice));
+        uint32_t *gt = nullptr;
+        CAPY_HIP(hipMalloc((void **)&gt, (size_t)FB_TABLE_DWORDS * 4));
+        hipLaunchKernelGGL(vb_kernel, grid64(n), dim3(64), 0, nullptr, (uint64_t)n, dsc.as<uint8_t>(), (uint64_t)56,
+                           dpts.as<uint8_t>(), (uint64_t)112, dout.as<uint8_t>(), dtab.as<uint32_t>());
+        hipLaunchKernelGGL(gtab_pack_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, nullptr, (uint32_t)n,
+                           dout.as<uint8_t>(), gt);
+        CAPY_HIP(hipGetLastError());
+        CAPY_HIP(hipDeviceSynchronize());
+        g_gtab[dev] = gt;
+    }
+    *out = g_gtab[dev];
+    return CAPY_OK;
+}
+
+static int fb_launch(size_t n, const uint8_t *scalars, uint8_t *out, hipStream_t s)
+{
+    if (!n) return CAPY_OK;
+    const uint32_t *gt = nullptr;
+    int rc = ensure_gtab(&gt);
+    if (rc) return rc;
+    hipLaunchKernelGGL(fb_kernel, grid64(n), dim3(64), 0, s, (uint64_t)n, scalars, out, gt);
+    CAPY_HIP(hipGetLastError());
+    return CAPY_OK;
+}
+
+static int dsm_launch(size_t n, const uint8_t *a, const uint8_t *b, const uint8_t *points, uint8_t *out, hipStream_t s)
+{
+    if (!n) return CAPY_OK;
+    const uint32_t *gt = nullptr;
+    int rc = ensure_gtab(&gt);
+    if (rc) return rc;
+    CAPY_WS(tab, uint32_t *, s, WS_TABLE, n * VB_TABLE_DWORDS * 4);
+    hipLaunchKernelGGL(dsm_kernel, grid64(n), dim3(64), 0, s, (uint64_t)n, a, b, points, out, tab, gt);
+    CAPY_HIP(hipGetLastError());
+    return CAPY_OK;
+}
+
+static int sc_mul4_launch(size_t n, const uint8_t *in, uint8_t *out, hipStream_t s)
+{
+    if (!n) return CAPY_OK;
+    hipLaunchKernelGGL(sc_mul4_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, (uint64_t)n, in, out);
+    CAPY_HIP(hipGetLastError());
+    return CAPY_OK;
+}
+
+// s_i = 4 * KMAC(pw_i, "", 448, "SK", d) mod r   (keypair.rs:42-43, signable.rs:41-43, ecc/encryptable.rs:76-77)
+static int derive_s_dev(int d, size_t n, const uint8_t *pws, size_t pw_len, uint8_t *s_be, hipStream_t st)
+{
+    MsgView none;
+    int rc = kmac_launch(d, n, pws, pw_len, pw_len, none, true, (const uint8_t *)"SK", 2, 0, s_be, 56, 56, nullptr, st);
+    if (rc) return rc;
+    return sc_mul4_launch(n, s_be, s_be, st);
+}
+
+// ------------------------------------------------------------------ protocol glue on device buffers
+// Signable::sign, src/ecc/signable.rs:40-57
+static int sign_dev(int d, size_t n, const uint8_t *pws, size_t pw_len, const MsgView &m, uint8_t *h, uint8_t *z,
+                    hipStream_t st)
+{
+    CAPY_WS(s_be, uint8_t *, st, WS_A, n * 56);
+    CAPY_WS(k_be, uint8_t *, st, WS_B, n * 56);
+    CAPY_WS(U, uint8_t *, st, WS_C, n * 112);
+    int rc = derive_s_dev(d, n, pws, pw_len, s_be, st);
+    if (rc) return rc;
+    // k = 4 * KMAC(s_bytes, msg, 448, "N")  (`*` taken as arithmetic mod r)
+    rc = kmac_launch(d, n, s_be, 56, 56, m, true, (const uint8_t *)"N", 1, 0, k_be, 56, 56, nullptr, st);
+    if (rc) return rc;
+    rc = sc_mul4_launch(n, k_be, k_be, st);
+    if (rc) return rc;
+    rc = fb_launch(n, k_be, U, st);  // U = k*G, affine
+    if (rc) return rc;
+    // h = KMAC(U.x bytes, msg, 448, "T")
+    rc = kmac_launch(d, n, U, 56, 112, m, true, (const uint8_t *)"T", 1, 0, h, 56, 56, nullptr, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(sc_sign_z_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, (uint64_t)n, k_be, h, s_be, z);
+    CAPY_HIP(hipGetLastError());
+    return CAPY_OK;
+}
+
+// Signable::verify, src/ecc/signable.rs:72-86
+static int verify_dev(int d, size_t n, const uint8_t *pubs, const MsgView &m, const uint8_t *h, const uint8_t *z,
+                      int32_t *status, hipStream_t st)
+{
+    CAPY_WS(U, uint8_t *, st, WS_C, n * 112);
+    CAPY_WS(h2, uint8_t *, st, WS_A, n * 56);
+    int rc = dsm_launch(n, z, h, pubs, U, st);  // U = z*G + h*V
+    if (rc) return rc;
+    rc = kmac_launch(d, n, U, 56, 112, m, true, (const uint8_t *)"T", 1, 0, h2, 56, 56, nullptr, st);
+    if (rc) return rc;
+    tag_compare_launch(h, 56, h2, 56, 56, status, n, st);
+    CAPY_HIP(hipGetLastError());
+    return CAPY_OK;
+}
+
+// the symmetric half shared by key_encrypt / key_decrypt: (ke || ka) = KMAC(W.x, "", 896, "PK")
+static int pk_keys_dev(int d, size_t n, const uint8_t *W, uint8_t *keka, hipStream_t st)
+{
+    MsgView none;
+    return kmac_launch(d, n, W, 56, 112, none, true, (const uint8_t *)"PK", 2, 0, keka, 112, 112, nullptr, st);
+}
+static int pk_tag_dev(int d, size_t n, const uint8_t *keka, const MsgView &m, uint8_t *tag, hipStream_t st)
+{
+    return kmac_launch(d, n, keka + 56, 56, 112, m, true, (const uint8_t *)"PKA", 3, 0, tag, 56, 56, nullptr, st);
+}
+static int pk_keystream_dev(int d, size_t n, const uint8_t *keka, const MsgView &m, const int32_t *mask, hipStream_t st)
+{
+    return kmac_launch(d, n, keka, 56, 112, m, false, (const uint8_t *)"PKE", 3, 1, nullptr, 0, 0, mask, st);
+}
+
+// KeyEncryptable::key_encrypt, src/ecc/encryptable.rs:34-50
+static int key_encrypt_dev(int d, size_t n, const uint8_t *pubs, const uint8_t *k_rand, const MsgView &m, uint8_t *z_xy,
+                           uint8_t *tags, hipStream_t st)
+{
+    CAPY_WS(k_be, uint8_t *, st, WS_B, n * 56);
+    CAPY_WS(W, uint8_t *, st, WS_C, n * 112);
+    CAPY_WS(keka, uint8_t *, st, WS_D, n * 112);
+    int rc = sc_mul4_launch(n, k_rand, k_be, st);
+    if (rc) return rc;
+    rc = vb_launch(n, k_be, 56, pubs, 112, W, st);  // W = k*V
+    if (rc) return rc;
+    rc = fb_launch(n, k_be, z_xy, st);  // Z = k*G
+    if (rc) return rc;
+    rc = pk_keys_dev(d, n, W, keka, st);
+    if (rc) return rc;
+    rc = pk_tag_dev(d, n, keka, m, tags, st);  // tag over the plaintext (:43)
+    if (rc) return rc;
+    return pk_keystream_dev(d, n, keka, m, nullptr, st);
+}
+
+// KeyEncryptable::key_decrypt, src/ecc/encryptable.rs:72-94
+static int key_decrypt_dev(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint8_t *z_xy, const MsgView &m,
+                           const uint8_t *tags, int32_t *status, hipStream_t st)
+{
+    CAPY_WS(s_be, uint8_t *, st, WS_A, n * 56);
+    CAPY_WS(W, uint8_t *, st, WS_C, n * 112);
+    CAPY_WS(keka, uint8_t *, st, WS_D, n * 112);
+    CAPY_WS(tag2, uint8_t *, st, WS_E, n * 56);
+    int rc = derive_s_dev(d, n, pws, pw_len, s_be, st);
+    if (rc) return rc;
+    rc = vb_launch(n, s_be, 56, z_xy, 112, W, st);  // W = s*Z
+    if (rc) return rc;
+    rc = pk_keys_dev(d, n, W, keka, st);
+    if (rc) return rc;
+    rc = pk_keystream_dev(d, n, keka, m, nullptr, st);  // candidate plaintext
+    if (rc) return rc;
+    rc = pk_tag_dev(d, n, keka, m, tag2, st);
+    if (rc) return rc;
+    tag_compare_launch(tags, 56, tag2, 56, 56, status, n, st);
+    return pk_keystream_dev(d, n, keka, m, status, st);  // restore the ciphertext where the tag failed (:91)
+}
+
+static int up(DevBuf &b, const void *src, size_t bytes)
+{
+    CAPY_HIP(b.alloc(bytes));
+    if (bytes) CAPY_HIP(hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
+    return CAPY_OK;
+}
+static int down(void *dst, const DevBuf &b, size_t bytes)
+{
+    if (bytes) CAPY_HIP(hipMemcpy(dst, b.p, bytes, hipMemcpyDeviceToHost));
+    return CAPY_OK;
+}
+
+}  // namespace capy
+
+using namespace capy;
+
+#define TRY(x)            \
+    do {                  \
+        int _rc = (x);    \
+        if (_rc) return _rc; \
+    } while (0)
+
+extern "C" {
+
+// ---------------------------------------------------------------- raw curve operations
+int capy_ed448_scalarmul_batch_dev(size_t n, const uint8_t *scalars_be, const uint8_t *points_xy, uint8_t *out_xy,
+                                   void *stream)
+{
+    return vb_launch(n, scalars_be, 56, points_xy, 112, out_xy, (hipStream_t)stream);
+}
+
+int capy_ed448_scalarmul_batch(size_t n, const uint8_t *scalars_be, const uint8_t *points_xy, uint8_t *out_xy)
+{
+    if (!n) return CAPY_OK;
+    if (!scalars_be || !points_xy || !out_xy) return fail(CAPY_ERR_ARG, "null argument");
+    DevBuf s, p, o;
+    TRY(up(s, scalars_be, n * 56));
+    TRY(up(p, points_xy, n * 112));
+    CAPY_HIP(o.alloc(n * 112));
+    TRY(vb_launch(n, s.as<uint8_t>(), 56, p.as<uint8_t>(), 112, o.as<uint8_t>(), nullptr));
+    return down(out_xy, o, n * 112);
+}
+
+int capy_ed448_basemul_batch_dev(size_t n, const uint8_t *scalars_be, uint8_t *out_xy, void *stream)
+{
+    return fb_launch(n, scalars_be, out_xy, (hipStream_t)stream);
+}
+
+int capy_ed448_basemul_batch(size_t n, const uint8_t *scalars_be, uint8_t *out_xy)
+{
+    if (!n) return CAPY_OK;
+    if (!scalars_be || !out_xy) return fail(CAPY_ERR_ARG, "null argument");
+    DevBuf s, o;
+    TRY(up(s, scalars_be, n * 56));
+    CAPY_HIP(o.alloc(n * 112));
+    TRY(fb_launch(n, s.as<uint8_t>(), o.as<uint8_t>(), nullptr));
+    return down(out_xy, o, n * 112);
+}
+
+int capy_ed448_add_batch(size_t n, const uint8_t *p_xy, const uint8_t *q_xy, uint8_t *out_xy)
+{
+    if (!n) return CAPY_OK;
+    if (!p_xy || !q_xy || !out_xy) return fail(CAPY_ERR_ARG, "null argument");
+    DevBuf p, q, o;
+    TRY(up(p, p_xy, n * 112));
+    TRY(up(q, q_xy, n * 112));
+    CAPY_HIP(o.alloc(n * 112));
+    hipLaunchKernelGGL(add_kernel, grid64(n), dim3(64), 0, nullptr, (uint64_t)n, p.as<uint8_t>(), q.as<uint8_t>(),
+                       o.as<uint8_t>());
+    CAPY_HIP(hipGetLastError());
+    return down(out_xy, o, n * 112);
+}
+
+int capy_ed448_double_scalarmul_batch(size_t n, const uint8_t *a_be, const uint8_t *b_be, const uint8_t *points_xy,
+                                      uint8_t *out_xy)
+{
+    if (!n) return CAPY_OK;
+    if (!a_be || !b_be || !points_xy || !out_xy) return fail(CAPY_ERR_ARG, "null argument");
+    DevBuf a, b, p, o;
+    TRY(up(a, a_be, n * 56));
+    TRY(up(b, b_be, n * 56));
+    TRY(up(p, points_xy, n * 112));
+    CAPY_HIP(o.alloc(n * 112));
+    TRY(dsm_launch(n, a.as<uint8_t>(), b.as<uint8_t>(), p.as<uint8_t>(), o.as<uint8_t>(), nullptr));
+    return down(out_xy, o, n * 112);
+}
+
+// ---------------------------------------------------------------- src/ecc protocols (host buffers)
+int capy_keypair_batch(int d, size_t n, const uint8_t *pws, size_t pw_len, uint8_t *pub_xy)
+{
+    if (!valid_d(d)) return fail(CAPY_ERR_UNSUPPORTED_SECPARAM, "unsupported security parameter");
+    if (!n) return CAPY_OK;
+    if (!pub_xy) return fail(CAPY_ERR_ARG, "null argument");
+    DevBuf pw, s, o;
+    TRY(up(pw, pws, n * pw_len));
+    CAPY_HIP(s.alloc(n * 56));
+    CAPY_HIP(o.alloc(n * 112));
+    TRY(derive_s_dev(d, n, pw.as<uint8_t>(), pw_len, s.as<uint8_t>(), nullptr));
+    TRY(fb_launch(n, s.as<uint8_t>(), o.as<uint8_t>(), nullptr));
+    return down(pub_xy, o, n * 112);
+}
+
+int capy_schnorr_sign_batch(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint8_t *msgs,
+                            const uint64_t *offsets, uint8_t *h, uint8_t *z_be)
+{
+    if (!valid_d(d)) return fail(CAPY_ERR_UNSUPPORTED_SECPARAM, "unsupported security parameter");
+    if (!n) return CAPY_OK;
+    if (!offsets || !h || !z_be) return fail(CAPY_ERR_ARG, "null argument");
+    PackedBatch b;
+    TRY(b.upload(n, msgs, offsets));
+    DevBuf pw, dh, dz;
+    TRY(up(pw, pws, n * pw_len));
+    CAPY_HIP(dh.alloc(n * 56));
+    CAPY_HIP(dz.alloc(n * 56));
+    TRY(sign_dev(d, n, pw.as<uint8_t>(), pw_len, view_of(b), dh.as<uint8_t>(), dz.as<uint8_t>(), nullptr));
+    TRY(down(h, dh, n * 56));
+    return down(z_be, dz, n * 56);
+}
+
+int capy_schnorr_verify_batch(int d, size_t n, const uint8_t *pub_xy, const uint8_t *msgs, const uint64_t *offsets,
+                              const uint8_t *h, const uint8_t *z_be, int32_t *status)
+{
+    if (!valid_d(d)) return fail(CAPY_ERR_UNSUPPORTED_SECPARAM, "unsupported security parameter");
+    if (!n) return CAPY_OK;
+    if (!offsets || !h || !z_be || !status || !pub_xy) return fail(CAPY_ERR_ARG, "null argument");
+    PackedBatch b;
+    TRY(b.upload(n, msgs, offsets));
+    DevBuf pk, dh, dz, st;
+    TRY(up(pk, pub_xy, n * 112));
+    TRY(up(dh, h, n * 56));
+    TRY(up(dz, z_be, n * 56));
+    CAPY_HIP(st.alloc(n * 4));
+    TRY(verify_dev(d, n, pk.as<uint8_t>(), view_of(b), dh.as<uint8_t>(), dz.as<uint8_t>(), st.as<int32_t>(), nullptr));
+    return down(status, st, n * 4);
+}
+
+int capy_key_encrypt_batch(int d, size_t n, const uint8_t *pub_xy, const uint8_t *k_rand, uint8_t *msgs,
+                           const uint64_t *offsets, uint8_t *z_xy, uint8_t *tags)
+{
+    if (!valid_d(d)) return fail(CAPY_ERR_UNSUPPORTED_SECPARAM, "unsupported security parameter");
+    if (!n) return CAPY_OK;
+    if (!offsets || !pub_xy || !k_rand || !z_xy || !tags) return fail(CAPY_ERR_ARG, "null argument");
+    PackedBatch b;
+    TRY(b.upload(n, msgs, offsets));
+    DevBuf pk, kr, dz, dt;
+    TRY(up(pk, pub_xy, n * 112));
+    TRY(up(kr, k_rand, n * 56));
+    CAPY_HIP(dz.alloc(n * 112));
+    CAPY_HIP(dt.alloc(n * 56));
+    TRY(key_encrypt_dev(d, n, pk.as<uint8_t>(), kr.as<uint8_t>(), view_of(b), dz.as<uint8_t>(), dt.as<uint8_t>(), nullptr));
+    CAPY_HIP(hipStreamSynchronize(nullptr));
+    TRY(b.download(n, msgs, offsets));
+    TRY(down(z_xy, dz, n * 112));
+    return down(tags, dt, n * 56);
+}
+
+int capy_key_decrypt_batch(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint8_t *z_xy, uint8_t *msgs,
+                           const uint64_t *offsets, const uint8_t *tags, int32_t *status)
+{
+    if (!valid_d(d)) return fail(CAPY_ERR_UNSUPPORTED_SECPARAM, "unsupported security parameter");
+    if (!n) return CAPY_OK;
+    if (!offsets || !z_xy || !tags || !status) return fail(CAPY_ERR_ARG, "null argument");
+    PackedBatch b;
+    TRY(b.upload(n, msgs, offsets));
+    DevBuf pw, dz, dt, st;
+    TRY(up(pw, pws, n * pw_len));
+    TRY(up(dz, z_xy, n * 112));
+    TRY(up(dt, tags, n * 56));
+    CAPY_HIP(st.alloc(n * 4));
+    TRY(key_decrypt_dev(d, n, pw.as<uint8_t>(), pw_len, dz.as<uint8_t>(), view_of(b), dt.as<uint8_t>(), st.as<int32_t>(),
+                        nullptr));
+    CAPY_HIP(hipStreamSynchronize(nullptr));
+    TRY(b.download(n, msgs, offsets));
+    return down(status, st, n * 4);
+}
+
+}  // extern "C"

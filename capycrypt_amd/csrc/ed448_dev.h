@@ -1,0 +1,464 @@
+// ed448_dev.h — Ed448-Goldilocks field and point arithmetic for one (scalar, point) pair per lane.
+//
+// Stands in for the un-vendored crate tiny_ed448_goldilocks 0.1.8 at its call sites in
+// /root/reference/src/ecc: untwisted Edwards curve x^2+y^2 = 1 + d x^2 y^2,
+// d = -39081, p = 2^448 - 2^224 - 1 (RFC 7748 §4.2 / RFC 8032 §5.2).
+//
+// Field element: 16 limbs of 28 bits in 16 VGPRs (radix 2^28, little endian).  Products are
+// accumulated with v_mad_u64_u32 (32x32+64 -> 64 in one instruction; measured 1.2x the cost of
+// v_mul_lo_u32 on gfx950, tools/microbench.hip), schoolbook over the Goldilocks split
+// a = a0 + a1*phi, phi = 2^224, phi^2 = phi + 1:
+//     a*b = (a0b0 + a1b1) + (a0b1 + a1(b0+b1)) phi          -> 256 MADs, no 64-bit Karatsuba subtractions
+// north_star suggests u64 limbs with __umul64hi; on gfx950 a 64x64 product is 4 MADs plus carry
+// adds, so 28-bit limbs with lazy carries do the same multiplication in fewer, cheaper instructions.
+//
+// Everything is __host__ __device__ so the same code is unit-tested on the CPU (tests/test_ed448_host.py).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define CAPY_HD __host__ __device__
+
+namespace capy {
+
+struct Fe {
+    uint32_t l[16];
+};
+struct Pt {  // extended homogeneous coordinates, x = X/Z, y = Y/Z, T = XY/Z
+    Fe X, Y, Z, T;
+};
+
+constexpr uint32_t M28 = 0x0fffffffu;
+constexpr uint32_t ED448_D_ABS = 39081;  // d = -39081
+
+CAPY_HD inline Fe fe_zero()
+{
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < 16; i++) r.l[i] = 0;
+    return r;
+}
+CAPY_HD inline Fe fe_one()
+{
+    Fe r = fe_zero();
+    r.l[0] = 1;
+    return r;
+}
+
+// carry-save normalisation: limbs < 2^31 in, limbs <= 2^28 + 8 out (value unchanged mod p)
+CAPY_HD inline void fe_weak_reduce(Fe &r)
+{
+    uint32_t c[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        c[i] = r.l[i] >> 28;
+        r.l[i] &= M28;
+    }
+#pragma unroll
+    for (int i = 1; i < 16; i++) r.l[i] += c[i - 1];
+    r.l[0] += c[15];  // 2^448 = 2^224 + 1
+    r.l[8] += c[15];
+}
+
+CAPY_HD inline Fe fe_add(const Fe &a, const Fe &b)
+{
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < 16; i++) r.l[i] = a.l[i] + b.l[i];
+    fe_weak_reduce(r);
+    return r;
+}
+
+// a - b + 2p, limbs of b must be <= 2^28 + 8
+CAPY_HD inline Fe fe_sub(const Fe &a, const Fe &b)
+{
+    Fe r;
+#pragma unroll
+    // limbs of 2p: 2*(2^28-1), except limb 8 (weight 2^224) = 2*(2^28-2)
+    for (int i = 0; i < 16; i++) r.l[i] = a.l[i] + (i == 8 ? 2 * (M28 - 1) : 2 * M28) - b.l[i];
+    fe_weak_reduce(r);
+    return r;
+}
+
+CAPY_HD inline Fe fe_neg(const Fe &a) { return fe_sub(fe_zero(), a); }
+
+// 16 column sums (lo = columns 0..7, hi = 8..15), each < 2^63, to 28-bit limbs
+CAPY_HD inline Fe fe_from_columns(uint64_t lo[8], uint64_t hi[8])
+{
+    Fe r;
+    uint64_t c = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        uint64_t v = lo[k] + c;
+        r.l[k] = (uint32_t)v & M28;
+        c = v >> 28;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        uint64_t v = hi[k] + c;
+        r.l[8 + k] = (uint32_t)v & M28;
+        c = v >> 28;
+    }
+    // c * 2^448 = c * (2^224 + 1), c < 2^36
+    uint64_t v = r.l[0] + c;
+    r.l[0] = (uint32_t)v & M28;
+    v = r.l[1] + (v >> 28);
+    r.l[1] = (uint32_t)v & M28;
+    r.l[2] += (uint32_t)(v >> 28);
+    v = r.l[8] + c;
+    r.l[8] = (uint32_t)v & M28;
+    v = r.l[9] + (v >> 28);
+    r.l[9] = (uint32_t)v & M28;
+    r.l[10] += (uint32_t)(v >> 28);
+    return r;
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CAPY_NOINLINE __noinline__
+#else
+#define CAPY_NOINLINE
+#endif
+
+// r = a * b mod p.  Inputs: limbs <= 2^28 + 8.  256 MADs.
+CAPY_HD CAPY_NOINLINE inline Fe fe_mul(const Fe a, const Fe b)
+{
+    uint64_t lo[8], hi[8], qh[7];
+    uint32_t bs[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) bs[j] = b.l[j] + b.l[8 + j];
+#pragma unroll
+    for (int k = 0; k < 8; k++) lo[k] = hi[k] = 0;
+#pragma unroll
+    for (int k = 0; k < 7; k++) qh[k] = 0;
+    // P = a0 b0 + a1 b1 ; Q = a0 b1 + a1 (b0 + b1)
+    // result_lo[k] = P[k] + Q[k+8] ; result_hi[k] = P[k+8] + Q[k] + Q[k+8]
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int k = i + j;
+            const uint64_t p1 = (uint64_t)a.l[i] * b.l[j], p2 = (uint64_t)a.l[8 + i] * b.l[8 + j];
+            const uint64_t q1 = (uint64_t)a.l[i] * b.l[8 + j], q2 = (uint64_t)a.l[8 + i] * bs[j];
+            if (k < 8) {
+                lo[k] += p1;
+                lo[k] += p2;
+                hi[k] += q1;
+                hi[k] += q2;
+            } else {
+                hi[k - 8] += p1;
+                hi[k - 8] += p2;
+                qh[k - 8] += q1;
+                qh[k - 8] += q2;
+            }
+        }
+#pragma unroll
+    for (int k = 0; k < 7; k++) {
+        lo[k] += qh[k];
+        hi[k] += qh[k];
+    }
+    return fe_from_columns(lo, hi);
+}
+
+// r = a^2 mod p.  P = a0^2 + a1^2 ; Q = a1 (2 a0 + a1).  136 MADs.
+CAPY_HD CAPY_NOINLINE inline Fe fe_sqr(const Fe a)
+{
+    uint64_t lo[8], hi[8], qh[7];
+    uint32_t s[8], d0[8], d1[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        s[j] = 2 * a.l[j] + a.l[8 + j];  // < 2^30
+        d0[j] = 2 * a.l[j];
+        d1[j] = 2 * a.l[8 + j];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) lo[k] = hi[k] = 0;
+#pragma unroll
+    for (int k = 0; k < 7; k++) qh[k] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int k = i + j;
+            // P: symmetric, take i <= j with the doubled operand for i < j
+            if (i <= j) {
+                const uint64_t p1 = (uint64_t)(i < j ? d0[i] : a.l[i]) * a.l[j];
+                const uint64_t p2 = (uint64_t)(i < j ? d1[i] : a.l[8 + i]) * a.l[8 + j];
+                if (k < 8) {
+                    lo[k] += p1;
+                    lo[k] += p2;
+                } else {
+                    hi[k - 8] += p1;
+                    hi[k - 8] += p2;
+                }
+            }
+            const uint64_t q = (uint64_t)a.l[8 + i] * s[j];
+            if (k < 8)
+                hi[k] += q;
+            else
+                qh[k - 8] += q;
+        }
+#pragma unroll
+    for (int k = 0; k < 7; k++) {
+        lo[k] += qh[k];
+        hi[k] += qh[k];
+    }
+    return fe_from_columns(lo, hi);
+}
+
+// a * k for a small constant k < 2^17
+CAPY_HD inline Fe fe_mul_small(const Fe &a, uint32_t k)
+{
+    Fe r;
+    uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        uint64_t v = (uint64_t)a.l[i] * k + c;
+        r.l[i] = (uint32_t)v & M28;
+        c = v >> 28;
+    }
+    r.l[0] += (uint32_t)c;
+    r.l[8] += (uint32_t)c;
+    fe_weak_reduce(r);
+    return r;
+}
+
+CAPY_HD inline Fe fe_sqrn(Fe a, int n)
+{
+#pragma unroll 1
+    for (int i = 0; i < n; i++) a = fe_sqr(a);
+    return a;
+}
+
+// a^(p-2); p-2 = [223 ones][0][222 ones][0][1] in binary
+CAPY_HD inline Fe fe_inv(const Fe &a)
+{
+    Fe x2 = fe_mul(fe_sqr(a), a);
+    Fe x3 = fe_mul(fe_sqr(x2), a);
+    Fe x6 = fe_mul(fe_sqrn(x3, 3), x3);
+    Fe x9 = fe_mul(fe_sqrn(x6, 3), x3);
+    Fe x18 = fe_mul(fe_sqrn(x9, 9), x9);
+    Fe x19 = fe_mul(fe_sqr(x18), a);
+    Fe x37 = fe_mul(fe_sqrn(x19, 18), x18);
+    Fe x74 = fe_mul(fe_sqrn(x37, 37), x37);
+    Fe x111 = fe_mul(fe_sqrn(x74, 37), x37);
+    Fe x222 = fe_mul(fe_sqrn(x111, 111), x111);
+    Fe x223 = fe_mul(fe_sqr(x222), a);
+    Fe t = fe_mul(fe_sqrn(x223, 223), x222);
+    return fe_mul(fe_sqrn(t, 2), a);
+}
+
+// full reduction to the canonical representative in [0, p), limbs < 2^28
+CAPY_HD inline void fe_canon(Fe &r)
+{
+    // sequential carries (twice: the wrap of the top carry can ripple once more)
+#pragma unroll
+    for (int pass = 0; pass < 3; pass++) {
+        uint32_t c = 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            uint32_t v = r.l[i] + c;
+            r.l[i] = v & M28;
+            c = v >> 28;
+        }
+        r.l[0] += c;
+        r.l[8] += c;
+    }
+    // now 0 <= r < 2^448 (+ at most a limb overflow of 1 at l[0]/l[8], absorbed below); subtract p if r >= p:
+    // r >= p  <=>  r + 2^224 + 1 >= 2^448
+#pragma unroll
+    for (int rep = 0; rep < 2; rep++) {
+        uint32_t t[16], c = 1;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            uint32_t v = r.l[i] + c + (i == 8 ? 1u : 0u);
+            t[i] = v & M28;
+            c = v >> 28;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; i++) r.l[i] = c ? t[i] : r.l[i];
+    }
+}
+
+// 56 little-endian bytes <-> limbs (input need not be < p)
+CAPY_HD inline Fe fe_from_bytes(const uint8_t *in)
+{
+    uint32_t w[15];
+#pragma unroll
+    for (int i = 0; i < 14; i++)
+        w[i] = (uint32_t)in[4 * i] | ((uint32_t)in[4 * i + 1] << 8) | ((uint32_t)in[4 * i + 2] << 16) |
+               ((uint32_t)in[4 * i + 3] << 24);
+    w[14] = 0;
+    Fe r;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int bit = 28 * k, j = bit >> 5, s = bit & 31;
+        uint64_t v = ((uint64_t)w[j + 1] << 32) | w[j];
+        r.l[k] = (uint32_t)(v >> s) & M28;
+    }
+    return r;
+}
+
+CAPY_HD inline void fe_to_bytes(uint8_t *out, Fe a)
+{
+    fe_canon(a);
+    uint32_t w[14];
+#pragma unroll
+    for (int i = 0; i < 14; i++) w[i] = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int bit = 28 * k, j = bit >> 5, s = bit & 31;
+        uint64_t v = (uint64_t)a.l[k] << s;
+        w[j] |= (uint32_t)v;
+        if (j + 1 < 14) w[j + 1] |= (uint32_t)(v >> 32);
+    }
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        out[4 * i] = (uint8_t)w[i];
+        out[4 * i + 1] = (uint8_t)(w[i] >> 8);
+        out[4 * i + 2] = (uint8_t)(w[i] >> 16);
+        out[4 * i + 3] = (uint8_t)(w[i] >> 24);
+    }
+}
+
+CAPY_HD inline Fe fe_select(bool take_b, const Fe &a, const Fe &b)
+{
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < 16; i++) r.l[i] = take_b ? b.l[i] : a.l[i];
+    return r;
+}
+
+// ------------------------------------------------------------------ group law, a = 1, d = -39081
+CAPY_HD inline Pt pt_identity()
+{
+    Pt r;
+    r.X = fe_zero();
+    r.Y = fe_one();
+    r.Z = fe_one();
+    r.T = fe_zero();
+    return r;
+}
+
+// d * t = -39081 t
+CAPY_HD inline Fe fe_mul_d(const Fe &t) { return fe_neg(fe_mul_small(t, ED448_D_ABS)); }
+
+// Unified, complete addition (add-2008-hwcd).  q is given in "cached" form: (X2, Y2, Z2, d*T2).
+CAPY_HD inline Pt pt_add_cached(const Pt &p, const Fe &X2, const Fe &Y2, const Fe &Z2, const Fe &Td2)
+{
+    Fe A = fe_mul(p.X, X2);
+    Fe B = fe_mul(p.Y, Y2);
+    Fe C = fe_mul(p.T, Td2);
+    Fe D = fe_mul(p.Z, Z2);
+    Fe E = fe_mul(fe_add(p.X, p.Y), fe_add(X2, Y2));
+    E = fe_sub(fe_sub(E, A), B);
+    Fe F = fe_sub(D, C);
+    Fe G = fe_add(D, C);
+    Fe H = fe_sub(B, A);
+    Pt r;
+    r.X = fe_mul(E, F);
+    r.Y = fe_mul(G, H);
+    r.Z = fe_mul(F, G);
+    r.T = fe_mul(E, H);
+    return r;
+}
+
+CAPY_HD inline Pt pt_add(const Pt &p, const Pt &q) { return pt_add_cached(p, q.X, q.Y, q.Z, fe_mul_d(q.T)); }
+
+// Mixed addition with an affine precomputed point (x2, y2, d*x2*y2), Z2 = 1: 8 multiplications.
+CAPY_HD inline Pt pt_add_affine_cached(const Pt &p, const Fe &x2, const Fe &y2, const Fe &td2)
+{
+    Fe A = fe_mul(p.X, x2);
+    Fe B = fe_mul(p.Y, y2);
+    Fe C = fe_mul(p.T, td2);
+    Fe E = fe_mul(fe_add(p.X, p.Y), fe_add(x2, y2));
+    E = fe_sub(fe_sub(E, A), B);
+    Fe F = fe_sub(p.Z, C);
+    Fe G = fe_add(p.Z, C);
+    Fe H = fe_sub(B, A);
+    Pt r;
+    r.X = fe_mul(E, F);
+    r.Y = fe_mul(G, H);
+    r.Z = fe_mul(F, G);
+    r.T = fe_mul(E, H);
+    return r;
+}
+
+// Doubling (dbl-2008-hwcd, a = 1): 4 squarings + 4 multiplications (3 if T is not needed).
+template <bool WANT_T>
+CAPY_HD inline Pt pt_dbl(const Pt &p)
+{
+    Fe A = fe_sqr(p.X);
+    Fe B = fe_sqr(p.Y);
+    Fe C = fe_sqr(p.Z);
+    C = fe_add(C, C);
+    Fe E = fe_sqr(fe_add(p.X, p.Y));
+    E = fe_sub(fe_sub(E, A), B);
+    Fe G = fe_add(A, B);
+    Fe F = fe_sub(G, C);
+    Fe H = fe_sub(A, B);
+    Pt r;
+    r.X = fe_mul(E, F);
+    r.Y = fe_mul(G, H);
+    r.Z = fe_mul(F, G);
+    if (WANT_T)
+        r.T = fe_mul(E, H);
+    else
+        r.T = p.T;
+    return r;
+}
+
+CAPY_HD inline Pt pt_from_affine_bytes(const uint8_t *xy)
+{
+    Pt r;
+    r.X = fe_from_bytes(xy);
+    r.Y = fe_from_bytes(xy + 56);
+    r.Z = fe_one();
+    r.T = fe_mul(r.X, r.Y);
+    return r;
+}
+
+CAPY_HD inline void pt_to_affine_bytes(uint8_t *xy, const Pt &p)
+{
+    Fe zi = fe_inv(p.Z);
+    fe_to_bytes(xy, fe_mul(p.X, zi));
+    fe_to_bytes(xy + 56, fe_mul(p.Y, zi));
+}
+
+// ------------------------------------------------------------------ scalars
+// 56 big-endian bytes -> 14 little-endian 32-bit words
+CAPY_HD inline void sc_from_be(uint32_t w[14], const uint8_t *in)
+{
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        const uint8_t *b = in + 52 - 4 * i;
+        w[i] = ((uint32_t)b[0] << 24) | ((uint32_t)b[1] << 16) | ((uint32_t)b[2] << 8) | b[3];
+    }
+}
+CAPY_HD inline void sc_to_be(uint8_t *out, const uint32_t w[14])
+{
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        uint8_t *b = out + 52 - 4 * i;
+        b[0] = (uint8_t)(w[i] >> 24);
+        b[1] = (uint8_t)(w[i] >> 16);
+        b[2] = (uint8_t)(w[i] >> 8);
+        b[3] = (uint8_t)w[i];
+    }
+}
+
+// Signed radix-16 recoding: k = sum_{i<112} (nib_i - 8) 16^i + top 16^112 with nib = nibbles of
+// k + 0x88..8 (112 eights), top = the carry out of that addition.  Returns top; w is overwritten
+// with the biased nibbles.
+CAPY_HD inline uint32_t sc_recode_signed16(uint32_t w[14])
+{
+    uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        uint64_t v = (uint64_t)w[i] + 0x88888888u + c;
+        w[i] = (uint32_t)v;
+        c = v >> 32;
+    }
+    return (uint32_t)c;
+}
+
+}  // namespace capy

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include "common.h"
 #include "sponge_kernels.h"
+#include "sponge_host.h"
 
 namespace capy {
 
@@ -198,14 +199,6 @@ static int launch_sponge(int rw, const SpongeParams &p, hipStream_t s)
     return CAPY_OK;
 }
 
-// where the per-item message bytes live on the device
-struct MsgView {
-    const uint8_t *msgs = nullptr;
-    const uint64_t *offsets = nullptr;  // n+1 starts (or null: uniform)
-    const uint64_t *lens = nullptr;     // optional n lengths (re-packed batches)
-    uint64_t uniform_len = 0, msg_stride = 0;
-};
-
 static void body_args(SpongeParams &p, const MsgView &m)
 {
     p.msgs = m.msgs;
@@ -230,7 +223,7 @@ static int launch_with_pre(int rw, SpongeParams &p, const std::vector<uint8_t> &
 
 // A KMACXOF launch in all its forms (kmac_xof, shake_functions.rs:79-89): digest-style output
 // (out_mode 0) or in-place keystream XOR over the message buffer (out_mode 1, X = ""), optional mask.
-static int kmac_launch(int d, size_t n, const uint8_t *keys, size_t key_len, uint64_t key_stride, const MsgView &m,
+int kmac_launch(int d, size_t n, const uint8_t *keys, size_t key_len, uint64_t key_stride, const MsgView &m,
                        bool absorb_body, const uint8_t *custom, size_t custom_len, int out_mode, uint8_t *outs,
                        uint64_t out_stride, size_t out_len, const int32_t *mask, hipStream_t s)
 {
@@ -309,7 +302,7 @@ static int cshake_launch(int d, size_t n, const MsgView &m, size_t l_bits, const
 }
 
 // device-side tag compare for decrypt: status[i] = tags match ? OK : FAIL
-__global__ void tag_compare_kernel(const uint8_t *a, const uint8_t *b, uint32_t tag_len, uint64_t a_stride,
+__global__ void tag_compare_kernel_(const uint8_t *a, const uint8_t *b, uint32_t tag_len, uint64_t a_stride,
                                    uint64_t b_stride, int32_t *status, uint64_t n)
 {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -330,6 +323,13 @@ __global__ void concat_rows_kernel(uint8_t *dst, const uint8_t *a, uint32_t a_le
         uint64_t r = i / row, c = i - r * row;
         dst[i] = c < a_len ? a[r * a_len + c] : b[r * b_len + (c - a_len)];
     }
+}
+
+void tag_compare_launch(const uint8_t *a, uint64_t a_stride, const uint8_t *b, uint64_t b_stride, uint32_t tag_len,
+                        int32_t *status, size_t n, hipStream_t s)
+{
+    hipLaunchKernelGGL(tag_compare_kernel_, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, b, tag_len, a_stride,
+                       b_stride, status, (uint64_t)n);
 }
 
 // SplitMix64 counter-mode fill (harness PRNG)
@@ -399,8 +399,7 @@ static int sha3_crypt_dev(bool encrypt, int d, size_t n, const uint8_t *pws, siz
             rc = keystream(nullptr);  // ciphertext -> candidate plaintext (:71-73)
             if (rc == CAPY_OK) rc = tag(tag2);
             if (rc == CAPY_OK) {
-                hipLaunchKernelGGL(tag_compare_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, tags, tag2,
-                                   64u, (uint64_t)64, (uint64_t)64, status, (uint64_t)n);
+                tag_compare_launch(tags, 64, tag2, 64, 64, status, n, s);
                 rc = keystream(status);  // restore the ciphertext where the tag did not match (:80)
             }
         }
@@ -461,7 +460,7 @@ int PackedBatch::download(size_t n, uint8_t *host_msgs, const uint64_t *host_off
     return CAPY_OK;
 }
 
-static MsgView view_of(const PackedBatch &b)
+MsgView view_of(const PackedBatch &b)
 {
     MsgView m;
     m.msgs = b.msgs.as<uint8_t>();
@@ -470,7 +469,7 @@ static MsgView view_of(const PackedBatch &b)
     return m;
 }
 
-static MsgView view_dev(const uint8_t *msgs, const uint64_t *offsets, uint64_t uniform_len, uint64_t msg_stride)
+MsgView view_dev(const uint8_t *msgs, const uint64_t *offsets, uint64_t uniform_len, uint64_t msg_stride)
 {
     MsgView m;
     m.msgs = msgs;

@@ -1,0 +1,28 @@
+// sponge_host.h — internal launcher interface of the sponge path, shared with the Ed448 protocol glue.
+#pragma once
+#include "common.h"
+
+namespace capy {
+
+// where the per-item message bytes live on the device
+struct MsgView {
+    const uint8_t *msgs = nullptr;
+    const uint64_t *offsets = nullptr;  // n+1 starts (or null: uniform)
+    const uint64_t *lens = nullptr;     // optional n lengths (re-packed batches)
+    uint64_t uniform_len = 0, msg_stride = 0;
+};
+
+MsgView view_of(const PackedBatch &b);
+MsgView view_dev(const uint8_t *msgs, const uint64_t *offsets, uint64_t uniform_len, uint64_t msg_stride);
+
+// kmac_xof over device buffers (see sponge.hip). out_mode 0: out_len bytes per item at outs + i*out_stride;
+// out_mode 1: keystream XOR into the message buffer (absorb_body must be false). mask: optional per-item enable.
+int kmac_launch(int d, size_t n, const uint8_t *keys, size_t key_len, uint64_t key_stride, const MsgView &m,
+                bool absorb_body, const uint8_t *custom, size_t custom_len, int out_mode, uint8_t *outs,
+                uint64_t out_stride, size_t out_len, const int32_t *mask, hipStream_t s);
+
+// status[i] = (a_i == b_i) ? CAPY_ITEM_OK : CAPY_ITEM_FAIL
+void tag_compare_launch(const uint8_t *a, uint64_t a_stride, const uint8_t *b, uint64_t b_stride, uint32_t tag_len,
+                        int32_t *status, size_t n, hipStream_t s);
+
+}  // namespace capy

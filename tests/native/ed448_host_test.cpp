@@ -1,0 +1,91 @@
+// Host-side build of the SAME field / point / scalar code the HIP kernels run (ed448_dev.h and
+// ed448_algo.h are __host__ __device__), exported through a tiny C ABI so pytest can check it against
+// the oracle on a machine without a GPU.  Test infrastructure only.
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "../../capycrypt_amd/csrc/ed448_algo.h"
+using namespace capy;
+
+extern "C" {
+void ht_fe_mul(const uint8_t *a, const uint8_t *b, uint8_t *out) { fe_to_bytes(out, fe_mul(fe_from_bytes(a), fe_from_bytes(b))); }
+void ht_fe_sqr(const uint8_t *a, uint8_t *out) { fe_to_bytes(out, fe_sqr(fe_from_bytes(a))); }
+void ht_fe_add(const uint8_t *a, const uint8_t *b, uint8_t *out) { fe_to_bytes(out, fe_add(fe_from_bytes(a), fe_from_bytes(b))); }
+void ht_fe_sub(const uint8_t *a, const uint8_t *b, uint8_t *out) { fe_to_bytes(out, fe_sub(fe_from_bytes(a), fe_from_bytes(b))); }
+void ht_fe_inv(const uint8_t *a, uint8_t *out) { fe_to_bytes(out, fe_inv(fe_from_bytes(a))); }
+void ht_fe_roundtrip(const uint8_t *a, uint8_t *out) { fe_to_bytes(out, fe_from_bytes(a)); }
+// chained: ((a*b)^2 - a + b) * ... exercises lazily reduced operands
+void ht_fe_chain(const uint8_t *a, const uint8_t *b, int n, uint8_t *out)
+{
+    Fe x = fe_from_bytes(a), y = fe_from_bytes(b);
+    for (int i = 0; i < n; i++) {
+        Fe t = fe_mul(x, y);
+        Fe u = fe_sqr(fe_sub(t, x));
+        x = fe_add(fe_sub(u, y), fe_mul_small(t, 39081));
+        y = fe_sub(fe_neg(t), fe_add(u, u));
+    }
+    fe_to_bytes(out, fe_add(x, y));
+}
+void ht_scalarmul(const uint8_t *k_be, const uint8_t *p_xy, uint8_t *out_xy)
+{
+    std::vector<uint32_t> tab(VB_TABLE_DWORDS + 4);
+    uint32_t *t = (uint32_t *)(((uintptr_t)tab.data() + 15) & ~(uintptr_t)15);
+    Pt r = vb_scalarmul(k_be, pt_from_affine_bytes(p_xy), t);
+    pt_to_affine_bytes(out_xy, r);
+}
+void ht_add(const uint8_t *p, const uint8_t *q, uint8_t *out) { pt_to_affine_bytes(out, pt_add(pt_from_affine_bytes(p), pt_from_affine_bytes(q))); }
+void ht_dbl(const uint8_t *p, uint8_t *out) { pt_to_affine_bytes(out, pt_dbl<true>(pt_from_affine_bytes(p))); }
+void ht_sc_mul_mod(const uint8_t *a, const uint8_t *b, uint8_t *out)
+{
+    uint32_t x[14], y[14], r[14];
+    sc_from_be(x, a);
+    sc_from_be(y, b);
+    sc_mul_mod(r, x, y);
+    sc_to_be(out, r);
+}
+void ht_sc_sub_mod(const uint8_t *a, const uint8_t *b, uint8_t *out)
+{
+    uint32_t x[14], y[14], r[14];
+    sc_from_be(x, a);
+    sc_from_be(y, b);
+    sc_sub_mod(r, x, y);
+    sc_to_be(out, r);
+}
+void ht_sc_mul4_mod(const uint8_t *a, uint8_t *out)
+{
+    uint32_t x[14], r[14];
+    sc_from_be(x, a);
+    sc_mul4_mod(r, x);
+    sc_to_be(out, r);
+}
+// fixed-base table built on the host with the same entry format the device uses
+static std::vector<uint32_t> g_tab;
+static const uint32_t *gtab_aligned() { return (const uint32_t *)(((uintptr_t)g_tab.data() + 15) & ~(uintptr_t)15); }
+void ht_build_gtab(const uint8_t *g_xy)
+{
+    g_tab.assign(FB_TABLE_DWORDS + 4, 0);
+    uint32_t *t = (uint32_t *)gtab_aligned();
+    Pt base = pt_from_affine_bytes(g_xy);  // 16^row * G
+    for (int row = 0; row < FB_ROWS; row++) {
+        Pt acc = pt_identity();
+        for (int j = 0; j < 9; j++) {
+            uint8_t xy[112];
+            pt_to_affine_bytes(xy, acc);
+            Fe x = fe_from_bytes(xy), y = fe_from_bytes(xy + 56);
+            uint32_t *e = t + (row * 9 + j) * FB_ENTRY_DWORDS;
+            store_fe(e, x);
+            store_fe(e + 16, y);
+            store_fe(e + 32, fe_mul_d(fe_mul(x, y)));
+            acc = pt_add(acc, base);
+        }
+        for (int d = 0; d < 4; d++) base = pt_dbl<true>(base);
+    }
+}
+void ht_basemul(const uint8_t *k_be, uint8_t *out_xy) { pt_to_affine_bytes(out_xy, fb_scalarmul(k_be, gtab_aligned())); }
+void ht_double_scalarmul(const uint8_t *a_be, const uint8_t *b_be, const uint8_t *p_xy, uint8_t *out_xy)
+{
+    std::vector<uint32_t> tab(VB_TABLE_DWORDS + 4);
+    uint32_t *t = (uint32_t *)(((uintptr_t)tab.data() + 15) & ~(uintptr_t)15);
+    pt_to_affine_bytes(out_xy, double_scalarmul(a_be, b_be, pt_from_affine_bytes(p_xy), t, gtab_aligned()));
+}
+}
