@@ -61,6 +61,32 @@ class CapyHipError(RuntimeError):
         self.code = code
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so.7 / libhsa-runtime64.so.1 and load them by path.
+    Two HIP runtimes in one process cannot both own the GPU ("No HIP GPUs are available"), so when torch is
+    installed its copy is loaded first (RTLD_GLOBAL) and libcapyhip.so's DT_NEEDED entries bind to it by
+    SONAME.  Without torch the system ROCm runtime is used."""
+    import importlib.util
+    import sys
+
+    if "torch" in sys.modules:
+        return  # torch already loaded its runtime; ours will bind to it
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    d = os.path.join(os.path.dirname(spec.origin), "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = os.path.join(d, name)
+        if os.path.exists(path):
+            try:
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+            except OSError:
+                return
+
+
 def lib():
     """Load libcapyhip.so (loudly: no fallback)."""
     global _lib
@@ -70,6 +96,7 @@ def lib():
                 "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). capycrypt_amd has no CPU fallback." % LIB_PATH
             )
+        _share_hip_runtime_with_torch()
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)  # AttributeError if the library does not export a declared symbol

@@ -1,0 +1,96 @@
+"""CPU: the field / point / scalar code the HIP kernels run (capycrypt_amd/csrc/ed448_dev.h, ed448_algo.h are
+__host__ __device__) compiled for the host and checked against the oracle.  Needs hipcc (present here and on
+the GPU box); no GPU."""
+import ctypes as C
+import os
+import random
+import shutil
+import subprocess
+
+import pytest
+
+from oracle import ed448_ref as E
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "native", "ed448_host_test.cpp")
+SO = os.path.join(HERE, "native", "libed448host.so")
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+@pytest.fixture(scope="module")
+def L():
+    deps = [SRC] + [os.path.join(HERE, "..", "capycrypt_amd", "csrc", f) for f in ("ed448_dev.h", "ed448_algo.h")]
+    if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):
+        if not os.path.exists(HIPCC):
+            pytest.skip("hipcc not available")
+        subprocess.check_call([HIPCC, "-O2", "-std=c++17", "-fPIC", "-shared", "-x", "hip", "--offload-arch=gfx950",
+                               "-o", SO, SRC])
+    return C.CDLL(SO)
+
+
+def call(L, fn, *args, outlen=56):
+    out = (C.c_uint8 * outlen)()
+    getattr(L, fn)(*[C.c_char_p(a) if isinstance(a, bytes) else a for a in args], out)
+    return bytes(out)
+
+
+def fb(x):
+    return int(x % E.P).to_bytes(56, "little")
+
+
+def test_field_ops(L):
+    rng = random.Random(5)
+    edge = [0, 1, E.P - 1, E.P, E.P + 1, 2**448 - 1, 2**224, 2**224 - 1, E.P - 2, 2]
+    for i in range(200):
+        a = edge[i] if i < len(edge) else rng.getrandbits(448)
+        b = rng.getrandbits(448)
+        ab, bb = a.to_bytes(56, "little"), b.to_bytes(56, "little")
+        assert call(L, "ht_fe_mul", ab, bb) == fb(a * b)
+        assert call(L, "ht_fe_sqr", ab) == fb(a * a)
+        assert call(L, "ht_fe_add", ab, bb) == fb(a + b)
+        assert call(L, "ht_fe_sub", ab, bb) == fb(a - b)
+        assert call(L, "ht_fe_roundtrip", ab) == fb(a)
+    for _ in range(8):
+        a = rng.getrandbits(448) % E.P or 1
+        assert call(L, "ht_fe_inv", a.to_bytes(56, "little")) == fb(pow(a, -1, E.P))
+
+
+def test_lazy_reduction_chain(L):
+    rng = random.Random(6)
+    for _ in range(10):
+        a, b = rng.getrandbits(448), rng.getrandbits(448)
+        x, y = a % E.P, b % E.P
+        for _i in range(50):
+            t = x * y % E.P
+            u = (t - x) ** 2 % E.P
+            x, y = (u - y + t * 39081) % E.P, (-t - 2 * u) % E.P
+        out = (C.c_uint8 * 56)()
+        L.ht_fe_chain(a.to_bytes(56, "little"), b.to_bytes(56, "little"), 50, out)
+        assert bytes(out) == fb(x + y)
+
+
+def test_scalarmul_algorithms(L):
+    rng = random.Random(7)
+    G = E.pt_to_bytes(E.G)
+    L.ht_build_gtab(C.c_char_p(G))
+    specials = [0, 1, 2, 8, E.R, 2**448 - 1, int("8" * 112, 16), int("7" * 112, 16)]
+    for i in range(12):
+        k = specials[i] if i < len(specials) else rng.getrandbits(448)
+        P = E.G if i == 0 else E.scalarmul(rng.getrandbits(446), E.G)
+        assert call(L, "ht_scalarmul", E.sc_to_bytes(k), E.pt_to_bytes(P), outlen=112) == E.pt_to_bytes(E.scalarmul(k, P))
+        assert call(L, "ht_basemul", E.sc_to_bytes(k), outlen=112) == E.pt_to_bytes(E.scalarmul(k, E.G))
+    for _ in range(3):
+        a, b = rng.getrandbits(448), rng.getrandbits(448)
+        P = E.scalarmul(rng.getrandbits(446), E.G)
+        got = call(L, "ht_double_scalarmul", E.sc_to_bytes(a), E.sc_to_bytes(b), E.pt_to_bytes(P), outlen=112)
+        assert got == E.pt_to_bytes(E.add(E.scalarmul(a, E.G), E.scalarmul(b, P)))
+
+
+def test_scalar_field(L):
+    rng = random.Random(8)
+    for i in range(10):
+        a = [0, E.R, E.R - 1, 2**448 - 1][i] if i < 4 else rng.getrandbits(448)
+        b = rng.getrandbits(448)
+        assert call(L, "ht_sc_mul_mod", E.sc_to_bytes(a), E.sc_to_bytes(b)) == E.sc_to_bytes(a * b % E.R)
+        assert call(L, "ht_sc_sub_mod", E.sc_to_bytes(a), E.sc_to_bytes(b)) == E.sc_to_bytes((a - b) % E.R)
+        assert call(L, "ht_sc_mul4_mod", E.sc_to_bytes(a)) == E.sc_to_bytes(4 * a % E.R)

@@ -1,0 +1,175 @@
+"""GPU parity tests of the Ed448 path through the C ABI: committed golden vectors (python big-int model, pinned to
+RFC 8032 / RFC 7748), seeded parity vs the C oracle, group-law properties at full batch size, and the src/ecc
+protocol round-trips the reference's integration tests run (tests/integration_tests.rs:20-81,116-130,267-281)."""
+import json
+import os
+import random
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+MIB5 = 5242880
+
+
+@pytest.fixture(scope="module")
+def capy():
+    import capycrypt_amd
+
+    return capycrypt_amd
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+
+    return oracle
+
+
+@pytest.fixture(scope="module")
+def vectors():
+    with open(os.path.join(HERE, "golden", "ed448_vectors.json")) as f:
+        return json.load(f)
+
+
+def test_golden_scalarmul(capy, vectors):
+    v = vectors["scalarmul"]
+    got = capy.ops.ed448_scalarmul_batch([bytes.fromhex(t["k"]) for t in v], [bytes.fromhex(t["p"]) for t in v])
+    assert [g.hex() for g in got] == [t["out"] for t in v]
+
+
+def test_golden_sign_and_keypair(capy, vectors):
+    for d in (224, 256, 384, 512):
+        v = [t for t in vectors["sign"] if t["d"] == d]
+        for t in v:  # key / message lengths differ per vector: batches of one, as the reference API
+            kp = capy.KeyPair.new(bytes.fromhex(t["pw"]), "test key", d)
+            assert kp.pub_key.hex() == t["pub"]
+            m = capy.Message(bytes.fromhex(t["msg"]))
+            m.sign(kp, d)
+            assert (m.sig.h.hex(), m.sig.z.hex()) == (t["h"], t["z"])
+            m.verify(kp.pub_key)
+
+
+def test_rfc8032_public_key_via_gpu(capy):
+    """RFC 8032 §7.4 test 1: A = [s]B with s from SHAKE256(sk) clamped; encoding = y with the sign of x."""
+    import hashlib
+
+    with open(os.path.join(HERE, "golden", "rfc_ed448.json")) as f:
+        t = json.load(f)["rfc8032_7_4"][0]
+    h = bytearray(hashlib.shake_256(bytes.fromhex(t["secret"])).digest(114)[:57])
+    h[0] &= 0xFC
+    h[55] |= 0x80
+    h[56] = 0
+    s = int.from_bytes(h, "little")
+    xy = capy.ops.ed448_basemul_batch([s.to_bytes(56, "big")])[0]
+    enc = bytearray(xy[56:] + b"\0")
+    enc[56] |= (xy[0] & 1) << 7
+    assert bytes(enc).hex() == t["public"]
+
+
+def test_seeded_parity_vs_oracle(capy, O):
+    rng = random.Random(0xCA9C0004)
+    n = 200  # > 3 waves, ragged tail
+    sc = [rng.randbytes(56) for _ in range(n)]
+    sc[0], sc[1], sc[2] = bytes(56), bytes(55) + b"\x01", b"\xff" * 56
+    pts = [O.ed448_basemul(rng.randbytes(56)) for _ in range(n)]
+    assert capy.ops.ed448_scalarmul_batch(sc, pts) == [O.ed448_scalarmul(s, p) for s, p in zip(sc, pts)]
+    assert capy.ops.ed448_basemul_batch(sc) == [O.ed448_basemul(s) for s in sc]
+    assert capy.ops.ed448_add_batch(pts, pts[::-1]) == [O.ed448_add(p, q) for p, q in zip(pts, pts[::-1])]
+    a = [rng.randbytes(56) for _ in range(n)]
+    exp = [O.ed448_add(O.ed448_basemul(x), O.ed448_scalarmul(s, p)) for x, s, p in zip(a, sc, pts)]
+    assert capy.ops.ed448_double_scalarmul_batch(a, sc, pts) == exp
+
+
+def test_group_law_properties_large_batch(capy, O):
+    """Size-independent checks on a batch larger than the oracle could verify item by item:
+    [a]P + [b]P == [a+b]P, [r]P == identity, fixed-base == variable-base on G."""
+    from oracle import ed448_ref as E
+
+    rng = random.Random(77)
+    n = 4096
+    G = O.ed448_generator()
+    t = [rng.randbytes(56) for _ in range(n)]
+    P = capy.ops.ed448_basemul_batch(t)
+    assert P == capy.ops.ed448_scalarmul_batch(t, [G] * n)
+    a = [rng.getrandbits(440) for _ in range(n)]
+    b = [rng.getrandbits(440) for _ in range(n)]
+    aP = capy.ops.ed448_scalarmul_batch([E.sc_to_bytes(x) for x in a], P)
+    bP = capy.ops.ed448_scalarmul_batch([E.sc_to_bytes(x) for x in b], P)
+    abP = capy.ops.ed448_scalarmul_batch([E.sc_to_bytes(x + y) for x, y in zip(a, b)], P)
+    assert capy.ops.ed448_add_batch(aP, bP) == abP
+    ident = (0).to_bytes(56, "little") + (1).to_bytes(56, "little")
+    assert capy.ops.ed448_scalarmul_batch([E.sc_to_bytes(E.R)] * 256, P[:256]) == [ident] * 256
+    for i in (0, 1000, 4095):
+        assert O.ed448_on_curve(aP[i]) and aP[i] == O.ed448_scalarmul(E.sc_to_bytes(a[i]), P[i])
+
+
+@pytest.mark.parametrize("d", [256, 512])
+def test_schnorr_and_ecdhies_batches_vs_oracle(capy, O, d):
+    rng = random.Random(500 + d)
+    n = 70
+    pws = [rng.randbytes(16) for _ in range(n)]
+    msgs = [rng.randbytes(rng.choice((0, 1, 100, 133, 136, 137, 1000, 5000))) for _ in range(n)]
+    pubs = capy.ops.keypair_batch(pws, d)
+    assert pubs == [O.keypair_pub(p, d) for p in pws]
+    sigs = capy.ops.schnorr_sign_batch(pws, msgs, d)
+    assert sigs == [O.sign(p, m, d) for p, m in zip(pws, msgs)]
+    assert all(capy.ops.schnorr_verify_batch(pubs, msgs, sigs, d))
+    tampered = list(msgs)
+    tampered[5] += b"x"
+    ok = capy.ops.schnorr_verify_batch(pubs, tampered, sigs, d)
+    assert ok.count(False) == 1 and not ok[5]
+    kr = [rng.randbytes(56) for _ in range(n)]
+    cts, zs, tags = capy.ops.key_encrypt_batch(pubs, kr, msgs, d)
+    exp = [O.key_encrypt(pk, k, m, d) for pk, k, m in zip(pubs, kr, msgs)]
+    assert (cts, zs, tags) == ([e[0] for e in exp], [e[1] for e in exp], [e[2] for e in exp])
+    pts, ok = capy.ops.key_decrypt_batch(pws, zs, cts, tags, d)
+    assert all(ok) and pts == msgs
+    pws2 = list(pws)
+    pws2[7] = b"y" * 16
+    pts, ok = capy.ops.key_decrypt_batch(pws2, zs, cts, tags, d)
+    assert ok.count(False) == 1 and not ok[7] and pts[7] == cts[7] and pts[8] == msgs[8]
+
+
+# ---- the reference's integration tests, same shape (5 MiB random messages)
+@pytest.mark.parametrize("d,pwlen", [(256, 64), (512, 32)])
+def test_key_gen_enc_dec(capy, d, pwlen):
+    msg = capy.Message(capy.get_random_bytes(MIB5))
+    original = bytes(msg.msg)
+    key_pair = capy.KeyPair.new(capy.get_random_bytes(pwlen), "test key", capy.SecParam.try_from(d))
+    msg.key_encrypt(key_pair.pub_key, d)
+    assert bytes(msg.msg) != original
+    msg.key_decrypt(key_pair.priv_key)
+    assert bytes(msg.msg) == original
+
+
+@pytest.mark.parametrize("d", [256, 512])
+def test_signature(capy, d):
+    msg = capy.Message(capy.get_random_bytes(MIB5))
+    key_pair = capy.KeyPair.new(capy.get_random_bytes(64), "test key", capy.SecParam.try_from(d))
+    msg.sign(key_pair, d)
+    msg.verify(key_pair.pub_key)
+    msg.msg[12345] ^= 1
+    with pytest.raises(capy.OperationError) as e:
+        msg.verify(key_pair.pub_key)
+    assert e.value.variant == "SignatureVerificationFailure"
+
+
+def test_key_decrypt_handling_bad_input(capy):
+    new_msg = capy.Message(capy.get_random_bytes(125))
+    kp1 = capy.KeyPair.new(capy.get_random_bytes(32), "test key", capy.SecParam.D512)
+    kp2 = capy.KeyPair.new(capy.get_random_bytes(32), "test key", capy.SecParam.D512)
+    new_msg.key_encrypt(kp1.pub_key, capy.SecParam.D512)
+    before = bytes(new_msg.msg)
+    with pytest.raises(capy.OperationError) as e:
+        new_msg.key_decrypt(kp2.priv_key)
+    assert e.value.variant == "KeyDecryptionError" and bytes(new_msg.msg) == before
+
+
+def test_sig_timing_side_channel_shape(capy):
+    """tests/integration_tests.rs:137-156: sign with passwords of 1..512 bytes, verify each."""
+    for i in (1, 2, 64, 257, 512):
+        msg = capy.Message(capy.get_random_bytes(4096))
+        kp = capy.KeyPair.new(capy.get_random_bytes(i), "test key", capy.SecParam.D512)
+        msg.sign(kp, capy.SecParam.D512)
+        msg.verify(kp.pub_key)

@@ -1,0 +1,240 @@
+"""GPU parity tests of the sponge path, through the C ABI (capycrypt_amd -> libcapyhip.so), against
+ (1) the reference's own known-answer vectors (tests/golden/reference_kats.json),
+ (2) the CPU oracle on seeded inputs (bit-exact, reference quirks included),
+ (3) size-independent properties at BASELINE.json's full sizes (5 MiB messages).
+They read like the reference's tests (src/sha3/shake_functions.rs:92-288, tests/integration_tests.rs)."""
+import hashlib
+import random
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+MIB5 = 5242880
+
+
+@pytest.fixture(scope="module")
+def capy():
+    import capycrypt_amd
+
+    from capycrypt_amd import _lib
+
+    assert _lib.lib().capy_device_count() >= 1, "no GPU visible"
+    return capycrypt_amd
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+
+    return oracle
+
+
+# ---------------------------------------------------------------- (1) the reference's KATs, via the mirrored API
+def test_shake_kats_via_message(capy, kats):
+    for v in kats["sha3"]:  # test_shake_224/256/384/512, test_hashable
+        data = capy.Message(bytes.fromhex(v["msg_hex"]))
+        data.compute_sha3_hash(capy.SecParam.try_from(v["d"]))
+        assert data.digest.hex() == v["digest_hex"], v["src"]
+
+
+def test_compute_tagged_hash_kats(capy, kats):
+    for v in kats["tagged_hash"]:
+        data = capy.Message(bytes.fromhex(v["msg_hex"]))
+        data.compute_tagged_hash(bytes.fromhex(v["pw_hex"]), v["s"], capy.SecParam.try_from(v["d"]))
+        assert data.digest.hex() == v["digest_hex"], v["src"]
+
+
+def test_cshake_kats(capy, kats):
+    for v in kats["cshake"]:
+        res = capy.cshake(bytes.fromhex(v["x_hex"]), v["l_bits"], v["n"], v["s"], v["d"])
+        assert res.hex() == v["out_hex"], v["src"]
+
+
+def test_kmac_kats(capy, kats):
+    for v in kats["kmac_xof"]:
+        res = capy.kmac_xof(bytes.fromhex(v["k_hex"]), bytes.fromhex(v["x_hex"]), v["l_bits"], v["s"], v["d"])
+        assert res.hex() == v["out_hex"], v["src"]
+
+
+def test_compute_sha3_hash_leaves_padding_in_msg(capy, O):
+    m = capy.Message(b"test")
+    m.compute_sha3_hash(capy.SecParam.D256)
+    assert bytes(m.msg) == O.sha3(b"test", 256, want_padded=True)[1]
+
+
+# ---------------------------------------------------------------- (2) seeded parity vs the oracle
+LENS = [0, 1, 7, 8, 9, 63, 64, 71, 72, 73, 103, 104, 105, 135, 136, 137, 143, 144, 145, 151, 152, 165, 166, 167,
+        168, 169, 171, 172, 173, 271, 272, 273, 335, 336, 337, 343, 344, 500, 1000, 4096, 10000, 70001]
+
+
+@pytest.mark.parametrize("d", [224, 256, 384, 512])
+def test_sha3_matches_oracle_all_lengths(capy, O, d):
+    rng = random.Random(d)
+    msgs = [rng.randbytes(n) for n in LENS + list(range(0, 300, 1))]
+    assert capy.ops.sha3_batch(msgs, d) == [O.sha3(m, d) for m in msgs]
+
+
+def test_sha3_256_is_fips202(capy):
+    rng = random.Random(1)
+    msgs = [rng.randbytes(n) for n in range(0, 700, 3)]
+    assert capy.ops.sha3_batch(msgs, 256) == [hashlib.sha3_256(m).digest() for m in msgs]
+
+
+@pytest.mark.parametrize("d", [224, 256, 384, 512])
+def test_kmac_xof_matches_oracle(capy, O, d):
+    rng = random.Random(100 + d)
+    msgs = [rng.randbytes(n) for n in LENS]
+    for klen, lbits, s in ((0, 256, b""), (32, 512, b"My Tagged Application"), (64, 8192, b"SKE"), (576, 1024, b"S"),
+                           (131, 448, b"T")):
+        keys = [rng.randbytes(klen) for _ in msgs]
+        got = capy.ops.kmac_xof_batch(keys, msgs, lbits, s, d)
+        assert got == [O.kmac_xof(k, m, lbits, s, d) for k, m in zip(keys, msgs)], (klen, lbits)
+
+
+@pytest.mark.parametrize("d", [224, 256, 384, 512])
+def test_cshake_matches_oracle(capy, O, d):
+    rng = random.Random(200 + d)
+    msgs = [rng.randbytes(n) for n in LENS]
+    for n, s, l in ((b"", b"Email Signature", 256), (b"KMAC", b"x" * 200, 2048), (b"fn", b"", 8)):
+        assert capy.ops.cshake_batch(msgs, l, n, s, d) == [O.cshake(m, l, n, s, d) for m in msgs]
+
+
+def test_cshake_empty_n_and_s_is_rejected(capy):
+    from capycrypt_amd._lib import CapyHipError
+
+    with pytest.raises(CapyHipError) as e:
+        capy.ops.cshake_batch([b"abc"], 256, b"", b"", 256)
+    assert e.value.code == -4
+
+
+def test_unsupported_security_parameter(capy):
+    from capycrypt_amd._lib import CapyHipError
+
+    with pytest.raises(CapyHipError) as e:
+        capy.ops.sha3_batch([b"abc"], 300)
+    assert e.value.code == -1
+    with pytest.raises(capy.OperationError):
+        capy.Message(b"x").compute_sha3_hash(300)
+
+
+def test_empty_batch_and_empty_messages(capy, O):
+    assert capy.ops.sha3_batch([], 256) == []
+    assert capy.ops.kmac_xof_batch([], [], 256, b"", 256) == []
+    assert capy.ops.sha3_batch([b""] * 130, 512) == [O.sha3(b"", 512)] * 130
+
+
+@pytest.mark.parametrize("d", [224, 256, 384, 512])
+def test_sha3_encrypt_decrypt_matches_oracle(capy, O, d):
+    rng = random.Random(300 + d)
+    msgs = [rng.randbytes(n) for n in LENS]
+    pws = [rng.randbytes(64) for _ in msgs]
+    zs = [rng.randbytes(512) for _ in msgs]
+    cts, tags = capy.ops.sha3_encrypt_batch(pws, zs, msgs, d)
+    exp = [O.sha3_encrypt(p, z, m, d) for p, z, m in zip(pws, zs, msgs)]
+    assert cts == [e[0] for e in exp] and tags == [e[1] for e in exp]
+    pts, ok = capy.ops.sha3_decrypt_batch(pws, zs, cts, tags, d)
+    assert all(ok) and pts == msgs
+    # wrong password on some items -> Err and ciphertext restored (tests/integration_tests.rs:250-262)
+    pws2 = list(pws)
+    for i in (0, 5, len(msgs) - 1):
+        pws2[i] = rng.randbytes(64)
+    pts, ok = capy.ops.sha3_decrypt_batch(pws2, zs, cts, tags, d)
+    for i in range(len(msgs)):
+        if i in (0, 5, len(msgs) - 1):
+            assert not ok[i] and pts[i] == cts[i]
+        else:
+            assert ok[i] and pts[i] == msgs[i]
+
+
+def test_sha3_decrypt_handling_bad_input_like_reference(capy):
+    pw1, pw2 = capy.get_random_bytes(64), capy.get_random_bytes(64)
+    new_msg = capy.Message(capy.get_random_bytes(523))
+    new_msg.sha3_encrypt(pw1, capy.SecParam.D512)
+    msg2 = bytes(new_msg.msg)
+    with pytest.raises(capy.OperationError) as e:
+        new_msg.sha3_decrypt(pw2)
+    assert e.value.variant == "SHA3DecryptionFailure" and bytes(new_msg.msg) == msg2
+
+
+def test_batch_of_one_equals_batch_of_many(capy):
+    rng = random.Random(9)
+    msgs = [rng.randbytes(rng.randrange(0, 3000)) for _ in range(200)]
+    many = capy.ops.sha3_batch(msgs, 256)
+    for i in (0, 1, 63, 64, 65, 199):
+        assert capy.ops.sha3_batch([msgs[i]], 256)[0] == many[i]
+
+
+def test_config2_keystream_units(capy, O):
+    """BASELINE config 2: unit = kmac_xof(k, "", 8192 bits, "SKE", D512), 64-byte keys."""
+    rng = random.Random(0xCA9C0002)
+    keys = [rng.randbytes(64) for _ in range(4096)]
+    got = capy.ops.kmac_xof_batch(keys, [b""] * len(keys), 8192, b"SKE", 512)
+    for i in list(range(0, 4096, 97)) + [4095]:
+        assert got[i] == O.kmac_xof(keys[i], b"", 8192, b"SKE", 512)
+    assert len(set(got)) == len(got)
+
+
+# ---------------------------------------------------------------- device-pointer API, unaligned inputs
+def test_dev_api_unaligned_and_strided(capy, O):
+    import ctypes as C
+
+    import torch
+
+    from capycrypt_amd import _lib
+
+    lib = _lib.lib()
+    rng = random.Random(11)
+    L, n = 1000, 100
+    for shift in (0, 1, 3, 8):
+        stride = 1024 + (8 if shift == 8 else 0)
+        raw = bytearray(rng.randbytes(shift + n * stride))
+        t = torch.tensor(list(raw), dtype=torch.uint8, device="cuda")
+        out = torch.zeros(n * 32, dtype=torch.uint8, device="cuda")
+        _lib.check(lib.capy_sha3_batch_dev(256, n, t.data_ptr() + shift, None, L, stride, out.data_ptr(), None))
+        torch.cuda.synchronize()
+        got = bytes(out.cpu().numpy())
+        for i in range(n):
+            m = bytes(raw[shift + i * stride: shift + i * stride + L])
+            assert got[32 * i:32 * i + 32] == O.sha3(m, 256), (shift, i)
+
+
+# ---------------------------------------------------------------- (3) full-size properties (5 MiB messages)
+def test_config1_sha3_256_of_5mib(capy, O):
+    rng = random.Random(0xCA9C0001)
+    msg = rng.randbytes(MIB5)
+    m = capy.Message(msg)
+    m.compute_sha3_hash(capy.SecParam.D256)
+    assert m.digest == hashlib.sha3_256(msg).digest() == O.sha3(msg, 256)
+
+
+def test_5mib_batch_order_and_independence(capy):
+    rng = random.Random(5)
+    base = rng.randbytes(MIB5)
+    msgs = []
+    for i in range(70):  # more than one wave, ragged around 5 MiB
+        cut = MIB5 - (i % 5) * 137
+        msgs.append(base[:cut - 1] + bytes([i]))
+    got = capy.ops.sha3_batch(msgs, 256)
+    assert len(set(got)) == 70
+    for i in (0, 33, 69):
+        assert got[i] == hashlib.sha3_256(msgs[i]).digest()
+
+
+def test_config3_encrypt_roundtrip_5mib(capy, O):
+    """sha3_encrypt over 5 MiB messages (test_symmetric_encryptable / benchmark sym_enc): tag and first/last
+    ciphertext blocks against the oracle for one message, round-trip + wrong-password restore for all."""
+    rng = random.Random(0xCA9C0003)
+    n = 6
+    msgs = [rng.randbytes(MIB5 - i) for i in range(n)]
+    pws = [rng.randbytes(64) for _ in range(n)]
+    zs = [rng.randbytes(512) for _ in range(n)]
+    cts, tags = capy.ops.sha3_encrypt_batch(pws, zs, msgs, 512)
+    ect, etag = O.sha3_encrypt(pws[0], zs[0], msgs[0], 512)
+    assert tags[0] == etag and cts[0] == ect
+    assert all(len(c) == len(m) and c != m for c, m in zip(cts, msgs))
+    pws_bad = list(pws)
+    pws_bad[2] = rng.randbytes(64)
+    pts, ok = capy.ops.sha3_decrypt_batch(pws_bad, zs, cts, tags, 512)
+    assert ok == [True, True, False, True, True, True]
+    assert pts[2] == cts[2] and all(pts[i] == msgs[i] for i in (0, 1, 3, 4, 5))

@@ -1,0 +1,101 @@
+"""CPU: the C-ABI library loads and exports every symbol include/capyhip.h declares (no compute call),
+the host mirror's non-GPU logic, and the sharding helpers."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    with open(os.path.join(ROOT, "include", "capyhip.h")) as f:
+        txt = f.read()
+    return sorted(set(re.findall(r"\b(capy_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from capycrypt_amd import _lib
+
+    assert os.path.exists(_lib.LIB_PATH), "build first: python -c 'import __graft_entry__ as g; g.build()'"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    declared = _declared_symbols()
+    assert len(declared) >= 25
+    for name in declared:
+        assert hasattr(lib, name), "libcapyhip.so does not export %s" % name
+    assert set(declared) == set(_lib.SIGNATURES), "python binding and header disagree"
+    assert _lib.lib().capy_version().startswith(b"capyhip")
+
+
+def test_every_entry_point_cites_the_reference():
+    with open(os.path.join(ROOT, "include", "capyhip.h")) as f:
+        txt = f.read()
+    for ref in ("shake_functions.rs:24-32", "shake_functions.rs:49-64", "shake_functions.rs:79-89",
+                "encryptable.rs:29-45", "encryptable.rs:58-83", "keypair.rs:41-51", "signable.rs:40-57",
+                "signable.rs:72-86", "ecc/encryptable.rs:34-50", "ecc/encryptable.rs:72-94"):
+        assert ref in txt, ref
+
+
+def test_secparam_and_errors():
+    from capycrypt_amd import Message, OperationError, SecParam
+
+    assert SecParam.try_from(256) is SecParam.D256 and SecParam.D224.bytepad_value() == 172
+    with pytest.raises(OperationError) as e:
+        SecParam.try_from(300)
+    assert e.value.variant == "UnsupportedSecurityParameter"
+    m = Message(b"abc")
+    with pytest.raises(OperationError) as e:
+        m.sha3_decrypt(b"pw")
+    assert e.value.variant == "SecurityParameterNotSet"
+    m.d = SecParam.D512
+    with pytest.raises(OperationError) as e:
+        m.sha3_decrypt(b"pw")
+    assert e.value.variant == "SymNonceNotSet"
+    with pytest.raises(OperationError) as e:
+        m.verify(b"\0" * 112)
+    assert e.value.variant == "SignatureNotSet"
+    with pytest.raises(OperationError) as e:
+        Message(b"x").key_decrypt(b"pw")
+    assert e.value.variant == "SymNonceNotSet"
+
+
+def test_shake_mutation_mirror_matches_oracle():
+    import random
+
+    from capycrypt_amd.message import _append_shake_padding
+    from oracle import oracle as O
+
+    rng = random.Random(4)
+    for d in (224, 256, 384, 512):
+        for n in list(range(0, 150)) + [271, 272, 1000]:
+            m = rng.randbytes(n)
+            buf = bytearray(m)
+            _append_shake_padding(buf, d)
+            assert bytes(buf) == O.sha3(m, d, want_padded=True)[1], (d, n)
+
+
+def test_shard_ranges_cover_and_preserve_order():
+    from capycrypt_amd.sharding import shard_by_bytes, shard_range
+
+    for n in (0, 1, 7, 8, 1024, 1000003):
+        for w in (1, 2, 4, 8):
+            parts = [shard_range(n, r, w) for r in range(w)]
+            assert parts[0][0] == 0 and parts[-1][1] == n
+            assert all(parts[i][1] == parts[i + 1][0] for i in range(w - 1))
+            assert max(hi - lo for lo, hi in parts) - min(hi - lo for lo, hi in parts) <= 1
+    lens = [5 << 20] * 10 + [100] * 1000 + [5 << 20] * 10
+    parts = shard_by_bytes(lens, 4)
+    assert parts[0][0] == 0 and parts[-1][1] == len(lens)
+    assert all(parts[i][1] == parts[i + 1][0] for i in range(3))
+    loads = [sum(lens[lo:hi]) for lo, hi in parts]
+    assert max(loads) <= 1.3 * (sum(lens) / 4)
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from capycrypt_amd import _lib
+
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(ImportError):
+        _lib.lib()

@@ -1,0 +1,101 @@
+"""CPU: pin the sponge oracle against every known-answer vector the reference's tests hold
+(tests/golden/reference_kats.json, each entry cites its reference file:line) and against hashlib."""
+import hashlib
+import random
+
+import pytest
+
+from oracle import oracle as O
+
+
+def test_sha3_kats(kats):
+    for v in kats["sha3"]:
+        assert O.sha3(bytes.fromhex(v["msg_hex"]), v["d"]).hex() == v["digest_hex"], v["src"]
+
+
+def test_tagged_hash_kats(kats):
+    for v in kats["tagged_hash"]:
+        got = O.kmac_xof(bytes.fromhex(v["pw_hex"]), bytes.fromhex(v["msg_hex"]), v["d"], v["s"].encode(), v["d"])
+        assert got.hex() == v["digest_hex"], v["src"]
+
+
+def test_cshake_kats(kats):
+    for v in kats["cshake"]:
+        got = O.cshake(bytes.fromhex(v["x_hex"]), v["l_bits"], v["n"].encode(), v["s"].encode(), v["d"])
+        assert got.hex() == v["out_hex"], v["src"]
+
+
+def test_kmac_kats(kats):
+    for v in kats["kmac_xof"]:
+        got = O.kmac_xof(bytes.fromhex(v["k_hex"]), bytes.fromhex(v["x_hex"]), v["l_bits"], v["s"].encode(), v["d"])
+        assert got.hex() == v["out_hex"], v["src"]
+
+
+def test_encodings(kats):
+    e = kats["encodings"]
+    for v, exp in e["right_encode"]:
+        assert list(O.right_encode(v)) == exp
+    for v, exp in e["left_encode"]:
+        assert list(O.left_encode(v)) == exp
+    assert list(O.byte_pad(b"test", 4)) == e["byte_pad"][0]["out"]
+    assert O.byte_pad(bytes.fromhex(e["byte_pad"][1]["x_hex"]), 200).hex() == e["byte_pad"][1]["out_hex"]
+
+
+@pytest.mark.parametrize("d,h", [(224, hashlib.sha3_224), (256, hashlib.sha3_256), (384, hashlib.sha3_384),
+                                 (512, hashlib.sha3_512)])
+def test_fips_mode_equals_hashlib(d, h):
+    rng = random.Random(d)
+    for n in list(range(0, 300)) + [1000, 4096, 10007]:
+        m = rng.randbytes(n)
+        assert O.sha3(m, d, quirks=0) == h(m).digest(), n
+
+
+def test_reference_quirks_d256_is_fips_everywhere():
+    rng = random.Random(1)
+    for n in range(0, 600):
+        m = rng.randbytes(n)
+        assert O.sha3(m, 256, quirks=1) == hashlib.sha3_256(m).digest()
+
+
+def test_reference_quirk_set_sha3_512():
+    """shake() decides 0x06/0x86 on len % 136 whatever d is (shake_functions.rs:25): SHA3-512 differs
+    from FIPS 202 exactly when one of len = 71 (mod 72), len = 135 (mod 136) holds."""
+    rng = random.Random(2)
+    diff = []
+    for n in range(0, 300):
+        m = rng.randbytes(n)
+        if O.sha3(m, 512, quirks=1) != hashlib.sha3_512(m).digest():
+            diff.append(n)
+    expect = [n for n in range(0, 300) if (n % 72 == 71) != (n % 136 == 135)]
+    assert diff == expect
+
+
+def test_shake_mutation_visible_to_caller():
+    d, padded = O.sha3(b"test", 256, want_padded=True)
+    assert padded == b"test" + b"\x06" + b"\0" * 130 + b"\x80" and len(padded) == 136
+
+
+def test_kmac_missing_pad_quirk_differs_from_standard():
+    # KMAC D512: len(X) = 133 (mod 136) lands the 0x04 suffix on a block boundary -> no 0x80 (sponge.rs:13)
+    x = bytes(range(133))
+    assert O.kmac_xof(b"k" * 32, x, 256, b"S", 512, quirks=1) != O.kmac_xof(b"k" * 32, x, 256, b"S", 512, quirks=0)
+    x = bytes(range(134))
+    assert O.kmac_xof(b"k" * 32, x, 256, b"S", 512, quirks=1) == O.kmac_xof(b"k" * 32, x, 256, b"S", 512, quirks=0)
+
+
+def test_sha3_encrypt_roundtrip_and_restore():
+    rng = random.Random(3)
+    for d in (224, 256, 384, 512):
+        for n in (0, 1, 523, 5000):
+            pw, z, m = rng.randbytes(64), rng.randbytes(512), rng.randbytes(n)
+            ct, tag = O.sha3_encrypt(pw, z, m, d)
+            assert len(ct) == n and len(tag) == 64
+            pt, ok = O.sha3_decrypt(pw, z, ct, tag, d)
+            assert ok and pt == m
+            pt, ok = O.sha3_decrypt(rng.randbytes(64), z, ct, tag, d)  # tests/integration_tests.rs:250-262
+            assert not ok and pt == ct
+
+
+def test_keccakf_zero_state():
+    st = O.keccakf1600([0] * 25)
+    assert st[0] == 0xF1258F7940E1DDE7 and st[24] == 0xEAF1FF7B5CECA249  # XKCP KeccakF-1600-IntermediateValues

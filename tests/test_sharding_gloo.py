@@ -1,0 +1,71 @@
+"""CPU, world_size 2 over gloo: the N>1 host path (contiguous batch sharding, output order, barrier +
+max-over-ranks timing) with a CPU stand-in operator.  The GPU data path has no collective."""
+import os
+import socket
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import hashlib
+    import time
+
+    import torch
+    import torch.distributed as dist
+
+    from capycrypt_amd.sharding import sharded_map
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    items = [bytes([i % 251]) * (i * 37 % 5000) for i in range(1001)]  # every rank regenerates the same batch
+    dist.barrier()
+    t0 = time.perf_counter()
+    lo, hi, res = sharded_map(lambda ms: [hashlib.sha3_256(m).digest() for m in ms], items, rank, world)
+    dist.barrier()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (lo, hi, res))
+    dist.destroy_process_group()
+    if rank == 0:
+        q.put((gathered, float(el.item())))
+
+
+def test_two_rank_sharding_preserves_order():
+    import hashlib
+
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    gathered, el = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    items = [bytes([i % 251]) * (i * 37 % 5000) for i in range(1001)]
+    out = []
+    expect_lo = 0
+    for lo, hi, res in gathered:
+        assert lo == expect_lo
+        expect_lo = hi
+        out.extend(res)
+    assert expect_lo == len(items)
+    assert out == [hashlib.sha3_256(m).digest() for m in items]
+    assert el > 0
