@@ -3,8 +3,10 @@
 // as the reference builds them) and launches kernels; there is NO CPU fallback for the data path.
 #include <string.h>
 #include <algorithm>
+#include <atomic>
 #include "common.h"
 #include "sponge_kernels.h"
+#include "sponge_kernels_k2.h"
 #include "sponge_host.h"
 
 namespace capy {
@@ -182,9 +184,32 @@ static void kmac_head(int d, size_t key_len, SpongeParams &p)
     p.key_len = (uint32_t)key_len;
 }
 
+// Lanes per sponge: 1 fills the chip once there are >= ~64k independent sponges; below that the
+// two-lane kernel is 1.5x faster per sponge (sponge_kernels_k2.h).  0 = choose by batch size.
+static std::atomic<int> g_lanes_per_sponge{0};
+static const size_t K2_MAX_ITEMS = 49152;
+
+static int launch_sponge_k2(int rw, const SpongeParams &p, hipStream_t s)
+{
+    dim3 grid((unsigned)((p.n + 31) / 32)), block(64);
+    switch (rw) {
+    case 9: hipLaunchKernelGGL(sponge_kernel_k2<9>, grid, block, 0, s, p); break;
+    case 13: hipLaunchKernelGGL(sponge_kernel_k2<13>, grid, block, 0, s, p); break;
+    case 17: hipLaunchKernelGGL(sponge_kernel_k2<17>, grid, block, 0, s, p); break;
+    case 18: hipLaunchKernelGGL(sponge_kernel_k2<18>, grid, block, 0, s, p); break;
+    case 19: hipLaunchKernelGGL(sponge_kernel_k2<19>, grid, block, 0, s, p); break;
+    case 21: hipLaunchKernelGGL(sponge_kernel_k2<21>, grid, block, 0, s, p); break;
+    default: return fail(CAPY_ERR_ARG, "internal: unsupported rate");
+    }
+    CAPY_HIP(hipGetLastError());
+    return CAPY_OK;
+}
+
 static int launch_sponge(int rw, const SpongeParams &p, hipStream_t s)
 {
     if (p.n == 0) return CAPY_OK;
+    const int forced = g_lanes_per_sponge.load();
+    if (forced == 2 || (forced == 0 && p.n <= K2_MAX_ITEMS)) return launch_sponge_k2(rw, p, s);
     dim3 grid((unsigned)((p.n + 63) / 64)), block(64);
     switch (rw) {
     case 9: hipLaunchKernelGGL(sponge_kernel<9>, grid, block, 0, s, p); break;
@@ -647,6 +672,13 @@ int capy_sha3_decrypt_batch(int d, size_t n, const uint8_t *pws, size_t pw_len, 
 }
 
 // ---------------------------------------------------------------- measurement helpers
+int capy_set_sponge_lanes(int lanes)
+{
+    if (lanes != 0 && lanes != 1 && lanes != 2) return fail(CAPY_ERR_ARG, "lanes must be 0 (auto), 1 or 2");
+    g_lanes_per_sponge.store(lanes);
+    return CAPY_OK;
+}
+
 int capy_fill_random_dev(uint8_t *dst, uint64_t nbytes, uint64_t seed, void *stream)
 {
     if (((uintptr_t)dst & 7) || (nbytes & 7)) return fail(CAPY_ERR_ARG, "dst and nbytes must be multiples of 8");

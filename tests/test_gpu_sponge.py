@@ -30,6 +30,16 @@ def O():
     return oracle
 
 
+@pytest.fixture(autouse=True, params=[1, 2], ids=["lane-per-sponge", "two-lanes-per-sponge"])
+def sponge_lanes(request):
+    """Every test runs against both sponge kernels (sponge_kernels.h / sponge_kernels_k2.h)."""
+    from capycrypt_amd import _lib
+
+    _lib.check(_lib.lib().capy_set_sponge_lanes(request.param))
+    yield request.param
+    _lib.check(_lib.lib().capy_set_sponge_lanes(0))
+
+
 # ---------------------------------------------------------------- (1) the reference's KATs, via the mirrored API
 def test_shake_kats_via_message(capy, kats):
     for v in kats["sha3"]:  # test_shake_224/256/384/512, test_hashable
