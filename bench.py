@@ -21,9 +21,10 @@ sys.path.insert(0, ROOT)
 
 MSG_BYTES = 5242880  # benches/benchmark_sha3.rs:17
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-# VALU ceiling for keccak-f on gfx950: 4354 VALU lane-ops per 136-byte block,
-# 256 CU x 128 lanes/clk x 2.4 GHz = 78.6e12 lane-ops/s  ->  2.46 TB/s of absorbed message.
-VALU_CEIL_GBS = 78.6432e12 / 4354.0 * 136.0 / 1e9
+# Integer-VALU ceiling for keccak-f[1600] on MI355X, MEASURED (profiles/r01_keccak_probe_and_size_sweep.txt):
+# a register-resident loop of nothing but permutations tops out at 10.06e9 permutations/s with 16k waves,
+# i.e. 1368 GB/s of absorbed message at 136 B per permutation ("Rooflines").
+VALU_CEIL_GBS = 10.06e9 * 136.0 / 1e9
 
 
 def parse():
@@ -31,8 +32,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("CAPY_BENCH_BATCH", "32768")),
-                    help="5 MiB messages per GPU per step")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("CAPY_BENCH_BATCH", "49152")),
+                    help="5 MiB messages per GPU per step (reduced automatically to what fits in HBM)")
+    ap.add_argument("--lanes", type=int, default=0, help="sponge lanes per item: 0 auto, 1 or 2 (tuning/debug)")
     ap.add_argument("--ed448-pairs", type=int, default=1 << 18, help="(scalar, point) pairs per GPU (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
@@ -113,8 +115,10 @@ def main():
     # ---- synthetic inputs resident in HBM
     B = a.batch
     free, _total = torch.cuda.mem_get_info()
-    while B > 64 and B * MSG_BYTES > free - (12 << 30):
-        B //= 2
+    fit = int((free - (14 << 30)) // MSG_BYTES)  # leave room for the Ed448 leg (table scratch) and torch itself
+    if B > fit:
+        B = max(64, fit // 2048 * 2048)
+    _lib.check(lib.capy_set_sponge_lanes(a.lanes))
     msgs = torch.empty(B * MSG_BYTES, dtype=torch.uint8, device=dev)
     digests = torch.empty(B * 32, dtype=torch.uint8, device=dev)
     _lib.check(lib.capy_fill_random_dev(msgs.data_ptr(), B * MSG_BYTES, 0xCA9C0001 + rank, sp))
@@ -217,7 +221,8 @@ def main():
                        "batch_per_gpu": B, "msg_bytes": MSG_BYTES, "parallelism": "batch-sharded x%d, no collective" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "sponge_kernel<17>", "kernel_ms": kern_ms,
+                         "kernel": "sponge_kernel_k2<17>" if (a.lanes == 2 or (a.lanes == 0 and B <= 32768)) else "sponge_kernel<17>",
+                         "kernel_ms": kern_ms,
                          "valu_ceiling_GBs": VALU_CEIL_GBS, "frac_of_valu_ceiling": achieved / VALU_CEIL_GBS},
         }
         if ed:

@@ -187,7 +187,7 @@ static void kmac_head(int d, size_t key_len, SpongeParams &p)
 // Lanes per sponge: 1 fills the chip once there are >= ~64k independent sponges; below that the
 // two-lane kernel is 1.5x faster per sponge (sponge_kernels_k2.h).  0 = choose by batch size.
 static std::atomic<int> g_lanes_per_sponge{0};
-static const size_t K2_MAX_ITEMS = 49152;
+static const size_t K2_MAX_ITEMS = 32768;  // 32 sponges x one wave per SIMD x 1024 SIMDs (measured crossover, profiles/)
 
 static int launch_sponge_k2(int rw, const SpongeParams &p, hipStream_t s)
 {

@@ -187,16 +187,23 @@ __global__ __launch_bounds__(64) void sponge_kernel(const SpongeParams p)
     __syncthreads();
     const uint32_t max_full = wave_max_u32(nfull);
     if (max_full) {
+        // source pointer and block limit of every (load slot, lane) pair, hoisted out of the block loop
+        const uint8_t *src[RW];
+        uint32_t lim[RW];
+#pragma unroll
+        for (int k = 0; k < RW; k++) {
+            const uint32_t i = k * 64 + lane;
+            const uint32_t m = i / RW, w = i - m * RW;
+            lim[k] = s_nfull[m];
+            src[k] = reinterpret_cast<const uint8_t *>(s_base[m]) + 8 * w;
+        }
+        const uint8_t *safe = p.msgs;  // readable whenever any message of this wave has a full block
         uint64_t pf[RW];
         auto coop_load = [&](uint32_t t) {
 #pragma unroll
             for (int k = 0; k < RW; k++) {
-                uint32_t i = k * 64 + lane;
-                uint32_t m = i / RW, w = i - m * RW;
-                uint64_t v = 0;
-                if (t < s_nfull[m])
-                    v = *reinterpret_cast<const uint64_t *>(s_base[m] + (uint64_t)t * RB + 8 * w);
-                pf[k] = v;
+                const uint8_t *q = t < lim[k] ? src[k] + (uint64_t)t * RB : safe;
+                pf[k] = *reinterpret_cast<const uint64_t *>(q);
             }
         };
         coop_load(0);
@@ -269,29 +276,44 @@ __global__ __launch_bounds__(64) void sponge_kernel(const SpongeParams p)
         s_nfull[lane] = xfull;
         __syncthreads();
         const uint32_t max_x = wave_max_u32(xfull);
-        for (uint32_t t = 0; t < max_x; t++) {
+        if (max_x) {
+            uint8_t *dst[RW];
+            uint32_t lim[RW];
 #pragma unroll
             for (int k = 0; k < RW; k++) {
-                uint32_t i = k * 64 + lane;
-                uint32_t m = i / RW, w = i - m * RW;
-                uint64_t v = 0;
-                if (t < s_nfull[m]) v = *reinterpret_cast<const uint64_t *>(s_base[m] + (uint64_t)t * RB + 8 * w);
-                s_stage[i] = v;
+                const uint32_t i = k * 64 + lane;
+                const uint32_t m = i / RW, w = i - m * RW;
+                lim[k] = s_nfull[m];
+                dst[k] = reinterpret_cast<uint8_t *>(s_base[m]) + 8 * w;
             }
-            __syncthreads();
-            if (t < xfull) {
+            uint8_t *safe = const_cast<uint8_t *>(p.msgs);
+            uint64_t pf[RW];
+            auto coop_load = [&](uint32_t t) {
 #pragma unroll
-                for (int w = 0; w < RW; w++) s_stage[lane * RW + w] ^= ((uint64_t)a.hi[w] << 32) | a.lo[w];
-            }
-            __syncthreads();
+                for (int k = 0; k < RW; k++) {
+                    const uint8_t *q = t < lim[k] ? dst[k] + (uint64_t)t * RB : safe;
+                    pf[k] = *reinterpret_cast<const uint64_t *>(q);
+                }
+            };
+            coop_load(0);
+            for (uint32_t t = 0; t < max_x; t++) {
 #pragma unroll
-            for (int k = 0; k < RW; k++) {
-                uint32_t i = k * 64 + lane;
-                uint32_t m = i / RW, w = i - m * RW;
-                if (t < s_nfull[m]) *reinterpret_cast<uint64_t *>(s_base[m] + (uint64_t)t * RB + 8 * w) = s_stage[i];
+                for (int k = 0; k < RW; k++) s_stage[k * 64 + lane] = pf[k];
+                __syncthreads();
+                if (t < xfull) {
+#pragma unroll
+                    for (int w = 0; w < RW; w++) s_stage[lane * RW + w] ^= ((uint64_t)a.hi[w] << 32) | a.lo[w];
+                }
+                __syncthreads();
+#pragma unroll
+                for (int k = 0; k < RW; k++) {
+                    const uint64_t v = s_stage[k * 64 + lane];
+                    if (t < lim[k]) *reinterpret_cast<uint64_t *>(dst[k] + (uint64_t)t * RB) = v;
+                }
+                __syncthreads();
+                if (t + 1 < max_x) coop_load(t + 1);
+                if (t < xfull && (uint64_t)(t + 1) * RB < tgt_len) keccakf1600(a);
             }
-            __syncthreads();
-            if (t < xfull && (uint64_t)(t + 1) * RB < tgt_len) keccakf1600(a);
         }
         // leftover bytes (unaligned messages: everything) byte-granular
         uint64_t pos = (uint64_t)xfull * RB;

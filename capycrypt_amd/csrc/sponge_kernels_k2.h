@@ -233,30 +233,45 @@ __global__ __launch_bounds__(64) void sponge_kernel_k2(const SpongeParams p)
         __syncthreads();
         const uint32_t max_x = wave_max_u32(xfull);
         uint32_t *stage32 = reinterpret_cast<uint32_t *>(s_stage);
-        for (uint32_t t = 0; t < max_x; t++) {
+        if (max_x) {
+            uint8_t *dst[NLOAD];
+            uint32_t lim[NLOAD];
 #pragma unroll
             for (int k = 0; k < NLOAD; k++) {
                 const uint32_t i = k * 64 + lane;
                 const uint32_t m = i / RW, w = i - m * RW;
-                uint64_t v = 0;
-                if (m < NSP && t < s_nfull[m]) v = *reinterpret_cast<const uint64_t *>(s_base[m] + (uint64_t)t * RB + 8 * w);
-                s_stage[i] = v;
+                const bool in = m < NSP;
+                lim[k] = in ? s_nfull[in ? m : 0] : 0;
+                dst[k] = reinterpret_cast<uint8_t *>(in ? s_base[in ? m : 0] : 0) + 8 * w;
             }
-            __syncthreads();
-            if (t < xfull) {
+            uint8_t *safe = const_cast<uint8_t *>(p.msgs);
+            uint64_t pf[NLOAD];
+            auto coop_load = [&](uint32_t t) {
 #pragma unroll
-                for (int w = 0; w < RW; w++) stage32[(j * RW + w) * 2 + h] ^= a.a[w];
-            }
-            __syncthreads();
+                for (int k = 0; k < NLOAD; k++) {
+                    const uint8_t *q = t < lim[k] ? dst[k] + (uint64_t)t * RB : safe;
+                    pf[k] = *reinterpret_cast<const uint64_t *>(q);
+                }
+            };
+            coop_load(0);
+            for (uint32_t t = 0; t < max_x; t++) {
 #pragma unroll
-            for (int k = 0; k < NLOAD; k++) {
-                const uint32_t i = k * 64 + lane;
-                const uint32_t m = i / RW, w = i - m * RW;
-                if (m < NSP && t < s_nfull[m])
-                    *reinterpret_cast<uint64_t *>(s_base[m] + (uint64_t)t * RB + 8 * w) = s_stage[i];
+                for (int k = 0; k < NLOAD; k++) s_stage[k * 64 + lane] = pf[k];
+                __syncthreads();
+                if (t < xfull) {
+#pragma unroll
+                    for (int w = 0; w < RW; w++) stage32[(j * RW + w) * 2 + h] ^= a.a[w];
+                }
+                __syncthreads();
+#pragma unroll
+                for (int k = 0; k < NLOAD; k++) {
+                    const uint64_t v = s_stage[k * 64 + lane];
+                    if (t < lim[k]) *reinterpret_cast<uint64_t *>(dst[k] + (uint64_t)t * RB) = v;
+                }
+                __syncthreads();
+                if (t + 1 < max_x) coop_load(t + 1);
+                if (t < xfull && (uint64_t)(t + 1) * RB < tgt_len) keccakf1600_k2(a, hmask);
             }
-            __syncthreads();
-            if (t < xfull && (uint64_t)(t + 1) * RB < tgt_len) keccakf1600_k2(a, hmask);
         }
         uint64_t pos = (uint64_t)xfull * RB;
         const uint64_t left = tgt_len - pos;

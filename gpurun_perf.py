@@ -1,0 +1,25 @@
+import sys, os, time, ctypes as C
+sys.path.insert(0, os.getcwd())
+import torch
+from capycrypt_amd import _lib
+lib=_lib.lib()
+dev=torch.device("cuda",0)
+st=torch.cuda.current_stream(); sp=C.c_void_p(st.cuda_stream)
+def timeit(fn, reps=2):
+    fn(); torch.cuda.synchronize()
+    e0=torch.cuda.Event(enable_timing=True); e1=torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    for _ in range(reps): fn()
+    e1.record(st); torch.cuda.synchronize()
+    return e0.elapsed_time(e1)/reps
+L=5242880
+cfgs=[(int(x.split('x')[0]), int(x.split('x')[1])) for x in sys.argv[1].split(',')] if len(sys.argv)>1 else [(4096,L),(16384,L)]
+for B,LL in cfgs:
+    msgs=torch.empty(B*LL,dtype=torch.uint8,device=dev)
+    dig=torch.empty(B*32,dtype=torch.uint8,device=dev)
+    _lib.check(lib.capy_fill_random_dev(msgs.data_ptr(),B*LL,1,sp))
+    for lanes in (1,2):
+        lib.capy_set_sponge_lanes(lanes)
+        ms=timeit(lambda: _lib.check(lib.capy_sha3_batch_dev(256,B,msgs.data_ptr(),None,LL,LL,dig.data_ptr(),sp)))
+        print("B=%d L=%d lanes=%d: %.2f ms  %.1f GB/s" % (B,LL,lanes,ms,B*LL/(ms*1e-3)/1e9), flush=True)
+    del msgs

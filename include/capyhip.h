@@ -126,7 +126,7 @@ int capy_key_decrypt_batch(int d, size_t n, const uint8_t *pws, size_t pw_len, c
 
 /* ------------------------------------------------------------------ measurement helpers */
 
-/* Tuning knob: GPU lanes per sponge. 0 = automatic (2 for batches of <= 49152 items, else 1), 1 or 2 = forced.
+/* Tuning knob: GPU lanes per sponge. 0 = automatic (2 for batches of <= 32768 items, else 1), 1 or 2 = forced.
  * Results are identical either way; process-wide. */
 int capy_set_sponge_lanes(int lanes);
 /* Fill a device buffer with the harness PRNG (SplitMix64 counter mode, seed + 8-byte word index). */
