@@ -248,3 +248,15 @@ def test_config3_encrypt_roundtrip_5mib(capy, O):
     pts, ok = capy.ops.sha3_decrypt_batch(pws_bad, zs, cts, tags, 512)
     assert ok == [True, True, False, True, True, True]
     assert pts[2] == cts[2] and all(pts[i] == msgs[i] for i in (0, 1, 3, 4, 5))
+
+
+def test_cpp_host_mirror_selftest():
+    """The C++ mirror of the reference interface (capycrypt_amd/host/capycrypt.hpp) run as its own process."""
+    import os
+    import subprocess
+
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "capycrypt_amd", "host", "host_selftest")
+    if not os.path.exists(exe):
+        pytest.skip("host_selftest not built (python -c 'import __graft_entry__ as g; g.build()')")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
