@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcapyhip.so")
+LIB_PATH = os.environ.get("CAPY_LIB_PATH") or os.path.join(_HERE, "libcapyhip.so")  # override: kernel A/B experiments
 
 u8p = C.POINTER(C.c_uint8)
 u64p = C.POINTER(C.c_uint64)

@@ -14,7 +14,10 @@ namespace capy {
     if (!var) return capy::fail(CAPY_ERR_HIP, "workspace allocation failed")
 
 // ------------------------------------------------------------------ kernels (one item per lane)
-__global__ __launch_bounds__(64) void vb_kernel(uint64_t n, const uint8_t *scalars_be, uint64_t scalar_stride,
+#ifndef CAPY_ED448_WAVES
+#define CAPY_ED448_WAVES 2
+#endif
+__global__ __launch_bounds__(64, CAPY_ED448_WAVES) void vb_kernel(uint64_t n, const uint8_t *scalars_be, uint64_t scalar_stride,
                                                 const uint8_t *points_xy, uint64_t point_stride, uint8_t *out_xy,
                                                 uint32_t *table_ws)
 {
@@ -25,7 +28,7 @@ __global__ __launch_bounds__(64) void vb_kernel(uint64_t n, const uint8_t *scala
     pt_to_affine_bytes(out_xy + i * 112, r);
 }
 
-__global__ __launch_bounds__(64) void fb_kernel(uint64_t n, const uint8_t *scalars_be, uint8_t *out_xy,
+__global__ __launch_bounds__(64, CAPY_ED448_WAVES) void fb_kernel(uint64_t n, const uint8_t *scalars_be, uint8_t *out_xy,
                                                 const uint32_t *gtab)
 {
     const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
@@ -33,7 +36,7 @@ __global__ __launch_bounds__(64) void fb_kernel(uint64_t n, const uint8_t *scala
     pt_to_affine_bytes(out_xy + i * 112, fb_scalarmul(scalars_be + i * 56, gtab));
 }
 
-__global__ __launch_bounds__(64) void dsm_kernel(uint64_t n, const uint8_t *a_be, const uint8_t *b_be,
+__global__ __launch_bounds__(64, CAPY_ED448_WAVES) void dsm_kernel(uint64_t n, const uint8_t *a_be, const uint8_t *b_be,
                                                  const uint8_t *points_xy, uint8_t *out_xy, uint32_t *table_ws,
                                                  const uint32_t *gtab)
 {

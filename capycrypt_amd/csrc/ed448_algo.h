@@ -75,9 +75,14 @@ CAPY_HD inline Pt vb_scalarmul(const uint8_t *k_be, const Pt &P, uint32_t *tab)
     Pt acc = vb_add_digit(pt_identity(), tab, (int)top);
 #pragma unroll 1
     for (int i = 0; i < 112; i++) {
+#if CAPY_ED448_INLINE && !defined(CAPY_ED448_SPLIT_DBL)
+#pragma unroll 1
+        for (int j = 0; j < 4; j++) acc = pt_dbl<true>(acc);  // one doubling body keeps the loop inside the I-cache
+#else
 #pragma unroll 1
         for (int j = 0; j < 3; j++) acc = pt_dbl<false>(acc);
         acc = pt_dbl<true>(acc);
+#endif
         const int digit = (int)(w[13] >> 28) - 8;
 #pragma unroll
         for (int t = 13; t > 0; t--) w[t] = (w[t] << 4) | (w[t - 1] >> 28);
@@ -131,9 +136,14 @@ CAPY_HD inline Pt double_scalarmul(const uint8_t *a_be, const uint8_t *b_be, con
     acc = fb_add_digit(acc, gtab, 0, (int)topa);
 #pragma unroll 1
     for (int i = 0; i < 112; i++) {
+#if CAPY_ED448_INLINE && !defined(CAPY_ED448_SPLIT_DBL)
+#pragma unroll 1
+        for (int j = 0; j < 4; j++) acc = pt_dbl<true>(acc);  // one doubling body keeps the loop inside the I-cache
+#else
 #pragma unroll 1
         for (int j = 0; j < 3; j++) acc = pt_dbl<false>(acc);
         acc = pt_dbl<true>(acc);
+#endif
         const int db = (int)(wb[13] >> 28) - 8, da = (int)(wa[13] >> 28) - 8;
 #pragma unroll
         for (int t = 13; t > 0; t--) {

@@ -113,7 +113,11 @@ CAPY_HD inline Fe fe_from_columns(uint64_t lo[8], uint64_t hi[8])
     return r;
 }
 
-#if defined(__HIP_DEVICE_COMPILE__)
+// CAPY_ED448_INLINE=1: inline fe_mul / fe_sqr at every call site (no call, no stack traffic, larger code).
+#ifndef CAPY_ED448_INLINE
+#define CAPY_ED448_INLINE 1
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && !CAPY_ED448_INLINE
 #define CAPY_NOINLINE __noinline__
 #else
 #define CAPY_NOINLINE

@@ -1,0 +1,126 @@
+#!/usr/bin/env python3
+"""Secondary measurements for BASELINE.json configs 2-5 and the PCIe-inclusive host-buffer rate.
+Run on the GPU box: python tools/bench_configs.py > gpurun_out/configs.jsonl ; summaries go to profiles/."""
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from capycrypt_amd import _lib, ops  # noqa: E402
+
+lib = _lib.lib()
+dev = torch.device("cuda", 0)
+st = torch.cuda.current_stream()
+sp = C.c_void_p(st.cuda_stream)
+MIB5 = 5242880
+
+
+def timeit(fn, reps=3):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    for _ in range(reps):
+        fn()
+    e1.record(st)
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e-3
+
+
+def rand(nbytes, seed):
+    t = torch.empty((nbytes + 7) // 8 * 8, dtype=torch.uint8, device=dev)
+    _lib.check(lib.capy_fill_random_dev(t.data_ptr(), t.numel(), seed, sp))
+    return t
+
+
+def emit(**kw):
+    print(json.dumps(kw), flush=True)
+
+
+# ---- config 2: 2^20 x kmac_xof(k, "", 8192 bits, "SKE", D512)
+n = 1 << 20
+keys = rand(n * 64, 2)
+out = torch.empty(n * 1024, dtype=torch.uint8, device=dev)
+s = timeit(lambda: _lib.check(lib.capy_kmac_xof_batch_dev(512, n, keys.data_ptr(), 64, 64, None, None, 0, 0, 8192,
+                                                          b"SKE", 3, out.data_ptr(), 1024, sp)))
+emit(config=2, what="2^20 x KMACXOF256 1 KiB squeeze (64-B keys)", seconds=s, units_per_s=n / s,
+     out_GBps=n * 1024 / s / 1e9, permutations_per_s=n * 10 / s)
+del keys, out
+
+# ---- config 3: sha3_encrypt D512 over 5 MiB messages: 128 per GPU (the 8-GPU split of 1024) and a larger batch
+for nmsg in (128, 2048, 16384):
+    msgs = rand(nmsg * MIB5, 3)
+    pws = rand(nmsg * 64, 31)
+    zs = rand(nmsg * 512, 32)
+    tags = torch.empty(nmsg * 64, dtype=torch.uint8, device=dev)
+    status = torch.empty(nmsg, dtype=torch.int32, device=dev)
+    before = msgs[:4096].clone()
+
+    def enc():
+        _lib.check(lib.capy_sha3_encrypt_batch_dev(512, nmsg, pws.data_ptr(), 64, zs.data_ptr(), msgs.data_ptr(), None,
+                                                   MIB5, MIB5, tags.data_ptr(), sp))
+
+    def dec():
+        _lib.check(lib.capy_sha3_decrypt_batch_dev(512, nmsg, pws.data_ptr(), 64, zs.data_ptr(), msgs.data_ptr(), None,
+                                                   MIB5, MIB5, tags.data_ptr(), status.data_ptr(), sp))
+
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    enc()
+    torch.cuda.synchronize()
+    te = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    dec()
+    torch.cuda.synchronize()
+    td = time.perf_counter() - t0
+    ok = bool((status == 0).all().item()) and bool((msgs[:4096] == before).all().item())
+    emit(config=3, what="sha3_encrypt / sha3_decrypt D512, %d x 5 MiB" % nmsg, enc_seconds=te, dec_seconds=td,
+         enc_GiBps=nmsg * MIB5 / te / 2**30, dec_GiBps=nmsg * MIB5 / td / 2**30, roundtrip_ok=ok)
+    del msgs
+
+# ---- config 4: Ed448 variable-base / fixed-base / double-scalar, 2^18 pairs
+n = 1 << 18
+sc = rand(n * 56, 4)
+tsc = rand(n * 56, 41)
+pts = torch.empty(n * 112, dtype=torch.uint8, device=dev)
+o = torch.empty(n * 112, dtype=torch.uint8, device=dev)
+_lib.check(lib.capy_ed448_basemul_batch_dev(n, tsc.data_ptr(), pts.data_ptr(), sp))
+s_fb = timeit(lambda: _lib.check(lib.capy_ed448_basemul_batch_dev(n, tsc.data_ptr(), o.data_ptr(), sp)))
+s_vb = timeit(lambda: _lib.check(lib.capy_ed448_scalarmul_batch_dev(n, sc.data_ptr(), pts.data_ptr(), o.data_ptr(), sp)))
+emit(config=4, what="Ed448 2^18 pairs", var_base_per_s=n / s_vb, fixed_base_per_s=n / s_fb, var_base_ms=s_vb * 1e3,
+     fixed_base_ms=s_fb * 1e3)
+
+# ---- config 5: Schnorr sign + verify, 2^16 x 1 KiB messages, D512 (host-buffer API: PCIe inclusive)
+import random  # noqa: E402
+
+rng = random.Random(5)
+n = 1 << 16
+msgs_h = [rng.randbytes(1024) for _ in range(n)]
+pws_h = [rng.randbytes(64) for _ in range(n)]
+t0 = time.perf_counter()
+pubs = ops.keypair_batch(pws_h, 512)
+tk = time.perf_counter() - t0
+t0 = time.perf_counter()
+sigs = ops.schnorr_sign_batch(pws_h, msgs_h, 512)
+ts = time.perf_counter() - t0
+t0 = time.perf_counter()
+ok = ops.schnorr_verify_batch(pubs, msgs_h, sigs, 512)
+tv = time.perf_counter() - t0
+emit(config=5, what="Schnorr D512, 2^16 x 1 KiB messages, host buffers (includes python packing + PCIe)",
+     keypair_per_s=n / tk, sign_per_s=n / ts, verify_per_s=n / tv, all_verified=all(ok))
+
+# ---- PCIe-inclusive SHA3-256 rate through the host-pointer entry point
+nmsg = 256
+host = (C.c_uint8 * (nmsg * MIB5))()
+offs = (C.c_uint64 * (nmsg + 1))(*[i * MIB5 for i in range(nmsg + 1)])
+dig = (C.c_uint8 * (nmsg * 32))()
+_lib.check(lib.capy_sha3_batch(256, nmsg, host, offs, dig))
+t0 = time.perf_counter()
+_lib.check(lib.capy_sha3_batch(256, nmsg, host, offs, dig))
+th = time.perf_counter() - t0
+emit(config="pcie", what="capy_sha3_batch from pageable host memory, 256 x 5 MiB (H2D copy + kernel + D2H)",
+     seconds=th, GiBps=nmsg * MIB5 / th / 2**30)
