@@ -37,6 +37,8 @@ SIGNATURES = {
     "capy_sha3_decrypt_batch": (C.c_int, [C.c_int, sz, vp, sz, vp, vp, vp, vp, vp]),
     "capy_sha3_encrypt_batch_dev": (C.c_int, [C.c_int, sz, vp, sz, vp, vp, vp, u64, u64, vp, vp]),
     "capy_sha3_decrypt_batch_dev": (C.c_int, [C.c_int, sz, vp, sz, vp, vp, vp, u64, u64, vp, vp, vp]),
+    "capy_kem_sponge_encrypt_batch": (C.c_int, [C.c_int, sz, vp, sz, vp, vp, vp, vp]),
+    "capy_kem_sponge_decrypt_batch": (C.c_int, [C.c_int, sz, vp, sz, vp, vp, vp, vp, vp]),
     "capy_ed448_scalarmul_batch": (C.c_int, [sz, vp, vp, vp]),
     "capy_ed448_scalarmul_batch_dev": (C.c_int, [sz, vp, vp, vp, vp]),
     "capy_ed448_basemul_batch": (C.c_int, [sz, vp, vp]),

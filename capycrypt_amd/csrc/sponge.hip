@@ -392,8 +392,10 @@ __global__ __launch_bounds__(64) void keccak_probe_kernel(uint64_t n_states, uin
 }
 
 // sha3_encrypt / sha3_decrypt on device buffers (src/sha3/encryptable.rs:29-83)
+// (and the sponge half of KEMEncryptable, src/kem/encryptable.rs:47-59,84-104: same flow, tags "KEMKE"/"KEMKA")
 static int sha3_crypt_dev(bool encrypt, int d, size_t n, const uint8_t *pws, size_t pw_len, const uint8_t *zs,
-                          const MsgView &m, uint8_t *tags, int32_t *status, hipStream_t s)
+                          const MsgView &m, uint8_t *tags, int32_t *status, hipStream_t s, const char *ke_custom = "SKE",
+                          const char *ka_custom = "SKA")
 {
     if (!valid_d(d)) return fail(CAPY_ERR_UNSUPPORTED_SECPARAM, "unsupported security parameter");
     if (n == 0) return CAPY_OK;
@@ -410,10 +412,12 @@ static int sha3_crypt_dev(bool encrypt, int d, size_t n, const uint8_t *pws, siz
     MsgView none;
     int rc = kmac_launch(d, n, zpw, zk, zk, none, true, (const uint8_t *)"S", 1, 0, keka, 128, 128, nullptr, s);
     auto keystream = [&](const int32_t *mask) {  // msg ^= kmac_xof(ke, "", |msg|, "SKE")
-        return kmac_launch(d, n, keka, 64, 128, m, false, (const uint8_t *)"SKE", 3, 1, nullptr, 0, 0, mask, s);
+        return kmac_launch(d, n, keka, 64, 128, m, false, (const uint8_t *)ke_custom, strlen(ke_custom), 1, nullptr, 0, 0,
+                           mask, s);
     };
     auto tag = [&](uint8_t *out) {  // kmac_xof(ka, msg, 512, "SKA")
-        return kmac_launch(d, n, keka + 64, 64, 128, m, true, (const uint8_t *)"SKA", 3, 0, out, 64, 64, nullptr, s);
+        return kmac_launch(d, n, keka + 64, 64, 128, m, true, (const uint8_t *)ka_custom, strlen(ka_custom), 0, out, 64, 64,
+                           nullptr, s);
     };
     if (rc == CAPY_OK) {
         if (encrypt) {
@@ -629,7 +633,8 @@ int capy_sha3_decrypt_batch_dev(int d, size_t n, const uint8_t *pws, size_t pw_l
 }
 
 static int sha3_crypt_host(bool encrypt, int d, size_t n, const uint8_t *pws, size_t pw_len, const uint8_t *zs,
-                           uint8_t *msgs, const uint64_t *offsets, uint8_t *tags, int32_t *status)
+                           uint8_t *msgs, const uint64_t *offsets, uint8_t *tags, int32_t *status,
+                           const char *ke_custom = "SKE", const char *ka_custom = "SKA")
 {
     if (!valid_d(d)) return fail(CAPY_ERR_UNSUPPORTED_SECPARAM, "unsupported security parameter");
     if (n == 0) return CAPY_OK;
@@ -646,7 +651,7 @@ static int sha3_crypt_host(bool encrypt, int d, size_t n, const uint8_t *pws, si
     CAPY_HIP(hipMemcpy(dz.p, zs, n * 512, hipMemcpyHostToDevice));
     if (!encrypt) CAPY_HIP(hipMemcpy(dtag.p, tags, n * 64, hipMemcpyHostToDevice));
     rc = sha3_crypt_dev(encrypt, d, n, dpw.as<uint8_t>(), pw_len, dz.as<uint8_t>(), view_of(b), dtag.as<uint8_t>(),
-                        dst.as<int32_t>(), nullptr);
+                        dst.as<int32_t>(), nullptr, ke_custom, ka_custom);
     if (rc) return rc;
     CAPY_HIP(hipStreamSynchronize(nullptr));
     rc = b.download(n, msgs, offsets);
@@ -669,6 +674,21 @@ int capy_sha3_decrypt_batch(int d, size_t n, const uint8_t *pws, size_t pw_len, 
 {
     if (!status) return fail(CAPY_ERR_ARG, "null status");
     return sha3_crypt_host(false, d, n, pws, pw_len, zs, msgs, offsets, const_cast<uint8_t *>(tags), status);
+}
+
+// ---------------------------------------------------------------- KEMEncryptable, sponge half
+int capy_kem_sponge_encrypt_batch(int d, size_t n, const uint8_t *secrets, size_t secret_len, const uint8_t *zs,
+                                  uint8_t *msgs, const uint64_t *offsets, uint8_t *tags)
+{
+    return sha3_crypt_host(true, d, n, secrets, secret_len, zs, msgs, offsets, tags, nullptr, "KEMKE", "KEMKA");
+}
+
+int capy_kem_sponge_decrypt_batch(int d, size_t n, const uint8_t *secrets, size_t secret_len, const uint8_t *zs,
+                                  uint8_t *msgs, const uint64_t *offsets, const uint8_t *tags, int32_t *status)
+{
+    if (!status) return fail(CAPY_ERR_ARG, "null status");
+    return sha3_crypt_host(false, d, n, secrets, secret_len, zs, msgs, offsets, const_cast<uint8_t *>(tags), status,
+                           "KEMKE", "KEMKA");
 }
 
 // ---------------------------------------------------------------- measurement helpers

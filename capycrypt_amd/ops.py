@@ -81,6 +81,34 @@ def sha3_decrypt_batch(pws, zs, cts, tags, d):
     return [raw[offs[i]:offs[i + 1]] for i in range(n)], [status[i] == 0 for i in range(n)]
 
 
+def kem_sponge_encrypt_batch(secrets, zs, msgs, d):
+    """Sponge half of kem_encrypt(), /root/reference/src/kem/encryptable.rs:47-59 -> (ciphertexts, tags)."""
+    d = _d(d)
+    n = len(msgs)
+    slen = len(secrets[0]) if n else 0
+    assert all(len(p) == slen for p in secrets) and all(len(z) == 512 for z in zs)
+    data, offs = L.pack(msgs)
+    tags = (C.c_uint8 * max(1, 64 * n))()
+    L.check(L.lib().capy_kem_sponge_encrypt_batch(d, n, L.buf(b"".join(map(bytes, secrets))), slen,
+                                                  L.buf(b"".join(map(bytes, zs))), data, offs, tags))
+    raw, t = bytes(data), bytes(tags)
+    return [raw[offs[i]:offs[i + 1]] for i in range(n)], [t[64 * i:64 * i + 64] for i in range(n)]
+
+
+def kem_sponge_decrypt_batch(secrets, zs, cts, tags, d):
+    """Sponge half of kem_decrypt(), /root/reference/src/kem/encryptable.rs:84-104 -> (messages, ok flags)."""
+    d = _d(d)
+    n = len(cts)
+    slen = len(secrets[0]) if n else 0
+    data, offs = L.pack(cts)
+    status = (C.c_int32 * max(1, n))()
+    L.check(L.lib().capy_kem_sponge_decrypt_batch(d, n, L.buf(b"".join(map(bytes, secrets))), slen,
+                                                  L.buf(b"".join(map(bytes, zs))), data, offs,
+                                                  L.buf(b"".join(map(bytes, tags))), status))
+    raw = bytes(data)
+    return [raw[offs[i]:offs[i + 1]] for i in range(n)], [status[i] == 0 for i in range(n)]
+
+
 # ------------------------------------------------------------------ Ed448
 def ed448_scalarmul_batch(scalars_be, points_xy):
     n = len(scalars_be)

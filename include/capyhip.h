@@ -89,6 +89,14 @@ int capy_sha3_decrypt_batch_dev(int d, size_t n, const uint8_t *pws, size_t pw_l
                                 uint8_t *msgs, const uint64_t *offsets, uint64_t uniform_len,
                                 uint64_t msg_stride, const uint8_t *tags, int32_t *status, void *stream);
 
+/* The sponge half of KEMEncryptable::kem_encrypt / kem_decrypt, src/kem/encryptable.rs:47-59, 84-104
+ * (SURVEY.md §8f rank 1): identical flow to sha3_encrypt with the ML-KEM shared secret in place of the
+ * password and the customisation strings "KEMKE" / "KEMKA".  ML-KEM itself (capy_kem) stays on the host. */
+int capy_kem_sponge_encrypt_batch(int d, size_t n, const uint8_t *secrets, size_t secret_len, const uint8_t *zs,
+                                  uint8_t *msgs, const uint64_t *offsets, uint8_t *tags);
+int capy_kem_sponge_decrypt_batch(int d, size_t n, const uint8_t *secrets, size_t secret_len, const uint8_t *zs,
+                                  uint8_t *msgs, const uint64_t *offsets, const uint8_t *tags, int32_t *status);
+
 /* ------------------------------------------------------------------ Ed448 (tiny_ed448_goldilocks boundary) */
 
 /* out_i = [scalar_i] P_i  — `ExtendedPoint * Scalar` followed by to_affine()

@@ -157,6 +157,27 @@ def test_sha3_encrypt_decrypt_matches_oracle(capy, O, d):
             assert ok[i] and pts[i] == msgs[i]
 
 
+def test_kem_sponge_half_matches_oracle(capy, O):
+    """kem_encrypt's sponge half (src/kem/encryptable.rs:51-57) = the same KMAC flow with
+    tags KEMKE / KEMKA; the oracle side is composed from kmac_xof exactly as the reference composes it."""
+    rng = random.Random(42)
+    msgs = [rng.randbytes(n) for n in (0, 1, 135, 136, 1000, 70001)]
+    secrets = [rng.randbytes(32) for _ in msgs]
+    zs = [rng.randbytes(512) for _ in msgs]
+    for d in (256, 512):
+        cts, tags = capy.ops.kem_sponge_encrypt_batch(secrets, zs, msgs, d)
+        for m, k, z, c, t in zip(msgs, secrets, zs, cts, tags):
+            ke_ka = O.kmac_xof(z + k, b"", 1024, b"S", d)
+            assert t == O.kmac_xof(ke_ka[64:], m, 512, b"KEMKA", d)
+            ks = O.kmac_xof(ke_ka[:64], b"", len(m) * 8, b"KEMKE", d)
+            assert c == bytes(a ^ b for a, b in zip(m, ks))
+        pts, ok = capy.ops.kem_sponge_decrypt_batch(secrets, zs, cts, tags, d)
+        assert all(ok) and pts == msgs
+        bad = [secrets[0]] + [rng.randbytes(32)] + secrets[2:]
+        pts, ok = capy.ops.kem_sponge_decrypt_batch(bad, zs, cts, tags, d)
+        assert not ok[1] and pts[1] == cts[1] and ok[0] and ok[2]
+
+
 def test_sha3_decrypt_handling_bad_input_like_reference(capy):
     pw1, pw2 = capy.get_random_bytes(64), capy.get_random_bytes(64)
     new_msg = capy.Message(capy.get_random_bytes(523))
