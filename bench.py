@@ -99,16 +99,23 @@ def main():
     if a.gpus != world and world == 1 and a.gpus > 1:
         print("bench.py: --gpus %d needs torch.distributed.run with %d ranks" % (a.gpus, a.gpus), file=sys.stderr)
         sys.exit(2)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % max(1, ndev)  # == local_rank on a real N-GPU node; lets 2 ranks share 1 GPU in rehearsals
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    backend = os.environ.get("CAPY_BENCH_BACKEND", "nccl")  # "gloo" only for single-GPU rehearsals of the N>1 path
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+    red_dev = dev if backend == "nccl" else torch.device("cpu")
 
     from capycrypt_amd import _lib
 
     lib = _lib.lib()
-    _lib.check(lib.capy_set_device(local_rank))
+    _lib.check(lib.capy_set_device(dev_index))
     stream = torch.cuda.current_stream()
     sp = C.c_void_p(stream.cuda_stream)
 
@@ -146,7 +153,7 @@ def main():
     el = time.perf_counter() - t0
     kern_ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / max(1, a.steps)
     if world > 1:
-        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        t = torch.tensor([el], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
 
@@ -184,7 +191,7 @@ def main():
             barrier()
             eel = time.perf_counter() - t1
             if world > 1:
-                t = torch.tensor([eel], dtype=torch.float64, device=dev)
+                t = torch.tensor([eel], dtype=torch.float64, device=red_dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 eel = float(t.item())
             ed = {"pairs_per_gpu": n, "scalar_mults_per_s": world * n * reps / eel,
