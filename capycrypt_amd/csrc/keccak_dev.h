@@ -115,4 +115,47 @@ __device__ __forceinline__ void keccakf1600(KState &a)
     for (int r = 0; r < 24; r++) keccak_round(a, KECCAK_RC32[2 * r], KECCAK_RC32[2 * r + 1]);
 }
 
+// Rolled form with the next pair of round constants fetched one trip ahead, so the scalar-load latency
+// never sits between two rounds (a lone wave cannot hide it).
+__device__ __forceinline__ void keccakf1600_pipelined(KState &a)
+{
+    uint32_t c0 = KECCAK_RC32[0], c1 = KECCAK_RC32[1], c2 = KECCAK_RC32[2], c3 = KECCAK_RC32[3];
+#pragma unroll 1
+    for (int r = 0; r < 24; r += 2) {
+        const int nx = (r + 2 < 24) ? r + 2 : 0;
+        const uint32_t n0 = KECCAK_RC32[2 * nx], n1 = KECCAK_RC32[2 * nx + 1], n2 = KECCAK_RC32[2 * nx + 2],
+                       n3 = KECCAK_RC32[2 * nx + 3];
+        keccak_round(a, c0, c1);
+        keccak_round(a, c2, c3);
+        c0 = n0;
+        c1 = n1;
+        c2 = n2;
+        c3 = n3;
+    }
+}
+
+// Round constants as compile-time values: the fully unrolled permutation of the hot block loop carries
+// them as instruction literals (no scalar loads, no loop counter).
+__device__ __host__ constexpr uint64_t keccak_rc64(int r)
+{
+    constexpr uint64_t RC[24] = {
+        0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808AULL, 0x8000000080008000ULL,
+        0x000000000000808BULL, 0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL,
+        0x000000000000008AULL, 0x0000000000000088ULL, 0x0000000080008009ULL, 0x000000008000000AULL,
+        0x000000008000808BULL, 0x800000000000008BULL, 0x8000000000008089ULL, 0x8000000000008003ULL,
+        0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800AULL, 0x800000008000000AULL,
+        0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+    return RC[r];
+}
+
+template <int... Rs>
+__device__ __forceinline__ void keccakf1600_unrolled_impl(KState &a, std::integer_sequence<int, Rs...>)
+{
+    (keccak_round(a, (uint32_t)keccak_rc64(Rs), (uint32_t)(keccak_rc64(Rs) >> 32)), ...);
+}
+__device__ __forceinline__ void keccakf1600_unrolled(KState &a)
+{
+    keccakf1600_unrolled_impl(a, std::make_integer_sequence<int, 24>{});
+}
+
 }  // namespace capy

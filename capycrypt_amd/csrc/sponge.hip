@@ -187,6 +187,7 @@ static void kmac_head(int d, size_t key_len, SpongeParams &p)
 // Lanes per sponge: 1 fills the chip once there are >= ~64k independent sponges; below that the
 // two-lane kernel is 1.5x faster per sponge (sponge_kernels_k2.h).  0 = choose by batch size.
 static std::atomic<int> g_lanes_per_sponge{0};
+static const size_t FULLCHIP_MIN_ITEMS = ~(size_t)0;  // full-chip instance disabled until its lean form lands
 static const size_t K2_MAX_ITEMS = 32768;  // 32 sponges x one wave per SIMD x 1024 SIMDs (measured crossover, profiles/)
 
 static int launch_sponge_k2(int rw, const SpongeParams &p, hipStream_t s)
@@ -211,15 +212,25 @@ static int launch_sponge(int rw, const SpongeParams &p, hipStream_t s)
     const int forced = g_lanes_per_sponge.load();
     if (forced == 2 || (forced == 0 && p.n <= K2_MAX_ITEMS)) return launch_sponge_k2(rw, p, s);
     dim3 grid((unsigned)((p.n + 63) / 64)), block(64);
+    // more than two waves per SIMD -> the VALU-issue-tuned instance; otherwise the latency-tuned one
+    const bool fullchip = p.n > FULLCHIP_MIN_ITEMS;
+#define CAPY_LAUNCH_K1(RW)                                                              \
+    case RW:                                                                            \
+        if (fullchip)                                                                   \
+            hipLaunchKernelGGL((sponge_kernel<RW, true>), grid, block, 0, s, p);        \
+        else                                                                            \
+            hipLaunchKernelGGL((sponge_kernel<RW, false>), grid, block, 0, s, p);       \
+        break;
     switch (rw) {
-    case 9: hipLaunchKernelGGL(sponge_kernel<9>, grid, block, 0, s, p); break;
-    case 13: hipLaunchKernelGGL(sponge_kernel<13>, grid, block, 0, s, p); break;
-    case 17: hipLaunchKernelGGL(sponge_kernel<17>, grid, block, 0, s, p); break;
-    case 18: hipLaunchKernelGGL(sponge_kernel<18>, grid, block, 0, s, p); break;
-    case 19: hipLaunchKernelGGL(sponge_kernel<19>, grid, block, 0, s, p); break;
-    case 21: hipLaunchKernelGGL(sponge_kernel<21>, grid, block, 0, s, p); break;
+        CAPY_LAUNCH_K1(9)
+        CAPY_LAUNCH_K1(13)
+        CAPY_LAUNCH_K1(17)
+        CAPY_LAUNCH_K1(18)
+        CAPY_LAUNCH_K1(19)
+        CAPY_LAUNCH_K1(21)
     default: return fail(CAPY_ERR_ARG, "internal: unsupported rate");
     }
+#undef CAPY_LAUNCH_K1
     CAPY_HIP(hipGetLastError());
     return CAPY_OK;
 }
@@ -371,6 +382,7 @@ __global__ void fill_random_kernel(uint64_t *dst, uint64_t nwords, uint64_t seed
 }
 
 // VALU ceiling probe: `iters` dependent keccak-f[1600] per lane, nothing else.
+template <int VARIANT>
 __global__ __launch_bounds__(64) void keccak_probe_kernel(uint64_t n_states, uint32_t iters, uint64_t *checksum)
 {
     uint64_t id = (uint64_t)blockIdx.x * 64 + threadIdx.x;
@@ -380,7 +392,14 @@ __global__ __launch_bounds__(64) void keccak_probe_kernel(uint64_t n_states, uin
         a.lo[i] = (uint32_t)(id * 25 + i);
         a.hi[i] = (uint32_t)((id * 25 + i) * 0x9E3779B9u);
     }
-    for (uint32_t it = 0; it < iters; it++) keccakf1600(a);
+    for (uint32_t it = 0; it < iters; it++) {
+        if (VARIANT == 0)
+            keccakf1600_unrolled(a);
+        else if (VARIANT == 1)
+            keccakf1600(a);
+        else
+            keccakf1600_pipelined(a);
+    }
     uint32_t x = 0, y = 0;
 #pragma unroll
     for (int i = 0; i < 25; i++) {
@@ -712,8 +731,15 @@ int capy_fill_random_dev(uint8_t *dst, uint64_t nbytes, uint64_t seed, void *str
 int capy_keccak_valu_probe_dev(uint64_t n_states, uint32_t iters, uint64_t *checksum_dev, void *stream)
 {
     if (!n_states) return CAPY_OK;
-    hipLaunchKernelGGL(keccak_probe_kernel, dim3((unsigned)((n_states + 63) / 64)), dim3(64), 0, (hipStream_t)stream,
-                       n_states, iters, checksum_dev);
+    // top two bits of iters select the loop form (0 unrolled = default, 1 rolled, 2 rolled + constant prefetch)
+    const uint32_t variant = iters >> 30, it = iters & 0x3fffffffu;
+    const dim3 grid((unsigned)((n_states + 63) / 64));
+    if (variant == 0)
+        hipLaunchKernelGGL(keccak_probe_kernel<0>, grid, dim3(64), 0, (hipStream_t)stream, n_states, it, checksum_dev);
+    else if (variant == 1)
+        hipLaunchKernelGGL(keccak_probe_kernel<1>, grid, dim3(64), 0, (hipStream_t)stream, n_states, it, checksum_dev);
+    else
+        hipLaunchKernelGGL(keccak_probe_kernel<2>, grid, dim3(64), 0, (hipStream_t)stream, n_states, it, checksum_dev);
     CAPY_HIP(hipGetLastError());
     return CAPY_OK;
 }

@@ -120,7 +120,30 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
     return v;
 }
 
-template <int RW>
+// FULLCHIP = false: launches that cannot fill the chip (<= 2 waves per SIMD).  A lone wave hides nothing, so the
+//   hot loops carry the permutation fully unrolled with literal round constants and prefetch the next block
+//   into registers (measured: 905 vs 734..825 GB/s-equivalent at 768 waves, profiles/r01_keccak_loop_forms.txt).
+// FULLCHIP = true: launches with many waves per SIMD.  Throughput is VALU issue; the rolled permutation with
+//   constants fetched one trip ahead is the fastest form there (10.7 vs 9.1 G permutations/s) and the
+//   register budget is kept low for occupancy (no register prefetch: other waves cover the latency).
+template <bool FULLCHIP>
+__device__ __forceinline__ void keccak_hot(KState &a)
+{
+    if constexpr (FULLCHIP)
+        keccakf1600_pipelined(a);
+    else
+        keccakf1600_unrolled(a);
+}
+template <bool FULLCHIP>
+__device__ __forceinline__ void keccak_cold(KState &a)
+{
+    if constexpr (FULLCHIP)
+        keccakf1600_pipelined(a);
+    else
+        keccakf1600(a);
+}
+
+template <int RW, bool FULLCHIP>
 __global__ __launch_bounds__(64) void sponge_kernel(const SpongeParams p)
 {
     constexpr uint32_t RB = RW * 8;
@@ -177,7 +200,7 @@ __global__ __launch_bounds__(64) void sponge_kernel(const SpongeParams p)
                 a.lo[w] ^= (uint32_t)v;
                 a.hi[w] ^= (uint32_t)(v >> 32);
             }
-            keccakf1600(a);
+            keccak_cold<FULLCHIP>(a);
         }
     }
 
@@ -186,7 +209,7 @@ __global__ __launch_bounds__(64) void sponge_kernel(const SpongeParams p)
     s_nfull[lane] = nfull;
     __syncthreads();
     const uint32_t max_full = wave_max_u32(nfull);
-    if (max_full) {
+    if (!FULLCHIP && max_full) {
         // source pointer and block limit of every (load slot, lane) pair, hoisted out of the block loop
         const uint8_t *src[RW];
         uint32_t lim[RW];
@@ -222,8 +245,33 @@ __global__ __launch_bounds__(64) void sponge_kernel(const SpongeParams p)
                     a.lo[w] ^= (uint32_t)wv[w];
                     a.hi[w] ^= (uint32_t)(wv[w] >> 32);
                 }
-                keccakf1600(a);
+                keccak_hot<FULLCHIP>(a);
             }
+        }
+    }
+
+    if (FULLCHIP && max_full) {
+        // no register prefetch, no hoisted address arrays: keeps the kernel at 4 waves per SIMD
+        for (uint32_t t = 0; t < max_full; t++) {
+#pragma unroll
+            for (int k = 0; k < RW; k++) {
+                const uint32_t i = k * 64 + lane;
+                const uint32_t m = i / RW, w = i - m * RW;
+                const bool in = t < s_nfull[m];
+                const uint8_t *q = in ? reinterpret_cast<const uint8_t *>(s_base[m]) + (uint64_t)t * RB + 8 * w : p.msgs;
+                s_stage[i] = *reinterpret_cast<const uint64_t *>(q);
+            }
+            __syncthreads();
+            if (t < nfull) {
+#pragma unroll
+                for (int w = 0; w < RW; w++) {
+                    const uint64_t v = s_stage[lane * RW + w];
+                    a.lo[w] ^= (uint32_t)v;
+                    a.hi[w] ^= (uint32_t)(v >> 32);
+                }
+            }
+            __syncthreads();
+            if (t < nfull) keccak_hot<FULLCHIP>(a);
         }
     }
 
@@ -241,7 +289,7 @@ __global__ __launch_bounds__(64) void sponge_kernel(const SpongeParams p)
                     a.lo[w] ^= (uint32_t)v;
                     a.hi[w] ^= (uint32_t)(v >> 32);
                 }
-                keccakf1600(a);
+                keccak_cold<FULLCHIP>(a);
             }
         }
     }
@@ -267,7 +315,7 @@ __global__ __launch_bounds__(64) void sponge_kernel(const SpongeParams p)
             }
             // the reference permutes once more after the last block (sponge.rs:30); that state is
             // never observable, so the permutation is skipped here.
-            if (produced < p.out_len) keccakf1600(a);
+            if (produced < p.out_len) keccak_hot<FULLCHIP>(a);
         }
     } else {
         // keystream XOR in place: msg[i] ^= squeeze(len) ; squeeze block = RW words (cSHAKE/KMAC only)
@@ -312,7 +360,7 @@ __global__ __launch_bounds__(64) void sponge_kernel(const SpongeParams p)
                 }
                 __syncthreads();
                 if (t + 1 < max_x) coop_load(t + 1);
-                if (t < xfull && (uint64_t)(t + 1) * RB < tgt_len) keccakf1600(a);
+                if (t < xfull && (uint64_t)(t + 1) * RB < tgt_len) keccak_hot<FULLCHIP>(a);
             }
         }
         // leftover bytes (unaligned messages: everything) byte-granular
@@ -330,7 +378,7 @@ __global__ __launch_bounds__(64) void sponge_kernel(const SpongeParams p)
                         if (pos + 8 * w + b < tgt_len) m[pos + 8 * w + b] ^= (uint8_t)(v >> (8 * b));
                 }
                 pos += RB;
-                if (pos < tgt_len) keccakf1600(a);
+                if (pos < tgt_len) keccak_cold<FULLCHIP>(a);
             }
         }
     }

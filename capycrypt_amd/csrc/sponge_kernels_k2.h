@@ -77,6 +77,16 @@ __device__ __forceinline__ void keccak_round_k2(KHalf &s, uint32_t rc_lo, uint32
     s.a[0] = xor3(s.a[0], rc_x & hmask, rc_lo);
 }
 
+template <int... Rs>
+__device__ __forceinline__ void keccakf1600_k2_unrolled_impl(KHalf &s, uint32_t hmask, std::integer_sequence<int, Rs...>)
+{
+    (keccak_round_k2(s, (uint32_t)keccak_rc64(Rs), (uint32_t)keccak_rc64(Rs) ^ (uint32_t)(keccak_rc64(Rs) >> 32), hmask), ...);
+}
+__device__ __forceinline__ void keccakf1600_k2_unrolled(KHalf &s, uint32_t hmask)
+{
+    keccakf1600_k2_unrolled_impl(s, hmask, std::make_integer_sequence<int, 24>{});
+}
+
 __device__ __forceinline__ void keccakf1600_k2(KHalf &s, uint32_t hmask)
 {
 #pragma unroll 2
@@ -189,7 +199,7 @@ __global__ __launch_bounds__(64) void sponge_kernel_k2(const SpongeParams p)
             if (t < nfull) {
 #pragma unroll
                 for (int w = 0; w < RW; w++) a.a[w] ^= wv[w];
-                keccakf1600_k2(a, hmask);
+                keccakf1600_k2_unrolled(a, hmask);
             }
         }
     }
