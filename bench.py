@@ -21,10 +21,10 @@ sys.path.insert(0, ROOT)
 
 MSG_BYTES = 5242880  # benches/benchmark_sha3.rs:17
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-# Integer-VALU ceiling for keccak-f[1600] on MI355X, MEASURED (profiles/r01_keccak_probe_and_size_sweep.txt):
-# a register-resident loop of nothing but permutations tops out at 10.06e9 permutations/s with 16k waves,
-# i.e. 1368 GB/s of absorbed message at 136 B per permutation ("Rooflines").
-VALU_CEIL_GBS = 10.06e9 * 136.0 / 1e9
+# Integer-VALU ceiling for keccak-f[1600] on MI355X, MEASURED (profiles/r01_keccak_loop_forms.txt): a
+# register-resident loop of nothing but permutations tops out at 10.68e9 permutations/s (16k waves, best loop
+# form), i.e. 1453 GB/s of absorbed message at 136 B per permutation ("Rooflines").
+VALU_CEIL_GBS = 10.68e9 * 136.0 / 1e9
 
 
 def parse():
@@ -228,7 +228,8 @@ def main():
                        "batch_per_gpu": B, "msg_bytes": MSG_BYTES, "parallelism": "batch-sharded x%d, no collective" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "sponge_kernel_k2<17>" if (a.lanes == 2 or (a.lanes == 0 and B <= 32768)) else "sponge_kernel<17>",
+                         "kernel": "sponge_kernel_k2<17,0>" if (a.lanes == 2 or (a.lanes == 0 and B <= 32768)) else
+                         ("sponge_kernel<17,true,0>" if B > 131072 else "sponge_kernel<17,false,0>"),
                          "kernel_ms": kern_ms,
                          "valu_ceiling_GBs": VALU_CEIL_GBS, "frac_of_valu_ceiling": achieved / VALU_CEIL_GBS},
         }

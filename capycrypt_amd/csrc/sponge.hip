@@ -5,8 +5,7 @@
 #include <algorithm>
 #include <atomic>
 #include "common.h"
-#include "sponge_kernels.h"
-#include "sponge_kernels_k2.h"
+#include "sponge_launch.h"
 #include "sponge_host.h"
 
 namespace capy {
@@ -187,51 +186,26 @@ static void kmac_head(int d, size_t key_len, SpongeParams &p)
 // Lanes per sponge: 1 fills the chip once there are >= ~64k independent sponges; below that the
 // two-lane kernel is 1.5x faster per sponge (sponge_kernels_k2.h).  0 = choose by batch size.
 static std::atomic<int> g_lanes_per_sponge{0};
-static const size_t FULLCHIP_MIN_ITEMS = ~(size_t)0;  // full-chip instance disabled until its lean form lands
+static std::atomic<unsigned> g_debug_flags{0};
+static const size_t FULLCHIP_MIN_ITEMS = 131072;  // > 2 waves per SIMD (64 sponges x 2 x 1024 SIMDs)
 static const size_t K2_MAX_ITEMS = 32768;  // 32 sponges x one wave per SIMD x 1024 SIMDs (measured crossover, profiles/)
-
-static int launch_sponge_k2(int rw, const SpongeParams &p, hipStream_t s)
-{
-    dim3 grid((unsigned)((p.n + 31) / 32)), block(64);
-    switch (rw) {
-    case 9: hipLaunchKernelGGL(sponge_kernel_k2<9>, grid, block, 0, s, p); break;
-    case 13: hipLaunchKernelGGL(sponge_kernel_k2<13>, grid, block, 0, s, p); break;
-    case 17: hipLaunchKernelGGL(sponge_kernel_k2<17>, grid, block, 0, s, p); break;
-    case 18: hipLaunchKernelGGL(sponge_kernel_k2<18>, grid, block, 0, s, p); break;
-    case 19: hipLaunchKernelGGL(sponge_kernel_k2<19>, grid, block, 0, s, p); break;
-    case 21: hipLaunchKernelGGL(sponge_kernel_k2<21>, grid, block, 0, s, p); break;
-    default: return fail(CAPY_ERR_ARG, "internal: unsupported rate");
-    }
-    CAPY_HIP(hipGetLastError());
-    return CAPY_OK;
-}
 
 static int launch_sponge(int rw, const SpongeParams &p, hipStream_t s)
 {
     if (p.n == 0) return CAPY_OK;
     const int forced = g_lanes_per_sponge.load();
-    if (forced == 2 || (forced == 0 && p.n <= K2_MAX_ITEMS)) return launch_sponge_k2(rw, p, s);
-    dim3 grid((unsigned)((p.n + 63) / 64)), block(64);
-    // more than two waves per SIMD -> the VALU-issue-tuned instance; otherwise the latency-tuned one
-    const bool fullchip = p.n > FULLCHIP_MIN_ITEMS;
-#define CAPY_LAUNCH_K1(RW)                                                              \
-    case RW:                                                                            \
-        if (fullchip)                                                                   \
-            hipLaunchKernelGGL((sponge_kernel<RW, true>), grid, block, 0, s, p);        \
-        else                                                                            \
-            hipLaunchKernelGGL((sponge_kernel<RW, false>), grid, block, 0, s, p);       \
-        break;
-    switch (rw) {
-        CAPY_LAUNCH_K1(9)
-        CAPY_LAUNCH_K1(13)
-        CAPY_LAUNCH_K1(17)
-        CAPY_LAUNCH_K1(18)
-        CAPY_LAUNCH_K1(19)
-        CAPY_LAUNCH_K1(21)
-    default: return fail(CAPY_ERR_ARG, "internal: unsupported rate");
-    }
-#undef CAPY_LAUNCH_K1
-    CAPY_HIP(hipGetLastError());
+    SpongeParams q = p;
+    q.debug_flags = g_debug_flags.load();
+    const SpongeParams &p2 = q;
+    hipError_t e;
+    if (forced == 2 || (forced == 0 && p.n <= K2_MAX_ITEMS))
+        e = launch_sponge_k2(rw, (int)p.out_mode, p2, s);
+    else if (p.n > FULLCHIP_MIN_ITEMS)
+        e = launch_sponge_k1_full(rw, (int)p.out_mode, p2, s);
+    else
+        e = launch_sponge_k1_lat(rw, (int)p.out_mode, p2, s);
+    if (e == hipErrorInvalidValue) return fail(CAPY_ERR_ARG, "internal: no kernel instance for this rate / mode");
+    CAPY_HIP(e);
     return CAPY_OK;
 }
 
@@ -713,6 +687,8 @@ int capy_kem_sponge_decrypt_batch(int d, size_t n, const uint8_t *secrets, size_
 // ---------------------------------------------------------------- measurement helpers
 int capy_set_sponge_lanes(int lanes)
 {
+    g_debug_flags.store((unsigned)lanes >> 8);  // undocumented A/B switches in the high bits
+    lanes &= 0xff;
     if (lanes != 0 && lanes != 1 && lanes != 2) return fail(CAPY_ERR_ARG, "lanes must be 0 (auto), 1 or 2");
     g_lanes_per_sponge.store(lanes);
     return CAPY_OK;

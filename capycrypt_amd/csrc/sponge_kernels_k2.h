@@ -14,7 +14,7 @@
 //
 // Same stream semantics, parameters and phases as sponge_kernels.h (which documents the framing).
 #pragma once
-#include "sponge_kernels.h"
+#include "sponge_params.h"
 
 namespace capy {
 
@@ -96,7 +96,7 @@ __device__ __forceinline__ void keccakf1600_k2(KHalf &s, uint32_t hmask)
     }
 }
 
-template <int RW>
+template <int RW, int MODE>
 __global__ __launch_bounds__(64) void sponge_kernel_k2(const SpongeParams p)
 {
     constexpr uint32_t RB = RW * 8;
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(64) void sponge_kernel_k2(const SpongeParams p)
     }
 
     // ---------------- squeeze
-    if (p.out_mode == 0) {
+    if constexpr (MODE == 0) {
         uint8_t *o = active ? p.out + item * p.out_stride : nullptr;
         uint32_t produced = 0;
         while (produced < p.out_len) {

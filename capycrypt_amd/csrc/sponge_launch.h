@@ -1,0 +1,14 @@
+// sponge_launch.h — the sponge kernel instances live in three translation units (built in parallel);
+// each exports one launcher.  mode: 0 digest, 1 keystream XOR.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "sponge_params.h"
+
+namespace capy {
+// one lane per sponge, latency-tuned instance (launches that cannot fill the chip)
+hipError_t launch_sponge_k1_lat(int rw, int mode, const SpongeParams &p, hipStream_t s);
+// one lane per sponge, issue-tuned instance (many waves per SIMD)
+hipError_t launch_sponge_k1_full(int rw, int mode, const SpongeParams &p, hipStream_t s);
+// two lanes per sponge (small batches of long messages)
+hipError_t launch_sponge_k2(int rw, int mode, const SpongeParams &p, hipStream_t s);
+}  // namespace capy

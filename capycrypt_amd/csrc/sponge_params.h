@@ -1,0 +1,109 @@
+// sponge_params.h — launch parameters and the byte-granular view of a sponge's input stream
+// (shared by the one-lane and two-lane kernels).  See sponge_kernels.h for the framing.
+#pragma once
+#include "keccak_dev.h"
+
+namespace capy {
+
+struct SpongeParams {
+    uint64_t init_state[25];  // state after the batch-shared prefix (zeros for SHA3)
+    // batch-shared prefix bytes that could NOT be folded into init_state (only when the prefix is
+    // not a whole number of absorb blocks, i.e. cSHAKE/KMAC at D224 where r = 172 but 168 B are consumed)
+    const uint8_t *pre;
+    uint32_t pre_len;
+    // per-item head = hdr bytes || key bytes || zeros up to head_len   (head_len = 0: no head)
+    const uint8_t *keys;
+    uint64_t key_stride;
+    uint32_t key_len;
+    uint32_t hdr_len;
+    uint64_t hdr0, hdr1;  // up to 16 header bytes, little-endian packed
+    uint32_t head_len;
+    // body / xor target
+    const uint8_t *msgs;
+    const uint64_t *offsets;  // n+1 byte offsets into msgs, or null: item i at msgs + i*msg_stride
+    const uint64_t *lens;     // optional n lengths (aligned re-packed batches); null: offsets[i+1]-offsets[i]
+    uint64_t msg_stride;
+    uint64_t uniform_len;
+    uint32_t absorb_body;  // 0: the body is not absorbed (keystream mode: X = "")
+    // trailer
+    uint64_t suffix;  // up to 8 suffix bytes, little-endian packed
+    uint32_t suffix_len;
+    uint32_t sha3_suffix_rule;  // reference shake(): first suffix byte is 0x86 iff len % 136 == 135
+    uint32_t fips_pad;          // 0: reference pad rule (pad only if unaligned); 1: FIPS 202 pad10*1
+    uint32_t stride_bytes;      // the reference's `r` (172 for cSHAKE/KMAC at D224), else 8*RW
+    // output
+    uint32_t out_mode;  // 0: write out_len bytes per item; 1: XOR keystream into msgs in place
+    uint32_t sq_words;  // words emitted per squeeze block
+    uint8_t *out;
+    uint64_t out_stride;
+    uint32_t out_len;
+    const int32_t *mask;  // optional: only items with mask[i] != 0 are processed
+    uint32_t debug_flags;  // bit 0: do not use the wave-uniform addressing path (A/B measurements)
+    uint64_t n;
+};
+
+struct ItemCtx {
+    const uint8_t *key;
+    const uint8_t *msg;
+    uint64_t len;     // absorbed body length
+    uint64_t padded;  // head + body + suffix + pad
+    uint64_t suffix;
+    bool pad80;
+};
+
+__device__ __forceinline__ uint32_t stream_byte(const SpongeParams &p, const ItemCtx &c, uint64_t pos)
+{
+    uint32_t v = 0;
+    if (pos < p.pre_len) {
+        v = p.pre[pos];
+        if (c.pad80 && pos + 1 == c.padded) v |= 0x80;
+        return v;
+    }
+    pos -= p.pre_len;
+    if (pos < p.head_len) {
+        if (pos < p.hdr_len) {
+            v = (uint32_t)((pos < 8 ? p.hdr0 >> (8 * pos) : p.hdr1 >> (8 * (pos - 8))) & 0xff);
+        } else {
+            uint64_t k = pos - p.hdr_len;
+            if (k < p.key_len) v = c.key[k];
+        }
+    } else {
+        uint64_t q = pos - p.head_len;
+        if (q < c.len) {
+            v = c.msg[q];
+        } else {
+            q -= c.len;
+            if (q < p.suffix_len) v = (uint32_t)((c.suffix >> (8 * q)) & 0xff);
+        }
+    }
+    if (c.pad80 && pos + p.pre_len + 1 == c.padded) v |= 0x80;
+    return v;
+}
+
+__device__ __forceinline__ uint64_t stream_word(const SpongeParams &p, const ItemCtx &c, uint64_t pos)
+{
+    const uint64_t body0 = (uint64_t)p.pre_len + p.head_len;
+    // whole word inside the body and 8-byte aligned in memory: one load
+    if (pos >= body0 && pos + 8 <= body0 + c.len) {
+        const uint8_t *a = c.msg + (pos - body0);
+        if (((uintptr_t)a & 7) == 0) return *reinterpret_cast<const uint64_t *>(a);
+    }
+    // whole word inside the zero fill (between suffix and the final pad byte)
+    if (pos >= body0 + c.len + p.suffix_len && pos + 8 < c.padded) return 0;
+    uint64_t w = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) w |= (uint64_t)stream_byte(p, c, pos + j) << (8 * j);
+    return w;
+}
+
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        uint32_t o = (uint32_t)__shfl_xor((int)v, off, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+}  // namespace capy
