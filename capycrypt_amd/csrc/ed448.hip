@@ -17,6 +17,9 @@ namespace capy {
 #ifndef CAPY_ED448_WAVES
 #define CAPY_ED448_WAVES 2
 #endif
+#ifdef CAPY_ED448_NUMVGPR
+__attribute__((amdgpu_num_vgpr(CAPY_ED448_NUMVGPR)))
+#endif
 __global__ __launch_bounds__(64, CAPY_ED448_WAVES) void vb_kernel(uint64_t n, const uint8_t *scalars_be, uint64_t scalar_stride,
                                                 const uint8_t *points_xy, uint64_t point_stride, uint8_t *out_xy,
                                                 uint32_t *table_ws)

@@ -411,6 +411,28 @@ CAPY_HD inline Pt pt_dbl(const Pt &p)
     return r;
 }
 
+// Same doubling with the T product behind a (wave-uniform) run-time flag: one code body for the
+// 4-doublings-per-window loop, the fourth multiplication only where an addition follows.
+CAPY_HD inline Pt pt_dbl_flag(const Pt &p, bool want_t)
+{
+    Fe A = fe_sqr(p.X);
+    Fe B = fe_sqr(p.Y);
+    Fe C = fe_sqr(p.Z);
+    C = fe_add(C, C);
+    Fe E = fe_sqr(fe_add(p.X, p.Y));
+    E = fe_sub(fe_sub(E, A), B);
+    Fe G = fe_add(A, B);
+    Fe F = fe_sub(G, C);
+    Fe H = fe_sub(A, B);
+    Pt r;
+    r.X = fe_mul(E, F);
+    r.Y = fe_mul(G, H);
+    r.Z = fe_mul(F, G);
+    r.T = p.T;
+    if (want_t) r.T = fe_mul(E, H);
+    return r;
+}
+
 CAPY_HD inline Pt pt_from_affine_bytes(const uint8_t *xy)
 {
     Pt r;
