@@ -6,6 +6,7 @@
 #include <atomic>
 #include "common.h"
 #include "sponge_launch.h"
+#include "sponge_fused.h"
 #include "sponge_host.h"
 
 namespace capy {
@@ -187,6 +188,8 @@ static void kmac_head(int d, size_t key_len, SpongeParams &p)
 // two-lane kernel is 1.5x faster per sponge (sponge_kernels_k2.h).  0 = choose by batch size.
 static std::atomic<int> g_lanes_per_sponge{0};
 static std::atomic<unsigned> g_debug_flags{0};
+static std::atomic<bool> g_fused_enabled{true};
+static const size_t FUSED_MAX_ITEMS = 16384;  // 16 items per wave x one wave per SIMD
 static const size_t FULLCHIP_MIN_ITEMS = 131072;  // > 2 waves per SIMD (64 sponges x 2 x 1024 SIMDs)
 static const size_t K2_MAX_ITEMS = 32768;  // 32 sponges x one wave per SIMD x 1024 SIMDs (measured crossover, profiles/)
 
@@ -404,6 +407,55 @@ static int sha3_crypt_dev(bool encrypt, int d, size_t n, const uint8_t *pws, siz
     }
     MsgView none;
     int rc = kmac_launch(d, n, zpw, zk, zk, none, true, (const uint8_t *)"S", 1, 0, keka, 128, 128, nullptr, s);
+    if (rc) return rc;
+    auto keystream_only = [&](const int32_t *mask) {
+        return kmac_launch(d, n, keka, 64, 128, m, false, (const uint8_t *)ke_custom, strlen(ke_custom), 1, nullptr, 0, 0,
+                           mask, s);
+    };
+    // Small batches are latency bound: run the tag and keystream sponges of every item in lock-step in one pass
+    // (sponge_fused.h).  Needs rate-aligned framing (not D224) and 8-byte aligned messages.
+    const Framing ff = cshake_framing(d);
+    const bool fused_ok = g_fused_enabled.load() && ff.stride == (uint32_t)ff.rw * 8 && n <= FUSED_MAX_ITEMS &&
+                          m.aligned8 && m.msgs != nullptr;
+    if (fused_ok) {
+        FusedParams fp;
+        memset(&fp, 0, sizeof fp);
+        SpongeParams t;
+        std::vector<uint8_t> unused;
+        memset(&t, 0, sizeof t);
+        cshake_prefix(d, (const uint8_t *)"KMAC", 4, (const uint8_t *)ka_custom, strlen(ka_custom), ff, t, unused);
+        memcpy(fp.init_tag, t.init_state, sizeof fp.init_tag);
+        cshake_prefix(d, (const uint8_t *)"KMAC", 4, (const uint8_t *)ke_custom, strlen(ke_custom), ff, t, unused);
+        memcpy(fp.init_ks, t.init_state, sizeof fp.init_ks);
+        kmac_head(d, 64, t);
+        fp.keka = keka;
+        fp.keka_stride = 128;
+        fp.ka_offset = 64;
+        fp.key_len = 64;
+        fp.hdr_len = t.hdr_len;
+        fp.hdr0 = t.hdr0;
+        fp.hdr1 = t.hdr1;
+        fp.head_len = t.head_len;
+        fp.msgs = const_cast<uint8_t *>(m.msgs);
+        fp.offsets = m.offsets;
+        fp.lens = m.lens;
+        fp.msg_stride = m.msg_stride;
+        fp.uniform_len = m.uniform_len;
+        fp.tag_stride = 64;
+        fp.tag_len = 64;
+        fp.decrypt = encrypt ? 0 : 1;
+        fp.n = n;
+        if (encrypt) {
+            fp.tags = tags;
+            CAPY_HIP(launch_sponge_fused(ff.rw, fp, s));
+            return CAPY_OK;
+        }
+        CAPY_WS(tag2f, uint8_t *, s, WS_TAG2, n * 64);
+        fp.tags = tag2f;
+        CAPY_HIP(launch_sponge_fused(ff.rw, fp, s));
+        tag_compare_launch(tags, 64, tag2f, 64, 64, status, n, s);
+        return keystream_only(status);  // restore the ciphertext where the tag did not match (:80)
+    }
     auto keystream = [&](const int32_t *mask) {  // msg ^= kmac_xof(ke, "", |msg|, "SKE")
         return kmac_launch(d, n, keka, 64, 128, m, false, (const uint8_t *)ke_custom, strlen(ke_custom), 1, nullptr, 0, 0,
                            mask, s);
@@ -488,6 +540,7 @@ MsgView view_of(const PackedBatch &b)
     m.msgs = b.msgs.as<uint8_t>();
     m.offsets = b.starts.as<uint64_t>();
     m.lens = b.lens.as<uint64_t>();
+    m.aligned8 = true;  // PackedBatch keeps or makes every start 8-byte aligned
     return m;
 }
 
@@ -498,6 +551,7 @@ MsgView view_dev(const uint8_t *msgs, const uint64_t *offsets, uint64_t uniform_
     m.offsets = offsets;
     m.uniform_len = uniform_len;
     m.msg_stride = msg_stride;
+    m.aligned8 = offsets == nullptr && (((uintptr_t)msgs | msg_stride) & 7) == 0;  // device offsets are not inspected
     return m;
 }
 
@@ -687,7 +741,8 @@ int capy_kem_sponge_decrypt_batch(int d, size_t n, const uint8_t *secrets, size_
 // ---------------------------------------------------------------- measurement helpers
 int capy_set_sponge_lanes(int lanes)
 {
-    g_debug_flags.store((unsigned)lanes >> 8);  // undocumented A/B switches in the high bits
+    g_debug_flags.store(((unsigned)lanes >> 8) & 0xff);  // undocumented A/B switches in the high bits
+    g_fused_enabled.store((((unsigned)lanes >> 16) & 1) == 0);  // bit 16: disable the fused encrypt kernel
     lanes &= 0xff;
     if (lanes != 0 && lanes != 1 && lanes != 2) return fail(CAPY_ERR_ARG, "lanes must be 0 (auto), 1 or 2");
     g_lanes_per_sponge.store(lanes);

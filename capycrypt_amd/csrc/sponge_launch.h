@@ -11,4 +11,7 @@ hipError_t launch_sponge_k1_lat(int rw, int mode, const SpongeParams &p, hipStre
 hipError_t launch_sponge_k1_full(int rw, int mode, const SpongeParams &p, hipStream_t s);
 // two lanes per sponge (small batches of long messages)
 hipError_t launch_sponge_k2(int rw, int mode, const SpongeParams &p, hipStream_t s);
+// tag + keystream sponges of sha3_encrypt / sha3_decrypt in one pass (sponge_fused.h); rw in {17, 19, 21}
+struct FusedParams;
+hipError_t launch_sponge_fused(int rw, const FusedParams &fp, hipStream_t s);
 }  // namespace capy

@@ -30,9 +30,12 @@ def O():
     return oracle
 
 
-@pytest.fixture(autouse=True, params=[1, 2], ids=["lane-per-sponge", "two-lanes-per-sponge"])
+@pytest.fixture(autouse=True, params=[1, 2, 1 | (1 << 16), 2 | (1 << 8)],
+                ids=["lane-per-sponge", "two-lanes-per-sponge", "lane-per-sponge,two-pass-encrypt",
+                     "two-lanes,no-uniform-addressing"])
 def sponge_lanes(request):
-    """Every test runs against both sponge kernels (sponge_kernels.h / sponge_kernels_k2.h)."""
+    """Every test runs against both sponge kernels (sponge_kernels.h / sponge_kernels_k2.h), with the fused
+    one-pass encrypt kernel (sponge_fused.h) on and off, and with the wave-uniform addressing path off."""
     from capycrypt_amd import _lib
 
     _lib.check(_lib.lib().capy_set_sponge_lanes(request.param))
