@@ -247,15 +247,6 @@ static int pk_keys_dev(int d, size_t n, const uint8_t *W, uint8_t *keka, hipStre
     MsgView none;
     return kmac_launch(d, n, W, 56, 112, none, true, (const uint8_t *)"PK", 2, 0, keka, 112, 112, nullptr, st);
 }
-static int pk_tag_dev(int d, size_t n, const uint8_t *keka, const MsgView &m, uint8_t *tag, hipStream_t st)
-{
-    return kmac_launch(d, n, keka + 56, 56, 112, m, true, (const uint8_t *)"PKA", 3, 0, tag, 56, 56, nullptr, st);
-}
-static int pk_keystream_dev(int d, size_t n, const uint8_t *keka, const MsgView &m, const int32_t *mask, hipStream_t st)
-{
-    return kmac_launch(d, n, keka, 56, 112, m, false, (const uint8_t *)"PKE", 3, 1, nullptr, 0, 0, mask, st);
-}
-
 // KeyEncryptable::key_encrypt, src/ecc/encryptable.rs:34-50
 static int key_encrypt_dev(int d, size_t n, const uint8_t *pubs, const uint8_t *k_rand, const MsgView &m, uint8_t *z_xy,
                            uint8_t *tags, hipStream_t st)
@@ -271,9 +262,8 @@ static int key_encrypt_dev(int d, size_t n, const uint8_t *pubs, const uint8_t *
     if (rc) return rc;
     rc = pk_keys_dev(d, n, W, keka, st);
     if (rc) return rc;
-    rc = pk_tag_dev(d, n, keka, m, tags, st);  // tag over the plaintext (:43)
-    if (rc) return rc;
-    return pk_keystream_dev(d, n, keka, m, nullptr, st);
+    // t = kmac_xof(ka, m, 448, "PKA") over the plaintext (:43), then m ^= kmac_xof(ke, "", |m|, "PKE") (:45-46)
+    return symmetric_crypt_dev(true, d, n, keka, 56, 112, m, tags, 56, "PKE", "PKA", nullptr, st);
 }
 
 // KeyEncryptable::key_decrypt, src/ecc/encryptable.rs:72-94
@@ -283,19 +273,14 @@ static int key_decrypt_dev(int d, size_t n, const uint8_t *pws, size_t pw_len, c
     CAPY_WS(s_be, uint8_t *, st, WS_A, n * 56);
     CAPY_WS(W, uint8_t *, st, WS_C, n * 112);
     CAPY_WS(keka, uint8_t *, st, WS_D, n * 112);
-    CAPY_WS(tag2, uint8_t *, st, WS_E, n * 56);
     int rc = derive_s_dev(d, n, pws, pw_len, s_be, st);
     if (rc) return rc;
     rc = vb_launch(n, s_be, 56, z_xy, 112, W, st);  // W = s*Z
     if (rc) return rc;
     rc = pk_keys_dev(d, n, W, keka, st);
     if (rc) return rc;
-    rc = pk_keystream_dev(d, n, keka, m, nullptr, st);  // candidate plaintext
-    if (rc) return rc;
-    rc = pk_tag_dev(d, n, keka, m, tag2, st);
-    if (rc) return rc;
-    tag_compare_launch(tags, 56, tag2, 56, 56, status, n, st);
-    return pk_keystream_dev(d, n, keka, m, status, st);  // restore the ciphertext where the tag failed (:91)
+    // candidate plaintext, tag check, restore the ciphertext where the tag failed (:82-93)
+    return symmetric_crypt_dev(false, d, n, keka, 56, 112, m, const_cast<uint8_t *>(tags), 56, "PKE", "PKA", status, st);
 }
 
 static int up(DevBuf &b, const void *src, size_t bytes)

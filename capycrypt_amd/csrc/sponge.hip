@@ -387,6 +387,82 @@ __global__ __launch_bounds__(64) void keccak_probe_kernel(uint64_t n_states, uin
         atomicXor((unsigned long long *)checksum, ((uint64_t)y << 32) | x);
 }
 
+// The symmetric half shared by sha3_encrypt/decrypt (src/sha3/encryptable.rs:39-42, 71-82), key_encrypt/decrypt
+// (src/ecc/encryptable.rs:43-46, 82-93) and kem_encrypt/decrypt (src/kem/encryptable.rs:55-57, 96-103):
+//     tag = kmac_xof(ka, m, 8*tag_len, ka_custom) ;  m ^= kmac_xof(ke, "", |m|, ke_custom)
+// with ke at keka + i*keka_stride and ka right behind it (key_len bytes each).  Encrypt tags the plaintext first;
+// decrypt XORs first, tags the candidate plaintext, writes status and restores the ciphertext of failed items.
+// Small batches run both sponges of an item in lock-step in one pass (sponge_fused.h); that needs rate-aligned
+// framing (not D224) and 8-byte aligned messages, otherwise the two-pass form is used.
+int symmetric_crypt_dev(bool encrypt, int d, size_t n, const uint8_t *keka, size_t key_len, uint64_t keka_stride,
+                        const MsgView &m, uint8_t *tags, size_t tag_len, const char *ke_custom, const char *ka_custom,
+                        int32_t *status, hipStream_t s)
+{
+    if (!valid_d(d)) return fail(CAPY_ERR_UNSUPPORTED_SECPARAM, "unsupported security parameter");
+    if (n == 0) return CAPY_OK;
+    auto keystream = [&](const int32_t *mask) {
+        return kmac_launch(d, n, keka, key_len, keka_stride, m, false, (const uint8_t *)ke_custom, strlen(ke_custom), 1,
+                           nullptr, 0, 0, mask, s);
+    };
+    auto tag = [&](uint8_t *out) {
+        return kmac_launch(d, n, keka + key_len, key_len, keka_stride, m, true, (const uint8_t *)ka_custom,
+                           strlen(ka_custom), 0, out, tag_len, tag_len, nullptr, s);
+    };
+    uint8_t *tag2 = nullptr;
+    if (!encrypt) {
+        tag2 = reinterpret_cast<uint8_t *>(workspace(s, WS_TAG2, n * tag_len));
+        if (!tag2) return fail(CAPY_ERR_HIP, "workspace allocation failed");
+    }
+    const Framing ff = cshake_framing(d);
+    const bool fused_ok = g_fused_enabled.load() && ff.stride == (uint32_t)ff.rw * 8 && n <= FUSED_MAX_ITEMS &&
+                          m.aligned8 && m.msgs != nullptr && tag_len <= 64 && (tag_len & 3) == 0;
+    if (fused_ok) {
+        FusedParams fp;
+        memset(&fp, 0, sizeof fp);
+        SpongeParams t;
+        std::vector<uint8_t> unused;
+        memset(&t, 0, sizeof t);
+        cshake_prefix(d, (const uint8_t *)"KMAC", 4, (const uint8_t *)ka_custom, strlen(ka_custom), ff, t, unused);
+        memcpy(fp.init_tag, t.init_state, sizeof fp.init_tag);
+        cshake_prefix(d, (const uint8_t *)"KMAC", 4, (const uint8_t *)ke_custom, strlen(ke_custom), ff, t, unused);
+        memcpy(fp.init_ks, t.init_state, sizeof fp.init_ks);
+        kmac_head(d, key_len, t);
+        fp.keka = keka;
+        fp.keka_stride = keka_stride;
+        fp.ka_offset = (uint32_t)key_len;
+        fp.key_len = (uint32_t)key_len;
+        fp.hdr_len = t.hdr_len;
+        fp.hdr0 = t.hdr0;
+        fp.hdr1 = t.hdr1;
+        fp.head_len = t.head_len;
+        fp.msgs = const_cast<uint8_t *>(m.msgs);
+        fp.offsets = m.offsets;
+        fp.lens = m.lens;
+        fp.msg_stride = m.msg_stride;
+        fp.uniform_len = m.uniform_len;
+        fp.tag_stride = tag_len;
+        fp.tag_len = (uint32_t)tag_len;
+        fp.decrypt = encrypt ? 0 : 1;
+        fp.n = n;
+        fp.tags = encrypt ? tags : tag2;
+        CAPY_HIP(launch_sponge_fused(ff.rw, fp, s));
+        if (encrypt) return CAPY_OK;
+        tag_compare_launch(tags, tag_len, tag2, tag_len, (uint32_t)tag_len, status, n, s);
+        return keystream(status);
+    }
+    int rc;
+    if (encrypt) {
+        rc = tag(tags);
+        if (rc == CAPY_OK) rc = keystream(nullptr);
+        return rc;
+    }
+    rc = keystream(nullptr);
+    if (rc == CAPY_OK) rc = tag(tag2);
+    if (rc) return rc;
+    tag_compare_launch(tags, tag_len, tag2, tag_len, (uint32_t)tag_len, status, n, s);
+    return keystream(status);
+}
+
 // sha3_encrypt / sha3_decrypt on device buffers (src/sha3/encryptable.rs:29-83)
 // (and the sponge half of KEMEncryptable, src/kem/encryptable.rs:47-59,84-104: same flow, tags "KEMKE"/"KEMKA")
 static int sha3_crypt_dev(bool encrypt, int d, size_t n, const uint8_t *pws, size_t pw_len, const uint8_t *zs,
@@ -408,77 +484,7 @@ static int sha3_crypt_dev(bool encrypt, int d, size_t n, const uint8_t *pws, siz
     MsgView none;
     int rc = kmac_launch(d, n, zpw, zk, zk, none, true, (const uint8_t *)"S", 1, 0, keka, 128, 128, nullptr, s);
     if (rc) return rc;
-    auto keystream_only = [&](const int32_t *mask) {
-        return kmac_launch(d, n, keka, 64, 128, m, false, (const uint8_t *)ke_custom, strlen(ke_custom), 1, nullptr, 0, 0,
-                           mask, s);
-    };
-    // Small batches are latency bound: run the tag and keystream sponges of every item in lock-step in one pass
-    // (sponge_fused.h).  Needs rate-aligned framing (not D224) and 8-byte aligned messages.
-    const Framing ff = cshake_framing(d);
-    const bool fused_ok = g_fused_enabled.load() && ff.stride == (uint32_t)ff.rw * 8 && n <= FUSED_MAX_ITEMS &&
-                          m.aligned8 && m.msgs != nullptr;
-    if (fused_ok) {
-        FusedParams fp;
-        memset(&fp, 0, sizeof fp);
-        SpongeParams t;
-        std::vector<uint8_t> unused;
-        memset(&t, 0, sizeof t);
-        cshake_prefix(d, (const uint8_t *)"KMAC", 4, (const uint8_t *)ka_custom, strlen(ka_custom), ff, t, unused);
-        memcpy(fp.init_tag, t.init_state, sizeof fp.init_tag);
-        cshake_prefix(d, (const uint8_t *)"KMAC", 4, (const uint8_t *)ke_custom, strlen(ke_custom), ff, t, unused);
-        memcpy(fp.init_ks, t.init_state, sizeof fp.init_ks);
-        kmac_head(d, 64, t);
-        fp.keka = keka;
-        fp.keka_stride = 128;
-        fp.ka_offset = 64;
-        fp.key_len = 64;
-        fp.hdr_len = t.hdr_len;
-        fp.hdr0 = t.hdr0;
-        fp.hdr1 = t.hdr1;
-        fp.head_len = t.head_len;
-        fp.msgs = const_cast<uint8_t *>(m.msgs);
-        fp.offsets = m.offsets;
-        fp.lens = m.lens;
-        fp.msg_stride = m.msg_stride;
-        fp.uniform_len = m.uniform_len;
-        fp.tag_stride = 64;
-        fp.tag_len = 64;
-        fp.decrypt = encrypt ? 0 : 1;
-        fp.n = n;
-        if (encrypt) {
-            fp.tags = tags;
-            CAPY_HIP(launch_sponge_fused(ff.rw, fp, s));
-            return CAPY_OK;
-        }
-        CAPY_WS(tag2f, uint8_t *, s, WS_TAG2, n * 64);
-        fp.tags = tag2f;
-        CAPY_HIP(launch_sponge_fused(ff.rw, fp, s));
-        tag_compare_launch(tags, 64, tag2f, 64, 64, status, n, s);
-        return keystream_only(status);  // restore the ciphertext where the tag did not match (:80)
-    }
-    auto keystream = [&](const int32_t *mask) {  // msg ^= kmac_xof(ke, "", |msg|, "SKE")
-        return kmac_launch(d, n, keka, 64, 128, m, false, (const uint8_t *)ke_custom, strlen(ke_custom), 1, nullptr, 0, 0,
-                           mask, s);
-    };
-    auto tag = [&](uint8_t *out) {  // kmac_xof(ka, msg, 512, "SKA")
-        return kmac_launch(d, n, keka + 64, 64, 128, m, true, (const uint8_t *)ka_custom, strlen(ka_custom), 0, out, 64, 64,
-                           nullptr, s);
-    };
-    if (rc == CAPY_OK) {
-        if (encrypt) {
-            rc = tag(tags);  // tag over the plaintext first (:39), then keystream XOR (:41-42)
-            if (rc == CAPY_OK) rc = keystream(nullptr);
-        } else {
-            CAPY_WS(tag2, uint8_t *, s, WS_TAG2, n * 64);
-            rc = keystream(nullptr);  // ciphertext -> candidate plaintext (:71-73)
-            if (rc == CAPY_OK) rc = tag(tag2);
-            if (rc == CAPY_OK) {
-                tag_compare_launch(tags, 64, tag2, 64, 64, status, n, s);
-                rc = keystream(status);  // restore the ciphertext where the tag did not match (:80)
-            }
-        }
-    }
-    return rc;
+    return symmetric_crypt_dev(encrypt, d, n, keka, 64, 128, m, tags, 64, ke_custom, ka_custom, status, s);
 }
 
 // ------------------------------------------------------------------ PackedBatch

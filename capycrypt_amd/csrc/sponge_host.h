@@ -22,6 +22,11 @@ int kmac_launch(int d, size_t n, const uint8_t *keys, size_t key_len, uint64_t k
                 bool absorb_body, const uint8_t *custom, size_t custom_len, int out_mode, uint8_t *outs,
                 uint64_t out_stride, size_t out_len, const int32_t *mask, hipStream_t s);
 
+// tag + keystream XOR of the encryptable traits (see sponge.hip); ke at keka + i*stride, ka right behind it
+int symmetric_crypt_dev(bool encrypt, int d, size_t n, const uint8_t *keka, size_t key_len, uint64_t keka_stride,
+                        const MsgView &m, uint8_t *tags, size_t tag_len, const char *ke_custom, const char *ka_custom,
+                        int32_t *status, hipStream_t s);
+
 // status[i] = (a_i == b_i) ? CAPY_ITEM_OK : CAPY_ITEM_FAIL
 void tag_compare_launch(const uint8_t *a, uint64_t a_stride, const uint8_t *b, uint64_t b_stride, uint32_t tag_len,
                         int32_t *status, size_t n, hipStream_t s);
