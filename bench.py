@@ -206,6 +206,19 @@ def main():
                     assert O.ed448_scalarmul(s_h[56 * i:56 * i + 56], p_h[112 * i:112 * i + 112]) == \
                         o_h[112 * i:112 * i + 112], "ed448 mismatch"
 
+    # HBM traffic of the dominant kernel: PMC counters cannot be collected from inside the timed process, so the
+    # figure measured with `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` on this same command (separate passes,
+    # gfx950 x2 read correction per MI355X_MICROARCH.md) is read from profiles/ when it was taken at the same batch.
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as f:
+            pm = json.load(f)
+        for k, e in pm.items():
+            if "sponge_kernel" in k and int(e.get("_grid", 0)) == B and "hbm_read_bytes_corrected_x2" in e:
+                traffic = e["hbm_read_bytes_corrected_x2"] + e.get("hbm_write_bytes", 0.0)
+    except (OSError, ValueError):
+        pass
+
     if rank == 0:
         total_bytes = world * B * MSG_BYTES * a.steps
         value = total_bytes / 2**30 / el
@@ -227,7 +240,9 @@ def main():
             "config": {"workload": "sha3_256_batch: %d x 5 MiB messages per GPU, resident in HBM" % B,
                        "batch_per_gpu": B, "msg_bytes": MSG_BYTES, "parallelism": "batch-sharded x%d, no collective" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_note": "bytes per launch from profiles/r01_pmc_summary.json (rocprofv3 PMC, x2 read correction: "
+                                         "upper bound for 8-B/lane loads); algorithmic = %d" % algo_bytes,
                          "kernel": "sponge_kernel_k2<17,0>" if (a.lanes == 2 or (a.lanes == 0 and B <= 32768)) else
                          ("sponge_kernel<17,true,0>" if B > 131072 else "sponge_kernel<17,false,0>"),
                          "kernel_ms": kern_ms,
