@@ -60,8 +60,8 @@ CAPY_HD inline Pt vb_add_digit(const Pt &acc, const uint32_t *tab, int digit)
     const uint32_t *e = tab + idx * 64;
     Fe X2 = load_fe(e), Y2 = load_fe(e + 16), Z2 = load_fe(e + 32), Td2 = load_fe(e + 48);
     // -(x, y) = (-x, y): negate X and T
-    X2 = fe_select(neg, X2, fe_neg(X2));
-    Td2 = fe_select(neg, Td2, fe_neg(Td2));
+    X2 = fe_select(neg, X2, fe_neg_nr(X2));  // <= 2^29, within pt_add_cached's operand bounds
+    Td2 = fe_select(neg, Td2, fe_neg_nr(Td2));
     return pt_add_cached(acc, X2, Y2, Z2, Td2);
 }
 
@@ -99,8 +99,8 @@ CAPY_HD inline Pt fb_add_digit(const Pt &acc, const uint32_t *gtab, int row, int
     const int idx = neg ? -digit : digit;
     const uint32_t *e = gtab + (row * 9 + idx) * FB_ENTRY_DWORDS;
     Fe x2 = load_fe(e), y2 = load_fe(e + 16), td2 = load_fe(e + 32);
-    x2 = fe_select(neg, x2, fe_neg(x2));
-    td2 = fe_select(neg, td2, fe_neg(td2));
+    x2 = fe_select(neg, x2, fe_neg_nr(x2));
+    td2 = fe_select(neg, td2, fe_neg_nr(td2));
     return pt_add_affine_cached(acc, x2, y2, td2);
 }
 

@@ -82,6 +82,44 @@ CAPY_HD inline Fe fe_sub(const Fe &a, const Fe &b)
 
 CAPY_HD inline Fe fe_neg(const Fe &a) { return fe_sub(fe_zero(), a); }
 
+// ---- lazily reduced forms.  Notation: R = a limb bound of 2^28 + 2^10 (every fe_mul / fe_sqr / weak-reduced
+// output).  fe_mul(a, b) is exact while 38 * max_limb(a) * max_limb(b) < 2^64 and fe_sqr(a) while
+// 40 * max_limb(a)^2 < 2^64 (column-sum bounds, see fe_mul), i.e. products of limb bounds up to 2^58.7.  The point
+// formulas below use these unreduced sums / differences only where that holds; each use states its bound.
+//   fe_add_nr(R, R)        <= 2^29 + 2^11
+//   fe_sub_nr(a, b<=2p_l)  <= max_limb(a) + 2^29      (b must be R so that 2p - b >= 0 limb-wise)
+//   fe_neg_nr(R)           <= 2^29
+CAPY_HD inline Fe fe_add_nr(const Fe &a, const Fe &b)
+{
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < 16; i++) r.l[i] = a.l[i] + b.l[i];
+    return r;
+}
+CAPY_HD inline Fe fe_sub_nr(const Fe &a, const Fe &b)
+{
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < 16; i++) r.l[i] = a.l[i] + (i == 8 ? 2 * (M28 - 1) : 2 * M28) - b.l[i];
+    return r;
+}
+CAPY_HD inline Fe fe_neg_nr(const Fe &a)
+{
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < 16; i++) r.l[i] = (i == 8 ? 2 * (M28 - 1) : 2 * M28) - a.l[i];
+    return r;
+}
+// a - b + 4p, reduced; limbs of b may be up to 2^30 - 8
+CAPY_HD inline Fe fe_sub4(const Fe &a, const Fe &b)
+{
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < 16; i++) r.l[i] = a.l[i] + (i == 8 ? 4 * (M28 - 1) : 4 * M28) - b.l[i];
+    fe_weak_reduce(r);
+    return r;
+}
+
 // 16 column sums (lo = columns 0..7, hi = 8..15), each < 2^63, to 28-bit limbs
 CAPY_HD inline Fe fe_from_columns(uint64_t lo[8], uint64_t hi[8])
 {
@@ -123,9 +161,39 @@ CAPY_HD inline Fe fe_from_columns(uint64_t lo[8], uint64_t hi[8])
 #define CAPY_NOINLINE
 #endif
 
-// r = a * b mod p.  Inputs: limbs <= 2^28 + 8.  256 MADs.
+#ifdef CAPY_FE_CHECK_BOUNDS
+// host-only audit of the lazy-reduction bounds (tests/native/ed448_host_test.cpp builds with this)
+extern "C" void capy_fe_bound_violation(const char *what, double bits);
+inline void fe_check_mul(const Fe &a, const Fe &b)
+{
+    uint64_t ma = 0, mb = 0;
+    for (int i = 0; i < 16; i++) {
+        ma = a.l[i] > ma ? a.l[i] : ma;
+        mb = b.l[i] > mb ? b.l[i] : mb;
+    }
+    const long double prod = 38.0L * (long double)ma * (long double)mb;
+    if (prod >= 18446744073709551616.0L) capy_fe_bound_violation("fe_mul", (double)prod);
+}
+inline void fe_check_sqr(const Fe &a)
+{
+    uint64_t ma = 0;
+    for (int i = 0; i < 16; i++) ma = a.l[i] > ma ? a.l[i] : ma;
+    const long double prod = 40.0L * (long double)ma * (long double)ma;
+    if (prod >= 18446744073709551616.0L) capy_fe_bound_violation("fe_sqr", (double)prod);
+}
+#define CAPY_FE_CHECK_MUL(a, b) fe_check_mul(a, b)
+#define CAPY_FE_CHECK_SQR(a) fe_check_sqr(a)
+#else
+#define CAPY_FE_CHECK_MUL(a, b)
+#define CAPY_FE_CHECK_SQR(a)
+#endif
+
+// r = a * b mod p.  256 MADs.  Exact while 38 * max_limb(a) * max_limb(b) < 2^64: with bs = b0 + b1 <= 2 Lb, column
+// hi[k] collects (k+1) pairs of (a0 b1 + a1 bs) <= 3 La Lb, (7-k) pairs of (a0 b0 + a1 b1) <= 2 La Lb and qh[k] of
+// (7-k) pairs <= 3 La Lb: at most (38 - 2k) La Lb.  Output limbs <= 2^28 + 2^9.
 CAPY_HD CAPY_NOINLINE inline Fe fe_mul(const Fe a, const Fe b)
 {
+    CAPY_FE_CHECK_MUL(a, b);
     uint64_t lo[8], hi[8], qh[7];
     uint32_t bs[8];
 #pragma unroll
@@ -166,6 +234,7 @@ CAPY_HD CAPY_NOINLINE inline Fe fe_mul(const Fe a, const Fe b)
 // r = a^2 mod p.  P = a0^2 + a1^2 ; Q = a1 (2 a0 + a1).  136 MADs.
 CAPY_HD CAPY_NOINLINE inline Fe fe_sqr(const Fe a)
 {
+    CAPY_FE_CHECK_SQR(a);
     uint64_t lo[8], hi[8], qh[7];
     uint32_t s[8], d0[8], d1[8];
 #pragma unroll
@@ -347,20 +416,21 @@ CAPY_HD inline Pt pt_identity()
 CAPY_HD inline Fe fe_mul_d(const Fe &t) { return fe_neg(fe_mul_small(t, ED448_D_ABS)); }
 
 // Unified, complete addition (add-2008-hwcd).  q is given in "cached" form: (X2, Y2, Z2, d*T2).
+// Limb bounds: p.* are R (products); X2, Td2 <= 2^29 (possibly fe_neg_nr'ed table entries), Y2, Z2 are R.
 CAPY_HD inline Pt pt_add_cached(const Pt &p, const Fe &X2, const Fe &Y2, const Fe &Z2, const Fe &Td2)
 {
-    Fe A = fe_mul(p.X, X2);
+    Fe A = fe_mul(p.X, X2);                                   // R x 2^29
     Fe B = fe_mul(p.Y, Y2);
-    Fe C = fe_mul(p.T, Td2);
+    Fe C = fe_mul(p.T, Td2);                                  // R x 2^29
     Fe D = fe_mul(p.Z, Z2);
-    Fe E = fe_mul(fe_add(p.X, p.Y), fe_add(X2, Y2));
-    E = fe_sub(fe_sub(E, A), B);
-    Fe F = fe_sub(D, C);
-    Fe G = fe_add(D, C);
-    Fe H = fe_sub(B, A);
+    Fe E = fe_mul(fe_add_nr(p.X, p.Y), fe_add_nr(X2, Y2));    // 2^29 x 2^29.58
+    E = fe_sub(fe_sub_nr(E, A), B);                           // reduced
+    Fe F = fe_sub_nr(D, C);                                   // <= 2^29.58
+    Fe G = fe_add_nr(D, C);                                   // <= 2^29
+    Fe H = fe_sub_nr(B, A);                                   // <= 2^29.58
     Pt r;
-    r.X = fe_mul(E, F);
-    r.Y = fe_mul(G, H);
+    r.X = fe_mul(E, F);                                       // R x 2^29.58
+    r.Y = fe_mul(G, H);                                       // 2^29 x 2^29.58 = 2^58.58
     r.Z = fe_mul(F, G);
     r.T = fe_mul(E, H);
     return r;
@@ -369,16 +439,17 @@ CAPY_HD inline Pt pt_add_cached(const Pt &p, const Fe &X2, const Fe &Y2, const F
 CAPY_HD inline Pt pt_add(const Pt &p, const Pt &q) { return pt_add_cached(p, q.X, q.Y, q.Z, fe_mul_d(q.T)); }
 
 // Mixed addition with an affine precomputed point (x2, y2, d*x2*y2), Z2 = 1: 8 multiplications.
+// Limb bounds as in pt_add_cached (x2, td2 <= 2^29; y2 is R).
 CAPY_HD inline Pt pt_add_affine_cached(const Pt &p, const Fe &x2, const Fe &y2, const Fe &td2)
 {
     Fe A = fe_mul(p.X, x2);
     Fe B = fe_mul(p.Y, y2);
     Fe C = fe_mul(p.T, td2);
-    Fe E = fe_mul(fe_add(p.X, p.Y), fe_add(x2, y2));
-    E = fe_sub(fe_sub(E, A), B);
-    Fe F = fe_sub(p.Z, C);
-    Fe G = fe_add(p.Z, C);
-    Fe H = fe_sub(B, A);
+    Fe E = fe_mul(fe_add_nr(p.X, p.Y), fe_add_nr(x2, y2));
+    E = fe_sub(fe_sub_nr(E, A), B);
+    Fe F = fe_sub_nr(p.Z, C);
+    Fe G = fe_add_nr(p.Z, C);
+    Fe H = fe_sub_nr(B, A);
     Pt r;
     r.X = fe_mul(E, F);
     r.Y = fe_mul(G, H);
@@ -394,15 +465,15 @@ CAPY_HD inline Pt pt_dbl(const Pt &p)
     Fe A = fe_sqr(p.X);
     Fe B = fe_sqr(p.Y);
     Fe C = fe_sqr(p.Z);
-    C = fe_add(C, C);
-    Fe E = fe_sqr(fe_add(p.X, p.Y));
-    E = fe_sub(fe_sub(E, A), B);
-    Fe G = fe_add(A, B);
-    Fe F = fe_sub(G, C);
-    Fe H = fe_sub(A, B);
+    C = fe_add_nr(C, C);                          // <= 2^29
+    Fe E = fe_sqr(fe_add_nr(p.X, p.Y));           // sqr of 2^29: 40 * 2^58 < 2^64
+    E = fe_sub(fe_sub_nr(E, A), B);               // reduced
+    Fe G = fe_add_nr(A, B);                       // <= 2^29
+    Fe F = fe_sub4(G, C);                         // reduced (C exceeds the 2p bias)
+    Fe H = fe_sub_nr(A, B);                       // <= 2^29.58
     Pt r;
     r.X = fe_mul(E, F);
-    r.Y = fe_mul(G, H);
+    r.Y = fe_mul(G, H);                           // 2^29 x 2^29.58
     r.Z = fe_mul(F, G);
     if (WANT_T)
         r.T = fe_mul(E, H);
@@ -415,21 +486,8 @@ CAPY_HD inline Pt pt_dbl(const Pt &p)
 // 4-doublings-per-window loop, the fourth multiplication only where an addition follows.
 CAPY_HD inline Pt pt_dbl_flag(const Pt &p, bool want_t)
 {
-    Fe A = fe_sqr(p.X);
-    Fe B = fe_sqr(p.Y);
-    Fe C = fe_sqr(p.Z);
-    C = fe_add(C, C);
-    Fe E = fe_sqr(fe_add(p.X, p.Y));
-    E = fe_sub(fe_sub(E, A), B);
-    Fe G = fe_add(A, B);
-    Fe F = fe_sub(G, C);
-    Fe H = fe_sub(A, B);
-    Pt r;
-    r.X = fe_mul(E, F);
-    r.Y = fe_mul(G, H);
-    r.Z = fe_mul(F, G);
-    r.T = p.T;
-    if (want_t) r.T = fe_mul(E, H);
+    Pt r = pt_dbl<false>(p);
+    if (want_t) r = pt_dbl<true>(p);
     return r;
 }
 

@@ -4,10 +4,15 @@
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
+#define CAPY_FE_CHECK_BOUNDS 1
 #include "../../capycrypt_amd/csrc/ed448_algo.h"
 using namespace capy;
 
+static int g_bound_violations = 0;
+extern "C" void capy_fe_bound_violation(const char *, double) { g_bound_violations++; }
+
 extern "C" {
+int ht_bound_violations() { return g_bound_violations; }
 void ht_fe_mul(const uint8_t *a, const uint8_t *b, uint8_t *out) { fe_to_bytes(out, fe_mul(fe_from_bytes(a), fe_from_bytes(b))); }
 void ht_fe_sqr(const uint8_t *a, uint8_t *out) { fe_to_bytes(out, fe_sqr(fe_from_bytes(a))); }
 void ht_fe_add(const uint8_t *a, const uint8_t *b, uint8_t *out) { fe_to_bytes(out, fe_add(fe_from_bytes(a), fe_from_bytes(b))); }

@@ -86,6 +86,22 @@ def test_scalarmul_algorithms(L):
         assert got == E.pt_to_bytes(E.add(E.scalarmul(a, E.G), E.scalarmul(b, P)))
 
 
+def test_lazy_reduction_bounds_hold(L):
+    """The host build audits every fe_mul / fe_sqr operand pair against the column-sum bound (CAPY_FE_CHECK_BOUNDS);
+    drive the point formulas with worst-case-ish inputs (limbs at their maxima: coordinates p-1, 2^448-1) and random
+    ones and require zero violations."""
+    rng = random.Random(9)
+    G = E.pt_to_bytes(E.G)
+    L.ht_build_gtab(C.c_char_p(G))
+    worst = [(E.P - 1).to_bytes(56, "little") * 2, (2**448 - 1).to_bytes(56, "little") * 2, G]
+    for xy in worst:
+        for k in (2**448 - 1, int("8" * 112, 16), int("7" * 112, 16), rng.getrandbits(448)):
+            call(L, "ht_scalarmul", E.sc_to_bytes(k), xy, outlen=112)  # off-curve inputs are fine: only bounds matter
+            call(L, "ht_double_scalarmul", E.sc_to_bytes(k), E.sc_to_bytes(k ^ 0x5555), xy, outlen=112)
+            call(L, "ht_basemul", E.sc_to_bytes(k), outlen=112)
+    assert L.ht_bound_violations() == 0
+
+
 def test_scalar_field(L):
     rng = random.Random(8)
     for i in range(10):
