@@ -284,3 +284,75 @@ def test_cpp_host_mirror_selftest():
         pytest.skip("host_selftest not built (python -c 'import __graft_entry__ as g; g.build()')")
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+# ---------------------------------------------------------------- device-pointer API: every kernel instance
+def _dev_rand(nbytes, seed):
+    import ctypes as C
+
+    import torch
+
+    from capycrypt_amd import _lib
+
+    t = torch.empty((nbytes + 7) // 8 * 8, dtype=torch.uint8, device="cuda")
+    _lib.check(_lib.lib().capy_fill_random_dev(t.data_ptr(), t.numel(), seed, None))
+    torch.cuda.synchronize()
+    return t
+
+
+@pytest.mark.parametrize("n,L", [(100, 1000), (4100, 2731 * 8), (140000, 304)])
+def test_dev_api_uniform_batches_all_instances(capy, O, n, L):
+    """Uniformly strided device batches (the bench layout) through sha3 / kmac_xof / sha3_encrypt / sha3_decrypt:
+    n = 100 and 4100 use the small-batch kernels (two-lane or latency-tuned, fused encrypt), n = 140000 the
+    issue-tuned full-chip instances.  Spot-checked against the oracle, round trip checked for every item."""
+    import torch
+
+    from capycrypt_amd import _lib
+
+    lib = _lib.lib()
+    stride = (L + 15) // 16 * 16
+    msgs = _dev_rand(n * stride, 7)
+    keys = _dev_rand(n * 64, 8)
+    zs = _dev_rand(n * 512, 9)
+    host = bytes(msgs.cpu().numpy())
+    hkeys = bytes(keys.cpu().numpy())
+    hz = bytes(zs.cpu().numpy())
+    picks = sorted({0, 1, 63, 64, n // 2, n - 2, n - 1})
+
+    dig = torch.zeros(n * 32, dtype=torch.uint8, device="cuda")
+    _lib.check(lib.capy_sha3_batch_dev(256, n, msgs.data_ptr(), None, L, stride, dig.data_ptr(), None))
+    out = torch.zeros(n * 72, dtype=torch.uint8, device="cuda")
+    _lib.check(lib.capy_kmac_xof_batch_dev(512, n, keys.data_ptr(), 64, 64, msgs.data_ptr(), None, L, stride, 576,
+                                           b"T", 1, out.data_ptr(), 72, None))
+    torch.cuda.synchronize()
+    hd, ho = bytes(dig.cpu().numpy()), bytes(out.cpu().numpy())
+    for i in picks:
+        m = host[i * stride:i * stride + L]
+        assert hd[32 * i:32 * i + 32] == O.sha3(m, 256), i
+        assert ho[72 * i:72 * i + 72] == O.kmac_xof(hkeys[64 * i:64 * i + 64], m, 576, b"T", 512), i
+
+    for d in (512, 256):
+        work = msgs.clone()
+        tags = torch.zeros(n * 64, dtype=torch.uint8, device="cuda")
+        status = torch.full((n,), 7, dtype=torch.int32, device="cuda")
+        _lib.check(lib.capy_sha3_encrypt_batch_dev(d, n, keys.data_ptr(), 64, zs.data_ptr(), work.data_ptr(), None, L,
+                                                   stride, tags.data_ptr(), None))
+        torch.cuda.synchronize()
+        hc, ht = bytes(work.cpu().numpy()), bytes(tags.cpu().numpy())
+        for i in picks:
+            ect, etag = O.sha3_encrypt(hkeys[64 * i:64 * i + 64], hz[512 * i:512 * i + 512], host[i * stride:i * stride + L], d)
+            assert hc[i * stride:i * stride + L] == ect and ht[64 * i:64 * i + 64] == etag, (d, i)
+            assert hc[i * stride + L:(i + 1) * stride] == host[i * stride + L:(i + 1) * stride]  # padding untouched
+        # corrupt one tag: that item must fail and keep its ciphertext, all others decrypt
+        bad = n // 3
+        tags[64 * bad] ^= 1
+        _lib.check(lib.capy_sha3_decrypt_batch_dev(d, n, keys.data_ptr(), 64, zs.data_ptr(), work.data_ptr(), None, L,
+                                                   stride, tags.data_ptr(), status.data_ptr(), None))
+        torch.cuda.synchronize()
+        st = status.cpu().numpy()
+        assert st[bad] == 1 and int(st.sum()) == 1
+        hp = bytes(work.cpu().numpy())
+        assert hp[bad * stride:bad * stride + L] == hc[bad * stride:bad * stride + L]
+        ref = bytearray(host)
+        ref[bad * stride:bad * stride + L] = hc[bad * stride:bad * stride + L]
+        assert hp == bytes(ref)
