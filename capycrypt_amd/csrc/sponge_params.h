@@ -88,6 +88,18 @@ __device__ __forceinline__ uint64_t stream_word(const SpongeParams &p, const Ite
         const uint8_t *a = c.msg + (pos - body0);
         if (((uintptr_t)a & 7) == 0) return *reinterpret_cast<const uint64_t *>(a);
     }
+    // whole word inside the per-item key (any alignment) or inside the head's zero fill
+    if (pos >= (uint64_t)p.pre_len + p.hdr_len && pos + 8 <= body0) {
+        const uint64_t k = pos - p.pre_len - p.hdr_len;
+        if (k >= p.key_len) return 0;
+        if (k + 8 <= p.key_len) {
+            const uint8_t *a = c.key + k;
+            uint64_t w = 0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) w |= (uint64_t)a[j] << (8 * j);
+            return w;
+        }
+    }
     // whole word inside the zero fill (between suffix and the final pad byte)
     if (pos >= body0 + c.len + p.suffix_len && pos + 8 < c.padded) return 0;
     uint64_t w = 0;
