@@ -50,6 +50,11 @@ SIGNATURES = {
     "capy_schnorr_verify_batch": (C.c_int, [C.c_int, sz, vp, vp, vp, vp, vp, vp]),
     "capy_key_encrypt_batch": (C.c_int, [C.c_int, sz, vp, vp, vp, vp, vp, vp]),
     "capy_key_decrypt_batch": (C.c_int, [C.c_int, sz, vp, sz, vp, vp, vp, vp, vp]),
+    "capy_keypair_batch_dev": (C.c_int, [C.c_int, sz, vp, sz, vp, vp]),
+    "capy_schnorr_sign_batch_dev": (C.c_int, [C.c_int, sz, vp, sz, vp, vp, u64, u64, vp, vp, vp]),
+    "capy_schnorr_verify_batch_dev": (C.c_int, [C.c_int, sz, vp, vp, vp, u64, u64, vp, vp, vp, vp]),
+    "capy_key_encrypt_batch_dev": (C.c_int, [C.c_int, sz, vp, vp, vp, vp, u64, u64, vp, vp, vp]),
+    "capy_key_decrypt_batch_dev": (C.c_int, [C.c_int, sz, vp, sz, vp, vp, vp, u64, u64, vp, vp, vp]),
     "capy_set_sponge_lanes": (C.c_int, [C.c_int]),
     "capy_fill_random_dev": (C.c_int, [vp, u64, u64, vp]),
     "capy_keccak_valu_probe_dev": (C.c_int, [u64, C.c_uint32, vp, vp]),

@@ -370,6 +370,56 @@ int capy_ed448_double_scalarmul_batch(size_t n, const uint8_t *a_be, const uint8
     return down(out_xy, o, n * 112);
 }
 
+// ---------------------------------------------------------------- src/ecc protocols (device buffers, stream ordered)
+int capy_keypair_batch_dev(int d, size_t n, const uint8_t *pws, size_t pw_len, uint8_t *pub_xy, void *stream)
+{
+    if (!valid_d(d)) return fail(CAPY_ERR_UNSUPPORTED_SECPARAM, "unsupported security parameter");
+    if (!n) return CAPY_OK;
+    hipStream_t st = (hipStream_t)stream;
+    CAPY_WS(s_be, uint8_t *, st, WS_A, n * 56);
+    TRY(derive_s_dev(d, n, pws, pw_len, s_be, st));
+    return fb_launch(n, s_be, pub_xy, st);
+}
+
+int capy_schnorr_sign_batch_dev(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint8_t *msgs,
+                                const uint64_t *offsets, uint64_t uniform_len, uint64_t msg_stride, uint8_t *h,
+                                uint8_t *z_be, void *stream)
+{
+    if (!valid_d(d)) return fail(CAPY_ERR_UNSUPPORTED_SECPARAM, "unsupported security parameter");
+    if (!n) return CAPY_OK;
+    return sign_dev(d, n, pws, pw_len, view_dev(msgs, offsets, uniform_len, msg_stride), h, z_be, (hipStream_t)stream);
+}
+
+int capy_schnorr_verify_batch_dev(int d, size_t n, const uint8_t *pub_xy, const uint8_t *msgs, const uint64_t *offsets,
+                                  uint64_t uniform_len, uint64_t msg_stride, const uint8_t *h, const uint8_t *z_be,
+                                  int32_t *status, void *stream)
+{
+    if (!valid_d(d)) return fail(CAPY_ERR_UNSUPPORTED_SECPARAM, "unsupported security parameter");
+    if (!n) return CAPY_OK;
+    return verify_dev(d, n, pub_xy, view_dev(msgs, offsets, uniform_len, msg_stride), h, z_be, status,
+                      (hipStream_t)stream);
+}
+
+int capy_key_encrypt_batch_dev(int d, size_t n, const uint8_t *pub_xy, const uint8_t *k_rand, uint8_t *msgs,
+                               const uint64_t *offsets, uint64_t uniform_len, uint64_t msg_stride, uint8_t *z_xy,
+                               uint8_t *tags, void *stream)
+{
+    if (!valid_d(d)) return fail(CAPY_ERR_UNSUPPORTED_SECPARAM, "unsupported security parameter");
+    if (!n) return CAPY_OK;
+    return key_encrypt_dev(d, n, pub_xy, k_rand, view_dev(msgs, offsets, uniform_len, msg_stride), z_xy, tags,
+                           (hipStream_t)stream);
+}
+
+int capy_key_decrypt_batch_dev(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint8_t *z_xy, uint8_t *msgs,
+                               const uint64_t *offsets, uint64_t uniform_len, uint64_t msg_stride, const uint8_t *tags,
+                               int32_t *status, void *stream)
+{
+    if (!valid_d(d)) return fail(CAPY_ERR_UNSUPPORTED_SECPARAM, "unsupported security parameter");
+    if (!n) return CAPY_OK;
+    return key_decrypt_dev(d, n, pws, pw_len, z_xy, view_dev(msgs, offsets, uniform_len, msg_stride), tags, status,
+                           (hipStream_t)stream);
+}
+
 // ---------------------------------------------------------------- src/ecc protocols (host buffers)
 int capy_keypair_batch(int d, size_t n, const uint8_t *pws, size_t pw_len, uint8_t *pub_xy)
 {

@@ -132,6 +132,22 @@ int capy_key_encrypt_batch(int d, size_t n, const uint8_t *pub_xy, const uint8_t
 int capy_key_decrypt_batch(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint8_t *z_xy,
                            uint8_t *msgs, const uint64_t *offsets, const uint8_t *tags, int32_t *status);
 
+/* Device-buffer forms of the src/ecc protocols (same semantics; messages via offsets or uniform_len/msg_stride,
+ * enqueued on `stream`, no host synchronisation). */
+int capy_keypair_batch_dev(int d, size_t n, const uint8_t *pws, size_t pw_len, uint8_t *pub_xy, void *stream);
+int capy_schnorr_sign_batch_dev(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint8_t *msgs,
+                                const uint64_t *offsets, uint64_t uniform_len, uint64_t msg_stride, uint8_t *h,
+                                uint8_t *z_be, void *stream);
+int capy_schnorr_verify_batch_dev(int d, size_t n, const uint8_t *pub_xy, const uint8_t *msgs, const uint64_t *offsets,
+                                  uint64_t uniform_len, uint64_t msg_stride, const uint8_t *h, const uint8_t *z_be,
+                                  int32_t *status, void *stream);
+int capy_key_encrypt_batch_dev(int d, size_t n, const uint8_t *pub_xy, const uint8_t *k_rand, uint8_t *msgs,
+                               const uint64_t *offsets, uint64_t uniform_len, uint64_t msg_stride, uint8_t *z_xy,
+                               uint8_t *tags, void *stream);
+int capy_key_decrypt_batch_dev(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint8_t *z_xy, uint8_t *msgs,
+                               const uint64_t *offsets, uint64_t uniform_len, uint64_t msg_stride, const uint8_t *tags,
+                               int32_t *status, void *stream);
+
 /* ------------------------------------------------------------------ measurement helpers */
 
 /* Tuning knob: GPU lanes per sponge. 0 = automatic (2 for batches of <= 32768 items, else 1), 1 or 2 = forced.

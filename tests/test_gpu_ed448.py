@@ -173,3 +173,50 @@ def test_sig_timing_side_channel_shape(capy):
         kp = capy.KeyPair.new(capy.get_random_bytes(i), "test key", capy.SecParam.D512)
         msg.sign(kp, capy.SecParam.D512)
         msg.verify(kp.pub_key)
+
+
+def test_dev_api_protocols_roundtrip(capy, O):
+    """Device-buffer forms of keypair / sign / verify / key_encrypt / key_decrypt on a uniformly strided batch."""
+    import torch
+
+    from capycrypt_amd import _lib
+
+    lib = _lib.lib()
+    n, L, stride, d = 300, 1000, 1008, 512
+
+    def rand(nb, seed):
+        t = torch.empty((nb + 7) // 8 * 8, dtype=torch.uint8, device="cuda")
+        _lib.check(lib.capy_fill_random_dev(t.data_ptr(), t.numel(), seed, None))
+        return t
+
+    msgs, pws, kr = rand(n * stride, 1), rand(n * 32, 2), rand(n * 56, 3)
+    pubs = torch.zeros(n * 112, dtype=torch.uint8, device="cuda")
+    h = torch.zeros(n * 56, dtype=torch.uint8, device="cuda")
+    z = torch.zeros(n * 56, dtype=torch.uint8, device="cuda")
+    st = torch.full((n,), 9, dtype=torch.int32, device="cuda")
+    _lib.check(lib.capy_keypair_batch_dev(d, n, pws.data_ptr(), 32, pubs.data_ptr(), None))
+    _lib.check(lib.capy_schnorr_sign_batch_dev(d, n, pws.data_ptr(), 32, msgs.data_ptr(), None, L, stride, h.data_ptr(),
+                                               z.data_ptr(), None))
+    _lib.check(lib.capy_schnorr_verify_batch_dev(d, n, pubs.data_ptr(), msgs.data_ptr(), None, L, stride, h.data_ptr(),
+                                                 z.data_ptr(), st.data_ptr(), None))
+    torch.cuda.synchronize()
+    assert int(st.abs().sum().item()) == 0
+    hm, hp = bytes(msgs.cpu().numpy()), bytes(pws.cpu().numpy())
+    hh, hz, hpub = bytes(h.cpu().numpy()), bytes(z.cpu().numpy()), bytes(pubs.cpu().numpy())
+    for i in (0, 63, 64, 299):
+        m, pw = hm[i * stride:i * stride + L], hp[32 * i:32 * i + 32]
+        assert hpub[112 * i:112 * i + 112] == O.keypair_pub(pw, d)
+        assert (hh[56 * i:56 * i + 56], hz[56 * i:56 * i + 56]) == O.sign(pw, m, d)
+    zxy = torch.zeros(n * 112, dtype=torch.uint8, device="cuda")
+    tags = torch.zeros(n * 56, dtype=torch.uint8, device="cuda")
+    work = msgs.clone()
+    _lib.check(lib.capy_key_encrypt_batch_dev(d, n, pubs.data_ptr(), kr.data_ptr(), work.data_ptr(), None, L, stride,
+                                              zxy.data_ptr(), tags.data_ptr(), None))
+    torch.cuda.synchronize()
+    hc, hk = bytes(work.cpu().numpy()), bytes(kr.cpu().numpy())
+    ect, ez, etag = O.key_encrypt(hpub[:112], hk[:56], hm[:L], d)
+    assert hc[:L] == ect and bytes(zxy[:112].cpu().numpy()) == ez and bytes(tags[:56].cpu().numpy()) == etag
+    _lib.check(lib.capy_key_decrypt_batch_dev(d, n, pws.data_ptr(), 32, zxy.data_ptr(), work.data_ptr(), None, L, stride,
+                                              tags.data_ptr(), st.data_ptr(), None))
+    torch.cuda.synchronize()
+    assert int(st.abs().sum().item()) == 0 and bytes(work.cpu().numpy()) == hm
