@@ -77,7 +77,9 @@ CAPY_HD inline Pt vb_scalarmul(const uint8_t *k_be, const Pt &P, uint32_t *tab)
     for (int i = 0; i < 112; i++) {
 #if CAPY_ED448_INLINE && !defined(CAPY_ED448_SPLIT_DBL)
 #pragma unroll 1
-        for (int j = 0; j < 4; j++) acc = pt_dbl<true>(acc);  // one doubling body keeps the loop inside the I-cache
+        // one doubling body keeps the loop inside the I-cache; the compiler sinks the T product (dead in all but
+        // the last trip) out of the loop, so this runs 4S+3M per doubling plus one multiplication per window
+        for (int j = 0; j < 4; j++) acc = pt_dbl<true>(acc);
 #else
 #pragma unroll 1
         for (int j = 0; j < 3; j++) acc = pt_dbl<false>(acc);
@@ -138,7 +140,9 @@ CAPY_HD inline Pt double_scalarmul(const uint8_t *a_be, const uint8_t *b_be, con
     for (int i = 0; i < 112; i++) {
 #if CAPY_ED448_INLINE && !defined(CAPY_ED448_SPLIT_DBL)
 #pragma unroll 1
-        for (int j = 0; j < 4; j++) acc = pt_dbl<true>(acc);  // one doubling body keeps the loop inside the I-cache
+        // one doubling body keeps the loop inside the I-cache; the compiler sinks the T product (dead in all but
+        // the last trip) out of the loop, so this runs 4S+3M per doubling plus one multiplication per window
+        for (int j = 0; j < 4; j++) acc = pt_dbl<true>(acc);
 #else
 #pragma unroll 1
         for (int j = 0; j < 3; j++) acc = pt_dbl<false>(acc);

@@ -482,15 +482,6 @@ CAPY_HD inline Pt pt_dbl(const Pt &p)
     return r;
 }
 
-// Same doubling with the T product behind a (wave-uniform) run-time flag: one code body for the
-// 4-doublings-per-window loop, the fourth multiplication only where an addition follows.
-CAPY_HD inline Pt pt_dbl_flag(const Pt &p, bool want_t)
-{
-    Pt r = pt_dbl<false>(p);
-    if (want_t) r = pt_dbl<true>(p);
-    return r;
-}
-
 CAPY_HD inline Pt pt_from_affine_bytes(const uint8_t *xy)
 {
     Pt r;

@@ -9,13 +9,13 @@
  * Conventions
  *   d            security parameter 224 | 256 | 384 | 512        (SecParam, src/lib.rs:111-135)
  *   msgs/offsets n messages packed in one buffer; message i is msgs[offsets[i] .. offsets[i+1]).
- *                offsets has n+1 entries.  Start offsets that are multiples of 8 take the fast path.
+ *                offsets has n+1 entries, non-decreasing.  Host batches are re-packed to aligned starts as needed.
  *   scalars      56-byte BIG-endian, unreduced                   (src/sha3/aux_functions.rs:102-110)
  *   points       affine (x, y), 2 x 56-byte little-endian canonical field elements (x first)
  *   return       0 = ok, <0 = CAPY_ERR_*; capy_last_error() gives the text (thread local)
  *   *_dev        same operation on buffers already resident in device memory, enqueued on `stream`
  *                (a hipStream_t passed as void*, NULL = default stream), no host synchronisation.
- *                Device message buffers must be 8-byte aligned; out buffers 8-byte aligned.
+ *                Message starts that are 8-byte aligned take the coalesced fast path (any alignment is correct).
  * All entry points are thread safe; no pointer is retained after return.  Randomness (nonces) is
  * always an input so results are reproducible.
  */
