@@ -356,3 +356,42 @@ def test_dev_api_uniform_batches_all_instances(capy, O, n, L):
         ref = bytearray(host)
         ref[bad * stride:bad * stride + L] = hc[bad * stride:bad * stride + L]
         assert hp == bytes(ref)
+
+
+def test_concurrent_host_threads(capy, O):
+    """include/capyhip.h promises thread safety: four host threads issue different batched calls at once
+    (ctypes drops the GIL during the call) and every result must still be bit-exact."""
+    import threading
+
+    rng = random.Random(77)
+    jobs = []
+    for t in range(4):
+        msgs = [rng.randbytes(rng.randrange(0, 4000)) for _ in range(150 + 37 * t)]
+        keys = [rng.randbytes(32) for _ in msgs]
+        jobs.append((msgs, keys, 256 if t % 2 else 512))
+    results, errors = [None] * 4, []
+
+    def work(i):
+        try:
+            msgs, keys, d = jobs[i]
+            out = []
+            for _ in range(5):
+                out.append((capy.ops.sha3_batch(msgs, d), capy.ops.kmac_xof_batch(keys, msgs, 512, b"T", d),
+                            capy.ops.sha3_encrypt_batch(keys, [k * 16 for k in keys], msgs, d)))
+            results[i] = out
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    for i, (msgs, keys, d) in enumerate(jobs):
+        exp_sha = [O.sha3(m, d) for m in msgs]
+        exp_kmac = [O.kmac_xof(k, m, 512, b"T", d) for k, m in zip(keys, msgs)]
+        exp_enc = [O.sha3_encrypt(k, k * 16, m, d) for k, m in zip(keys, msgs)]
+        for sha, kmac, (cts, tags) in results[i]:
+            assert sha == exp_sha and kmac == exp_kmac
+            assert cts == [e[0] for e in exp_enc] and tags == [e[1] for e in exp_enc]
