@@ -108,7 +108,7 @@ static int vb_launch(size_t n, const uint8_t *scalars, uint64_t scalar_stride, c
     return CAPY_OK;
 }
 
-// The shared fixed-base table: row i, entry j = (j * 16^i mod r) * G, affine cached.  Built once per
+// The shared fixed-base table: row i, entry j = (j * 2^(WBITS i) mod r) * G, affine cached.  Built once per
 // device by running the variable-base kernel on G itself, then packed into limbs.
 static std::mutex g_gtab_mu;
 static uint32_t *g_gtab[64] = {nullptr};
@@ -128,17 +128,17 @@ static int ensure_gtab(const uint32_t **out)
     if (dev < 0 || dev >= 64) return fail(CAPY_ERR_ARG, "device index out of range");
     std::lock_guard<std::mutex> lk(g_gtab_mu);
     if (!g_gtab[dev]) {
-        const size_t n = FB_ROWS * 9;
+        const size_t n = (size_t)FB_ROWS * TAB_ENTRIES;
         std::vector<uint8_t> sc(n * 56), pts(n * 112);
-        uint32_t pw[14] = {1};  // 16^row mod r
+        uint32_t pw[14] = {1};  // 2^(WBITS row) mod r
         for (int row = 0; row < FB_ROWS; row++) {
             uint32_t acc[14] = {0};
-            for (int j = 0; j < 9; j++) {
-                sc_to_be(sc.data() + (size_t)(row * 9 + j) * 56, acc);
-                memcpy(pts.data() + (size_t)(row * 9 + j) * 112, G_XY, 112);
+            for (int j = 0; j < TAB_ENTRIES; j++) {
+                sc_to_be(sc.data() + (size_t)(row * TAB_ENTRIES + j) * 56, acc);
+                memcpy(pts.data() + (size_t)(row * TAB_ENTRIES + j) * 112, G_XY, 112);
                 sc_add_mod(acc, pw);
             }
-            for (int d = 0; d < 4; d++) sc_dbl_mod(pw);
+            for (int d = 0; d < WBITS; d++) sc_dbl_mod(pw);
         }
         DevBuf dsc, dpts, dout, dtab;
         CAPY_HIP(dsc.alloc(sc.size()));

@@ -1,19 +1,20 @@
 // ed448_algo.h — scalar-multiplication algorithms shared by the HIP kernels and the host unit test.
 //
-// Variable base: signed radix-16 fixed windows over all 448 scalar bits (scalars arrive unreduced,
-// /root/reference/src/sha3/aux_functions.rs:102-106), 9-entry per-item table {0..8}P in "cached" extended
-// form kept in HBM (2304 B per item, lane-major so every lane streams whole 128-B lines), uniform control flow
-// (every window does 4 doublings + 1 complete addition; the digit only selects the table row and a sign).
-// Fixed base: 113 x 9 affine table of j*16^i*G shared by all lanes, 113 mixed additions, no doublings.
+// Variable base: signed fixed windows of WBITS bits over all 448 scalar bits (scalars arrive unreduced,
+// /root/reference/src/sha3/aux_functions.rs:102-106), per-item table {0..2^(WBITS-1)}P in "cached" extended form
+// kept in HBM (lane-major so every lane streams whole 128-B lines), uniform control flow (every window does WBITS
+// doublings + 1 complete addition; the digit only selects the table row and a sign).
+// Fixed base: (NWIN+1) x TAB_ENTRIES affine table of j*2^(WBITS i)*G shared by all lanes, NWIN+1 mixed additions,
+// no doublings.  WBITS = 5: 90 windows, 17 entries (4352 B per item); measured against WBITS = 4 in profiles/.
 #pragma once
 #include "ed448_dev.h"
 
 namespace capy {
 
-constexpr int VB_TABLE_DWORDS = 9 * 64;   // per item: 9 entries x (X, Y, Z, dT) x 16 limbs
-constexpr int FB_ROWS = 113;              // windows 0..111 plus the recoding carry
-constexpr int FB_ENTRY_DWORDS = 48;       // (x, y, d*x*y) x 16 limbs
-constexpr int FB_TABLE_DWORDS = FB_ROWS * 9 * FB_ENTRY_DWORDS;
+constexpr int VB_TABLE_DWORDS = TAB_ENTRIES * 64;  // per item: entries x (X, Y, Z, dT) x 16 limbs
+constexpr int FB_ROWS = NWIN + 1;                  // one row per window plus the recoding carry
+constexpr int FB_ENTRY_DWORDS = 48;                // (x, y, d*x*y) x 16 limbs
+constexpr int FB_TABLE_DWORDS = FB_ROWS * TAB_ENTRIES * FB_ENTRY_DWORDS;
 
 CAPY_HD inline void store_fe(uint32_t *dst, const Fe &a)
 {
@@ -37,18 +38,18 @@ CAPY_HD inline Fe load_fe(const uint32_t *src)
     return a;
 }
 
-// Build the per-item table {0,1,..,8}P (cached form) at tab[0 .. VB_TABLE_DWORDS).
+// Build the per-item table {0,1,..,WHALF}P (cached form) at tab[0 .. VB_TABLE_DWORDS).
 CAPY_HD inline void vb_build_table(uint32_t *tab, const Pt &P)
 {
     const Fe Pd = fe_mul_d(P.T);
     Pt acc = pt_identity();
 #pragma unroll 1
-    for (int j = 0; j < 9; j++) {
+    for (int j = 0; j < TAB_ENTRIES; j++) {
         store_fe(tab + j * 64, acc.X);
         store_fe(tab + j * 64 + 16, acc.Y);
         store_fe(tab + j * 64 + 32, acc.Z);
         store_fe(tab + j * 64 + 48, fe_mul_d(acc.T));
-        if (j < 8) acc = pt_add_cached(acc, P.X, P.Y, P.Z, Pd);
+        if (j + 1 < TAB_ENTRIES) acc = pt_add_cached(acc, P.X, P.Y, P.Z, Pd);
     }
 }
 
@@ -69,27 +70,18 @@ CAPY_HD inline Pt vb_add_digit(const Pt &acc, const uint32_t *tab, int digit)
 CAPY_HD inline Pt vb_scalarmul(const uint8_t *k_be, const Pt &P, uint32_t *tab)
 {
     vb_build_table(tab, P);
-    uint32_t w[14];
-    sc_from_be(w, k_be);
-    const uint32_t top = sc_recode_signed16(w);
+    uint32_t k[14], w[15];
+    sc_from_be(k, k_be);
+    const uint32_t top = sc_recode_signed(w, k);
+    sc_msb_align(w);
     Pt acc = vb_add_digit(pt_identity(), tab, (int)top);
 #pragma unroll 1
-    for (int i = 0; i < 112; i++) {
-#if CAPY_ED448_INLINE && !defined(CAPY_ED448_SPLIT_DBL)
-#pragma unroll 1
+    for (int i = 0; i < NWIN; i++) {
         // one doubling body keeps the loop inside the I-cache; the compiler sinks the T product (dead in all but
         // the last trip) out of the loop, so this runs 4S+3M per doubling plus one multiplication per window
-        for (int j = 0; j < 4; j++) acc = pt_dbl<true>(acc);
-#else
 #pragma unroll 1
-        for (int j = 0; j < 3; j++) acc = pt_dbl<false>(acc);
-        acc = pt_dbl<true>(acc);
-#endif
-        const int digit = (int)(w[13] >> 28) - 8;
-#pragma unroll
-        for (int t = 13; t > 0; t--) w[t] = (w[t] << 4) | (w[t - 1] >> 28);
-        w[0] <<= 4;
-        acc = vb_add_digit(acc, tab, digit);
+        for (int j = 0; j < WBITS; j++) acc = pt_dbl<true>(acc);
+        acc = vb_add_digit(acc, tab, sc_next_digit_msb(w));
     }
     return acc;
 }
@@ -99,7 +91,7 @@ CAPY_HD inline Pt fb_add_digit(const Pt &acc, const uint32_t *gtab, int row, int
 {
     const bool neg = digit < 0;
     const int idx = neg ? -digit : digit;
-    const uint32_t *e = gtab + (row * 9 + idx) * FB_ENTRY_DWORDS;
+    const uint32_t *e = gtab + (row * TAB_ENTRIES + idx) * FB_ENTRY_DWORDS;
     Fe x2 = load_fe(e), y2 = load_fe(e + 16), td2 = load_fe(e + 32);
     x2 = fe_select(neg, x2, fe_neg_nr(x2));
     td2 = fe_select(neg, td2, fe_neg_nr(td2));
@@ -109,18 +101,12 @@ CAPY_HD inline Pt fb_add_digit(const Pt &acc, const uint32_t *gtab, int row, int
 // [k]G from the shared table gtab[FB_TABLE_DWORDS]
 CAPY_HD inline Pt fb_scalarmul(const uint8_t *k_be, const uint32_t *gtab)
 {
-    uint32_t w[14];
-    sc_from_be(w, k_be);
-    const uint32_t top = sc_recode_signed16(w);
-    Pt acc = fb_add_digit(pt_identity(), gtab, 112, (int)top);
+    uint32_t k[14], w[15];
+    sc_from_be(k, k_be);
+    const uint32_t top = sc_recode_signed(w, k);
+    Pt acc = fb_add_digit(pt_identity(), gtab, NWIN, (int)top);
 #pragma unroll 1
-    for (int i = 0; i < 112; i++) {
-        const int digit = (int)(w[0] & 15) - 8;
-#pragma unroll
-        for (int t = 0; t < 13; t++) w[t] = (w[t] >> 4) | (w[t + 1] << 28);
-        w[13] >>= 4;
-        acc = fb_add_digit(acc, gtab, i, digit);
-    }
+    for (int i = 0; i < NWIN; i++) acc = fb_add_digit(acc, gtab, i, sc_next_digit_lsb(w));
     return acc;
 }
 
@@ -130,34 +116,20 @@ CAPY_HD inline Pt double_scalarmul(const uint8_t *a_be, const uint8_t *b_be, con
                                    const uint32_t *gtab)
 {
     vb_build_table(tab, P);
-    uint32_t wa[14], wb[14];
-    sc_from_be(wa, a_be);
-    sc_from_be(wb, b_be);
-    const uint32_t topa = sc_recode_signed16(wa), topb = sc_recode_signed16(wb);
+    uint32_t ka[14], kb[14], wa[15], wb[15];
+    sc_from_be(ka, a_be);
+    sc_from_be(kb, b_be);
+    const uint32_t topa = sc_recode_signed(wa, ka), topb = sc_recode_signed(wb, kb);
+    sc_msb_align(wa);
+    sc_msb_align(wb);
     Pt acc = vb_add_digit(pt_identity(), tab, (int)topb);
     acc = fb_add_digit(acc, gtab, 0, (int)topa);
 #pragma unroll 1
-    for (int i = 0; i < 112; i++) {
-#if CAPY_ED448_INLINE && !defined(CAPY_ED448_SPLIT_DBL)
+    for (int i = 0; i < NWIN; i++) {
 #pragma unroll 1
-        // one doubling body keeps the loop inside the I-cache; the compiler sinks the T product (dead in all but
-        // the last trip) out of the loop, so this runs 4S+3M per doubling plus one multiplication per window
-        for (int j = 0; j < 4; j++) acc = pt_dbl<true>(acc);
-#else
-#pragma unroll 1
-        for (int j = 0; j < 3; j++) acc = pt_dbl<false>(acc);
-        acc = pt_dbl<true>(acc);
-#endif
-        const int db = (int)(wb[13] >> 28) - 8, da = (int)(wa[13] >> 28) - 8;
-#pragma unroll
-        for (int t = 13; t > 0; t--) {
-            wb[t] = (wb[t] << 4) | (wb[t - 1] >> 28);
-            wa[t] = (wa[t] << 4) | (wa[t - 1] >> 28);
-        }
-        wb[0] <<= 4;
-        wa[0] <<= 4;
-        acc = vb_add_digit(acc, tab, db);
-        acc = fb_add_digit(acc, gtab, 0, da);
+        for (int j = 0; j < WBITS; j++) acc = pt_dbl<true>(acc);
+        acc = vb_add_digit(acc, tab, sc_next_digit_msb(wb));
+        acc = fb_add_digit(acc, gtab, 0, sc_next_digit_msb(wa));
     }
     return acc;
 }

@@ -521,19 +521,70 @@ CAPY_HD inline void sc_to_be(uint8_t *out, const uint32_t w[14])
     }
 }
 
-// Signed radix-16 recoding: k = sum_{i<112} (nib_i - 8) 16^i + top 16^112 with nib = nibbles of
-// k + 0x88..8 (112 eights), top = the carry out of that addition.  Returns top; w is overwritten
-// with the biased nibbles.
-CAPY_HD inline uint32_t sc_recode_signed16(uint32_t w[14])
+// Signed fixed-window recoding, window width WBITS (radix 2^WBITS), NWIN windows cover the 448 scalar bits:
+//     k = sum_{i<NWIN} (dig_i - HALF) 2^(WBITS i) + top 2^(WBITS NWIN),   dig_i = WBITS-bit digits of k' = k + OFFSET,
+// OFFSET = sum_i HALF 2^(WBITS i), HALF = 2^(WBITS-1), top = bit WBITS*NWIN of k'.  Digits lie in [-HALF, HALF), so a
+// table of {0..HALF} P plus a sign serves every window with the same control flow.
+#ifndef CAPY_ED448_WBITS
+#define CAPY_ED448_WBITS 5
+#endif
+constexpr int WBITS = CAPY_ED448_WBITS;
+constexpr int NWIN = (448 + WBITS - 1) / WBITS;
+constexpr int WHALF = 1 << (WBITS - 1);
+constexpr int TAB_ENTRIES = WHALF + 1;
+constexpr int TOP_BIT = WBITS * NWIN;  // >= 448, < 480
+
+CAPY_HD constexpr uint32_t sc_recode_offset_word(int j)
+{
+    uint32_t w = 0;
+    for (int i = 0; i < NWIN; i++) {
+        const int pos = WBITS * i + WBITS - 1;
+        if (pos / 32 == j) w |= 1u << (pos % 32);
+    }
+    return w;
+}
+
+// in: 14 words of k (LE).  out: 15 words of k' (LE).  returns top.
+CAPY_HD inline uint32_t sc_recode_signed(uint32_t kp[15], const uint32_t k[14])
 {
     uint64_t c = 0;
 #pragma unroll
-    for (int i = 0; i < 14; i++) {
-        uint64_t v = (uint64_t)w[i] + 0x88888888u + c;
-        w[i] = (uint32_t)v;
+    for (int i = 0; i < 15; i++) {
+        const uint64_t v = (uint64_t)(i < 14 ? k[i] : 0u) + sc_recode_offset_word(i) + c;
+        kp[i] = (uint32_t)v;
         c = v >> 32;
     }
-    return (uint32_t)c;
+    return (kp[14] >> (TOP_BIT - 448)) & 1u;
+}
+
+// most-significant digit first: after sc_msb_align the current digit is the top WBITS bits of kp[14]
+CAPY_HD inline void sc_shl(uint32_t kp[15], int s)  // 1 <= s <= 32
+{
+    if (s == 32) {
+#pragma unroll
+        for (int t = 14; t > 0; t--) kp[t] = kp[t - 1];
+        kp[0] = 0;
+    } else {
+#pragma unroll
+        for (int t = 14; t > 0; t--) kp[t] = (kp[t] << s) | (kp[t - 1] >> (32 - s));
+        kp[0] <<= s;
+    }
+}
+CAPY_HD inline void sc_msb_align(uint32_t kp[15]) { sc_shl(kp, 480 - TOP_BIT); }
+CAPY_HD inline int sc_next_digit_msb(uint32_t kp[15])
+{
+    const int dig = (int)(kp[14] >> (32 - WBITS)) - WHALF;
+    sc_shl(kp, WBITS);
+    return dig;
+}
+// least-significant digit first
+CAPY_HD inline int sc_next_digit_lsb(uint32_t kp[15])
+{
+    const int dig = (int)(kp[0] & ((1u << WBITS) - 1u)) - WHALF;
+#pragma unroll
+    for (int t = 0; t < 14; t++) kp[t] = (kp[t] >> WBITS) | (kp[t + 1] << (32 - WBITS));
+    kp[14] >>= WBITS;
+    return dig;
 }
 
 }  // namespace capy
