@@ -109,10 +109,20 @@ __device__ __forceinline__ void keccak_round(KState &a, uint32_t rc_lo, uint32_t
     a.hi[0] ^= rc_hi;
 }
 
+// gfx950 fetches instructions in 8-byte granules: a stream of 8-byte VOP3 encodings (v_bitop3_b32, v_alignbit_b32)
+// that sits at 4 mod 8 issues ~20 % slower for a lone wave (measured: the same 4361-instruction loop body ran 363 ms
+// vs 300 ms depending only on that phase).  The iota XOR is a 4-byte encoding whenever the round constant half is an
+// inline constant, so the phase can flip between rounds: re-align after every unrolled round (at most one s_nop).
+// The directive is tied to the lane the iota XORs just wrote, so it lands between two rounds.
+__device__ __forceinline__ void keccak_round_aligned(KState &a, uint32_t rc_lo, uint32_t rc_hi)
+{
+    keccak_round(a, rc_lo, rc_hi);
+    asm volatile(".p2align 3" : "+v"(a.lo[0]), "+v"(a.hi[0]));
+}
 __device__ __forceinline__ void keccakf1600(KState &a)
 {
 #pragma unroll 2
-    for (int r = 0; r < 24; r++) keccak_round(a, KECCAK_RC32[2 * r], KECCAK_RC32[2 * r + 1]);
+    for (int r = 0; r < 24; r++) keccak_round_aligned(a, KECCAK_RC32[2 * r], KECCAK_RC32[2 * r + 1]);
 }
 
 // Rolled form with the next pair of round constants fetched one trip ahead, so the scalar-load latency
@@ -125,7 +135,7 @@ __device__ __forceinline__ void keccakf1600_pipelined(KState &a)
         const int nx = (r + 2 < 24) ? r + 2 : 0;
         const uint32_t n0 = KECCAK_RC32[2 * nx], n1 = KECCAK_RC32[2 * nx + 1], n2 = KECCAK_RC32[2 * nx + 2],
                        n3 = KECCAK_RC32[2 * nx + 3];
-        keccak_round(a, c0, c1);
+        keccak_round(a, c0, c1);  // many waves per SIMD: fetch phase is hidden, no re-alignment
         keccak_round(a, c2, c3);
         c0 = n0;
         c1 = n1;
@@ -151,7 +161,7 @@ __device__ __host__ constexpr uint64_t keccak_rc64(int r)
 template <int... Rs>
 __device__ __forceinline__ void keccakf1600_unrolled_impl(KState &a, std::integer_sequence<int, Rs...>)
 {
-    (keccak_round(a, (uint32_t)keccak_rc64(Rs), (uint32_t)(keccak_rc64(Rs) >> 32)), ...);
+    (keccak_round_aligned(a, (uint32_t)keccak_rc64(Rs), (uint32_t)(keccak_rc64(Rs) >> 32)), ...);
 }
 __device__ __forceinline__ void keccakf1600_unrolled(KState &a)
 {

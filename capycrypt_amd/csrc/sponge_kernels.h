@@ -26,6 +26,7 @@
 #pragma once
 #include "sponge_params.h"
 
+
 namespace capy {
 
 // Measured on MI355X (profiles/r01_keccak_loop_forms.txt): a lone wave hides nothing, so with <= 1 wave per SIMD

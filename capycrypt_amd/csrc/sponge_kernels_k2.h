@@ -80,7 +80,10 @@ __device__ __forceinline__ void keccak_round_k2(KHalf &s, uint32_t rc_lo, uint32
 template <int... Rs>
 __device__ __forceinline__ void keccakf1600_k2_unrolled_impl(KHalf &s, uint32_t hmask, std::integer_sequence<int, Rs...>)
 {
-    (keccak_round_k2(s, (uint32_t)keccak_rc64(Rs), (uint32_t)keccak_rc64(Rs) ^ (uint32_t)(keccak_rc64(Rs) >> 32), hmask), ...);
+    // re-aligned to 8 bytes after every round, see keccak_round_aligned (keccak_dev.h)
+    ((keccak_round_k2(s, (uint32_t)keccak_rc64(Rs), (uint32_t)keccak_rc64(Rs) ^ (uint32_t)(keccak_rc64(Rs) >> 32), hmask),
+      [&] { asm volatile(".p2align 3" : "+v"(s.a[0])); }()),
+     ...);
 }
 __device__ __forceinline__ void keccakf1600_k2_unrolled(KHalf &s, uint32_t hmask)
 {
@@ -93,6 +96,7 @@ __device__ __forceinline__ void keccakf1600_k2(KHalf &s, uint32_t hmask)
     for (int r = 0; r < 24; r++) {
         const uint32_t lo = KECCAK_RC32[2 * r], hi = KECCAK_RC32[2 * r + 1];
         keccak_round_k2(s, lo, lo ^ hi, hmask);
+        asm volatile(".p2align 3" : "+v"(s.a[0]));
     }
 }
 
