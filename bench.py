@@ -234,15 +234,24 @@ def main():
                     assert O.ed448_scalarmul(s_h[56 * i:56 * i + 56], p_h[112 * i:112 * i + 112]) == \
                         o_h[112 * i:112 * i + 112], "ed448 mismatch"
 
+    # which kernel the library picked for this shape (one launch per step, or P phase launches of the mixed kernel)
+    kind, phases = C.c_int(0), C.c_int(1)
+    _lib.check(lib.capy_sha3_launch_plan(256, B, MSG_BYTES, MSG_BYTES, C.byref(kind), C.byref(phases)))
+    kname = {1: "sponge_kernel<17, false, 0>", 2: "sponge_kernel_k2<17, 0>", 3: "sponge_mixed_kernel<17>",
+             4: "sponge_kernel<17, true, 0>"}[kind.value]
+    launches = phases.value
+
     # HBM traffic of the dominant kernel: PMC counters cannot be collected from inside the timed process, so the
     # figure measured with `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` on this same command (separate passes,
-    # gfx950 x2 read correction per MI355X_MICROARCH.md) is read from profiles/ when it was taken at the same batch.
+    # gfx950 x2 read correction per MI355X_MICROARCH.md) is read from profiles/ when it was taken for the same kernel
+    # at the same batch.  Per launch, like `achieved`.
     traffic = None
     try:
         with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as f:
             pm = json.load(f)
         for k, e in pm.items():
-            if "sponge_kernel" in k and int(e.get("_grid", 0)) == B and "hbm_read_bytes_corrected_x2" in e:
+            if kname.split("<")[0] + "<" in k and int(e.get("_items", e.get("_grid", 0))) == B and \
+                    "hbm_read_bytes_corrected_x2" in e:
                 traffic = e["hbm_read_bytes_corrected_x2"] + e.get("hbm_write_bytes", 0.0)
     except (OSError, ValueError):
         pass
@@ -250,8 +259,12 @@ def main():
     if rank == 0:
         total_bytes = world * B * MSG_BYTES * a.steps
         value = total_bytes / 2**30 / el
-        algo_bytes = B * MSG_BYTES + B * 32  # read every message once + 32-byte digests
-        achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
+        # algorithmic bytes per launch of the dominant kernel (every message byte read once + 32-byte
+        # digests), and that kernel's average launch duration from the HIP events around each step (the events also
+        # span the 0.03 ms tail/squeeze launch that follows the phase launches of the mixed schedule)
+        algo_bytes = (B * MSG_BYTES + B * 32) / launches
+        launch_ms = kern_ms / launches
+        achieved = algo_bytes / (launch_ms * 1e-3) / 1e9
         res = {
             "metric": "GiB/s SHA3-256 (5MB msgs)",
             "value": value,
@@ -266,14 +279,14 @@ def main():
             "dtype": "u64",
             "data": "synthetic",
             "config": {"workload": "sha3_256_batch: %d x 5 MiB messages per GPU, resident in HBM" % B,
-                       "batch_per_gpu": B, "msg_bytes": MSG_BYTES, "parallelism": "batch-sharded x%d, no collective" % world},
+                       "batch_per_gpu": B, "msg_bytes": MSG_BYTES,
+                       "parallelism": "batch-sharded x%d, no collective" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_note": "bytes per launch from profiles/r01_pmc_summary.json (rocprofv3 PMC, x2 read correction: "
-                                         "upper bound for 8-B/lane loads); algorithmic = %d" % algo_bytes,
-                         "kernel": "sponge_kernel_k2<17,0>" if (a.lanes == 2 or (a.lanes == 0 and B <= 32768)) else
-                         ("sponge_kernel<17,true,0>" if B > 131072 else "sponge_kernel<17,false,0>"),
-                         "kernel_ms": kern_ms,
+                         "traffic_note": "bytes per launch from profiles/r01_pmc_summary.json (rocprofv3 PMC, x2 read "
+                                         "correction: upper bound for 8-B/lane loads); algorithmic per launch = %d"
+                                         % algo_bytes,
+                         "kernel": kname, "launches_per_step": launches, "kernel_ms": launch_ms,
                          "valu_ceiling_GBs": VALU_CEIL_GBS, "frac_of_valu_ceiling": achieved / VALU_CEIL_GBS},
         }
         if ed:

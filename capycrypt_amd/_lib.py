@@ -56,6 +56,7 @@ SIGNATURES = {
     "capy_key_encrypt_batch_dev": (C.c_int, [C.c_int, sz, vp, vp, vp, vp, u64, u64, vp, vp, vp]),
     "capy_key_decrypt_batch_dev": (C.c_int, [C.c_int, sz, vp, sz, vp, vp, vp, u64, u64, vp, vp, vp]),
     "capy_set_sponge_lanes": (C.c_int, [C.c_int]),
+    "capy_sha3_launch_plan": (C.c_int, [C.c_int, sz, u64, u64, vp, vp]),
     "capy_fill_random_dev": (C.c_int, [vp, u64, u64, vp]),
     "capy_keccak_valu_probe_dev": (C.c_int, [u64, C.c_uint32, vp, vp]),
 }

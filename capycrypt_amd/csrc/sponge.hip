@@ -7,6 +7,7 @@
 #include "common.h"
 #include "sponge_launch.h"
 #include "sponge_fused.h"
+#include "sponge_mixed.h"
 #include "sponge_host.h"
 
 namespace capy {
@@ -190,8 +191,126 @@ static std::atomic<int> g_lanes_per_sponge{0};
 static std::atomic<unsigned> g_debug_flags{0};
 static std::atomic<bool> g_fused_enabled{true};
 static const size_t FUSED_MAX_ITEMS = 16384;  // 16 items per wave x one wave per SIMD
-static const size_t FULLCHIP_MIN_ITEMS = 131072;  // > 2 waves per SIMD (64 sponges x 2 x 1024 SIMDs)
-static const size_t K2_MAX_ITEMS = 32768;  // 32 sponges x one wave per SIMD x 1024 SIMDs (measured crossover, profiles/)
+// Kernel choice by batch size relative to the device's SIMD count S (1024 on MI355X; measured crossovers, profiles/):
+//   n <= 32 S        two lanes per sponge, at most one wave per SIMD
+//   32 S < n < 64 S  rotating one-lane / two-lane schedule when eligible (sponge_mixed.h), else one lane
+//   n <= 128 S       one lane per sponge, latency-tuned instance
+//   above            one lane per sponge, issue-tuned instance (> 2 waves per SIMD)
+
+static std::atomic<bool> g_mixed_enabled{true};
+
+// SIMDs of the current device (4 per CU)
+static unsigned device_simds()
+{
+    static std::atomic<unsigned> cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 1024;
+    unsigned v = cached[dev].load();
+    if (!v) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        v = 4u * (unsigned)cus;
+        cached[dev].store(v);
+    }
+    return v;
+}
+
+// speed of the two-lane form relative to the one-lane form, per sponge, one wave per SIMD (40.4 vs 59.7 ms per MiB of
+// message = 1.48; the phase time is flat between 1.48 and 1.52, profiles/r01_mixed_schedule.txt); CAPY_MIXED_RATIO overrides
+static double mixed_ratio()
+{
+    static const double r = [] {
+        const char *e = getenv("CAPY_MIXED_RATIO");
+        double v = e ? atof(e) : 0.0;
+        return (v >= 1.0 && v <= 2.0) ? v : 1.50;
+    }();
+    return r;
+}
+
+// The rotating one-lane / two-lane schedule of sponge_mixed.h for batches between half a chip and a full chip of
+// one-lane sponges: P groups of gs sponges, P phases; each sponge gets one two-lane phase of nb2 blocks and P-1
+// one-lane phases of nb1 blocks.
+struct MixedPlan {
+    uint64_t P, gs, nf;
+    uint32_t nb1, nb2;
+};
+static bool mixed_plan(int rw, const SpongeParams &p, bool forced, MixedPlan &m)
+{
+    const uint32_t rb = (uint32_t)rw * 8;
+    if (p.out_mode != 0 || !p.absorb_body || p.offsets || p.mask || p.pre_len || p.head_len || p.stride_bytes != rb) return false;
+    if ((((uintptr_t)p.msgs | p.msg_stride) & 7) || p.msg_stride * 64 >= 0xfff00000ULL || p.msg_stride < p.uniform_len) return false;
+    if (rw == 19) return false;  // no instance (D384-as-capacity cSHAKE never comes without a head)
+    const uint64_t S = device_simds(), n = p.n;
+    m.nf = p.uniform_len / rb;
+    if (n <= 32 * S || n >= 64 * S || m.nf < 1024) return false;
+    const uint64_t spare = 64 * S - n;        // sponges' worth of idle lanes under the one-lane kernel
+    uint64_t P = (n + spare - 1) / spare;     // phases = groups
+    if (P < 2) P = 2;
+    if (P > 6 && !forced) return false;       // gain (ratio + P - 1) / P would be below 8 %
+    if (P > 16) return false;
+    m.gs = ((n + P - 1) / P + 63) / 64 * 64;  // group size: whole one-lane waves
+    m.P = (n + m.gs - 1) / m.gs;
+    if (m.P < 2) return false;
+    m.nb1 = (uint32_t)((double)m.nf / (mixed_ratio() + (double)(m.P - 1)));
+    m.nb2 = (uint32_t)(m.nf - (m.P - 1) * (uint64_t)m.nb1);
+    return m.nb1 != 0;
+}
+
+// Returns 1 if it handled the launch, 0 if the launch is not eligible, < 0 on error.
+static int try_launch_mixed(int rw, const SpongeParams &p, bool forced, hipStream_t s)
+{
+    MixedPlan m;
+    if (!mixed_plan(rw, p, forced, m)) return 0;
+    const uint64_t n = p.n, n_pad = (n + 63) / 64 * 64;
+    CAPY_WS(state, uint64_t *, s, WS_STATE, 25 * n_pad * sizeof(uint64_t));
+    MixedParams q;
+    memset(&q, 0, sizeof q);
+    q.msgs = p.msgs;
+    q.msg_stride = p.msg_stride;
+    q.n = n;
+    q.state = state;
+    q.n_pad = n_pad;
+    memcpy(q.init_state, p.init_state, sizeof q.init_state);
+    q.k1_count = m.nb1;
+    q.k2_count = m.nb2;
+    for (uint64_t ph = 0; ph < m.P; ph++) {
+        q.load_state = ph ? 1 : 0;
+        q.k2_begin = ph * m.gs;
+        q.k2_end = std::min(n, (ph + 1) * m.gs);
+        q.k2_waves = (uint32_t)((q.k2_end - q.k2_begin + 31) / 32);
+        q.k2_first = (uint32_t)(ph * m.nb1);
+        q.k1_first_lo = (uint32_t)((ph ? ph - 1 : 0) * m.nb1 + m.nb2);  // groups below ph have had their fast phase
+        q.k1_first_hi = (uint32_t)(ph * m.nb1);
+        const uint64_t k1_items = n - (q.k2_end - q.k2_begin);
+        const unsigned waves = q.k2_waves + (unsigned)((k1_items + 63) / 64);
+        hipError_t e = launch_sponge_mixed(rw, q, waves, s);
+        if (e == hipErrorInvalidValue) return fail(CAPY_ERR_ARG, "internal: no mixed kernel instance for this rate");
+        CAPY_HIP(e);
+    }
+    // tail blocks, padding and squeeze from the saved states
+    SpongeParams r = p;
+    r.debug_flags = g_debug_flags.load();
+    r.resume_state = state;
+    r.resume_pad = n_pad;
+    r.resume_blocks = (uint32_t)m.nf;
+    CAPY_HIP(launch_sponge_k1_lat(rw, 0, r, s));
+    return 1;
+}
+
+// which kernel launch_sponge() picks: 1 one-lane latency-tuned, 2 two-lane, 3 rotating schedule, 4 one-lane issue-tuned
+static int sponge_plan(int rw, const SpongeParams &p, int *phases)
+{
+    const int forced = g_lanes_per_sponge.load();
+    const size_t simds = device_simds();
+    *phases = 1;
+    MixedPlan m;
+    if ((forced == 3 || (forced == 0 && g_mixed_enabled.load())) && mixed_plan(rw, p, forced == 3, m)) {
+        *phases = (int)m.P;
+        return 3;
+    }
+    if (forced == 2 || ((forced == 0 || forced == 3) && p.n <= 32 * simds)) return 2;
+    return p.n > 128 * simds ? 4 : 1;
+}
 
 static int launch_sponge(int rw, const SpongeParams &p, hipStream_t s)
 {
@@ -201,9 +320,15 @@ static int launch_sponge(int rw, const SpongeParams &p, hipStream_t s)
     q.debug_flags = g_debug_flags.load();
     const SpongeParams &p2 = q;
     hipError_t e;
-    if (forced == 2 || (forced == 0 && p.n <= K2_MAX_ITEMS))
+    const size_t simds = device_simds();
+    if (forced == 3 || (forced == 0 && g_mixed_enabled.load())) {
+        const int m = try_launch_mixed(rw, p, forced == 3, s);
+        if (m < 0) return m;
+        if (m > 0) return CAPY_OK;
+    }
+    if (forced == 2 || ((forced == 0 || forced == 3) && p.n <= 32 * simds))
         e = launch_sponge_k2(rw, (int)p.out_mode, p2, s);
-    else if (p.n > FULLCHIP_MIN_ITEMS)
+    else if (p.n > 128 * simds)
         e = launch_sponge_k1_full(rw, (int)p.out_mode, p2, s);
     else
         e = launch_sponge_k1_lat(rw, (int)p.out_mode, p2, s);
@@ -749,9 +874,26 @@ int capy_set_sponge_lanes(int lanes)
 {
     g_debug_flags.store(((unsigned)lanes >> 8) & 0xff);  // undocumented A/B switches in the high bits
     g_fused_enabled.store((((unsigned)lanes >> 16) & 1) == 0);  // bit 16: disable the fused encrypt kernel
+    g_mixed_enabled.store((((unsigned)lanes >> 17) & 1) == 0);  // bit 17: disable the mixed one/two-lane schedule
     lanes &= 0xff;
-    if (lanes != 0 && lanes != 1 && lanes != 2) return fail(CAPY_ERR_ARG, "lanes must be 0 (auto), 1 or 2");
+    if (lanes < 0 || lanes > 3) return fail(CAPY_ERR_ARG, "lanes must be 0 (auto), 1, 2 or 3 (mixed where eligible)");
     g_lanes_per_sponge.store(lanes);
+    return CAPY_OK;
+}
+
+int capy_sha3_launch_plan(int d, size_t n, uint64_t uniform_len, uint64_t msg_stride, int *kind, int *phases)
+{
+    if (!kind || !phases) return fail(CAPY_ERR_ARG, "null output");
+    if (!valid_d(d)) return fail(CAPY_ERR_UNSUPPORTED_SECPARAM, "unsupported security parameter");
+    Framing f = sha3_framing(d);
+    SpongeParams p;
+    memset(&p, 0, sizeof p);
+    p.uniform_len = uniform_len;
+    p.msg_stride = msg_stride;
+    p.absorb_body = 1;
+    p.stride_bytes = f.stride;
+    p.n = n;
+    *kind = sponge_plan(f.rw, p, phases);
     return CAPY_OK;
 }
 

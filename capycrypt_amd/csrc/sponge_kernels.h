@@ -116,9 +116,18 @@ __global__ __launch_bounds__(64, FULLCHIP ? CAPY_FULLCHIP_WAVES : 2) void sponge
         a.lo[i] = (uint32_t)p.init_state[i];
         a.hi[i] = (uint32_t)(p.init_state[i] >> 32);
     }
+    const bool resume = p.resume_state != nullptr;  // wave-uniform; phases H and B already done elsewhere
+    if (resume && active) {
+#pragma unroll
+        for (int i = 0; i < 25; i++) {
+            const uint64_t v = p.resume_state[(uint64_t)i * p.resume_pad + item];
+            a.lo[i] = (uint32_t)v;
+            a.hi[i] = (uint32_t)(v >> 32);
+        }
+    }
 
     // ---------------- phase H: per-item head blocks (uniform trip count)
-    for (uint32_t b = 0; b < hb; b++) {
+    for (uint32_t b = 0; b < (resume ? 0u : hb); b++) {
         if (active) {
 #pragma unroll
             for (int w = 0; w < RW; w++) xor_word(a, w, stream_word(p, c, (uint64_t)b * RB + 8 * w));
@@ -134,7 +143,9 @@ __global__ __launch_bounds__(64, FULLCHIP ? CAPY_FULLCHIP_WAVES : 2) void sponge
     };
 
     // ---------------- phase B: full body blocks, wave-cooperative loads through LDS
-    if (uniform) {
+    if (resume) {
+        // nothing: blocks [0, resume_blocks) are in the loaded state
+    } else if (uniform) {
         const uint32_t nf = p.absorb_body ? (uint32_t)(p.uniform_len / RB) : 0;  // same for every lane
         if (nf) {
             uint32_t voff[RW];
@@ -240,7 +251,7 @@ __global__ __launch_bounds__(64, FULLCHIP ? CAPY_FULLCHIP_WAVES : 2) void sponge
 
     // ---------------- phase T: remaining blocks (tail of the body, suffix, pad) byte-granular
     {
-        const uint32_t first = hb + nfull;
+        const uint32_t first = resume ? p.resume_blocks : hb + nfull;
         const uint32_t cnt = nb > first ? nb - first : 0;
         const uint32_t max_cnt = wave_max_u32(cnt);
         for (uint32_t j = 0; j < max_cnt; j++) {

@@ -8,9 +8,11 @@
 // holds the low 32-bit halves of all 25 Keccak lanes, the odd lane the high halves.
 //   theta / chi / iota are bit-parallel            -> identical code on both halves (25 VGPRs of state)
 //   rotations need the partner's half              -> one v_mov_b32_dpp quad_perm:[1,0,3,2] + one v_alignbit_b32
-// 120 VALU per round per wave instead of 180, for 32 sponges per wave instead of 64: 1.5x the
-// throughput of the one-lane-per-sponge kernel whenever the chip is under-occupied, 0.7x when it is full
-// (so the launcher picks this kernel only for small batches, see sponge.hip).
+// 120 VALU per round per wave instead of 180, for 32 sponges per wave instead of 64: 1.48x the
+// per-sponge speed of the one-lane-per-sponge kernel whenever the chip is under-occupied (40.4 vs 59.7 ms per MiB
+// of message), 0.75x when it is full (so the launcher picks this kernel only for small batches, see sponge.hip).
+// The DPP move must carry bound_ctrl: without it the compiler materialises the "old" operand with a v_mov_b32 per
+// swap (+29 VALU per round, measured 1.12x instead of 1.48x).
 //
 // Same stream semantics, parameters and phases as sponge_kernels.h (which documents the framing).
 #pragma once
@@ -21,7 +23,7 @@ namespace capy {
 __device__ __forceinline__ uint32_t dpp_swap_pair(uint32_t v)
 {
     // quad_perm:[1,0,3,2] -> dpp_ctrl = 1 | 0<<2 | 3<<4 | 2<<6 = 0xB1
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
 }
 
 // rotate-left of a 64-bit lane split as (own half, partner half); valid for both halves

@@ -1,4 +1,4 @@
-// sponge_launch.h — the sponge kernel instances live in three translation units (built in parallel);
+// sponge_launch.h — the sponge kernel instances live in several translation units (built in parallel);
 // each exports one launcher.  mode: 0 digest, 1 keystream XOR.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -12,6 +12,9 @@ hipError_t launch_sponge_k1_full(int rw, int mode, const SpongeParams &p, hipStr
 // two lanes per sponge (small batches of long messages)
 hipError_t launch_sponge_k2(int rw, int mode, const SpongeParams &p, hipStream_t s);
 // tag + keystream sponges of sha3_encrypt / sha3_decrypt in one pass (sponge_fused.h); rw in {17, 19, 21}
+// one- and two-lane waves side by side, one phase of the rotating schedule (sponge_mixed.h); rw in {9,13,17,18,21}
+struct MixedParams;
+hipError_t launch_sponge_mixed(int rw, const MixedParams &q, unsigned waves, hipStream_t s);
 struct FusedParams;
 hipError_t launch_sponge_fused(int rw, const FusedParams &fp, hipStream_t s);
 }  // namespace capy

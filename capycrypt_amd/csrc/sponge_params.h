@@ -39,6 +39,11 @@ struct SpongeParams {
     uint32_t out_len;
     const int32_t *mask;  // optional: only items with mask[i] != 0 are processed
     uint32_t debug_flags;  // bit 0: do not use the wave-uniform addressing path (A/B measurements)
+    // resume (one-lane digest kernel only): the first resume_blocks blocks were absorbed by sponge_mixed_kernel,
+    // whose states sit word-major in resume_state[25][resume_pad]; only the tail blocks and the squeeze remain
+    const uint64_t *resume_state;
+    uint64_t resume_pad;
+    uint32_t resume_blocks;
     uint64_t n;
 };
 

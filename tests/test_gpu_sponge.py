@@ -358,6 +358,43 @@ def test_dev_api_uniform_batches_all_instances(capy, O, n, L):
         assert hp == bytes(ref)
 
 
+@pytest.mark.parametrize("d,n,L,stride", [(256, 40000, 200003, 200008), (512, 34001, 100001, 100008),
+                                          (224, 57344, 160000, 160000), (384, 45000, 140007, 140008),
+                                          (256, 60000, 150001, 150008)])
+def test_rotating_schedule_matches_one_lane_kernel(capy, sponge_lanes, d, n, L, stride):
+    """Batches between half a chip and a full chip of one-lane sponges take the rotating one-/two-lane schedule
+    (sponge_mixed.h: P phase launches + a resume launch).  Every digest must equal the one-lane kernel's, and
+    hashlib's where the reference is FIPS 202 for that length (d = 256 always; the other lengths here are off the
+    135 (mod 136) / r-1 (mod r) cases of SURVEY.md 8a row 9).  Covers ragged last groups and partial waves."""
+    import ctypes as C
+    import hashlib
+
+    import torch
+
+    from capycrypt_amd import _lib
+
+    if sponge_lanes != 1:
+        pytest.skip("sets the kernel choice itself")
+    lib = _lib.lib()
+    msgs = _dev_rand(n * stride, 11)
+    outs = []
+    for lanes in (1, 3):
+        _lib.check(lib.capy_set_sponge_lanes(lanes))
+        kind, phases = C.c_int(0), C.c_int(0)
+        _lib.check(lib.capy_sha3_launch_plan(d, n, L, stride, C.byref(kind), C.byref(phases)))
+        assert (kind.value, phases.value >= 2) == ((3, True) if lanes == 3 else (1, False))
+        dig = torch.zeros(n * (d // 8), dtype=torch.uint8, device="cuda")
+        _lib.check(lib.capy_sha3_batch_dev(d, n, msgs.data_ptr(), None, L, stride, dig.data_ptr(), None))
+        torch.cuda.synchronize()
+        outs.append(dig)
+    assert torch.equal(outs[0], outs[1])
+    h = getattr(hashlib, "sha3_%d" % d)
+    hd = bytes(outs[1].cpu().numpy())
+    for i in sorted({0, 31, 32, 63, 64, n // 2, n - 65, n - 2, n - 1}):
+        m = bytes(msgs[i * stride:i * stride + L].cpu().numpy())
+        assert hd[i * (d // 8):(i + 1) * (d // 8)] == h(m).digest(), i
+
+
 def test_concurrent_host_threads(capy, O):
     """include/capyhip.h promises thread safety: four host threads issue different batched calls at once
     (ctypes drops the GIL during the call) and every result must still be bit-exact."""

@@ -20,6 +20,8 @@ for d in dirs:
             agg[k]["_dur_ns"] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
             agg[k]["_grid"] = int(r["Grid_Size"])
             agg[k]["_vgpr"] = int(r["VGPR_Count"]) + int(r["Accum_VGPR_Count"])
+            if os.environ.get("CAPY_PMC_ITEMS") and "sponge_" in k:
+                agg[k]["_items"] = int(os.environ["CAPY_PMC_ITEMS"])  # batch size behind the grid (bench.py matches on it)
 res = {}
 for k, c in agg.items():
     e = dict(c)
