@@ -31,6 +31,7 @@ SIGNATURES = {
     "capy_sha3_batch": (C.c_int, [C.c_int, sz, vp, vp, vp]),
     "capy_sha3_batch_dev": (C.c_int, [C.c_int, sz, vp, vp, u64, u64, vp, vp]),
     "capy_cshake_batch": (C.c_int, [C.c_int, sz, vp, vp, sz, vp, sz, vp, sz, vp]),
+    "capy_cshake_batch_dev": (C.c_int, [C.c_int, sz, vp, vp, u64, u64, sz, vp, sz, vp, sz, vp, u64, vp]),
     "capy_kmac_xof_batch": (C.c_int, [C.c_int, sz, vp, sz, vp, vp, sz, vp, sz, vp]),
     "capy_kmac_xof_batch_dev": (C.c_int, [C.c_int, sz, vp, sz, u64, vp, vp, u64, u64, sz, vp, sz, vp, u64, vp]),
     "capy_sha3_encrypt_batch": (C.c_int, [C.c_int, sz, vp, sz, vp, vp, vp, vp]),

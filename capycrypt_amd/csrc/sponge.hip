@@ -251,7 +251,6 @@ static bool mixed_plan(int rw, const SpongeParams &p, bool forced, MixedPlan &m)
     const uint32_t rb = (uint32_t)rw * 8;
     if (p.out_mode != 0 || !p.absorb_body || p.offsets || p.mask || p.pre_len || p.head_len || p.stride_bytes != rb) return false;
     if ((((uintptr_t)p.msgs | p.msg_stride) & 7) || p.msg_stride * 64 >= 0xfff00000ULL || p.msg_stride < p.uniform_len) return false;
-    if (rw == 19) return false;  // no instance (D384-as-capacity cSHAKE never comes without a head)
     const uint64_t S = device_simds(), n = p.n;
     m.nf = p.uniform_len / rb;
     if (n <= 32 * S || n >= 64 * S || m.nf < 1024) return false;
@@ -787,6 +786,16 @@ int capy_cshake_batch(int d, size_t n, const uint8_t *xs, const uint64_t *offset
     if (rc) return rc;
     if (ol) CAPY_HIP(hipMemcpy2D(outs, ol, out.p, os, ol, n, hipMemcpyDeviceToHost));
     return CAPY_OK;
+}
+
+int capy_cshake_batch_dev(int d, size_t n, const uint8_t *xs, const uint64_t *offsets, uint64_t uniform_len,
+                          uint64_t msg_stride, size_t l_bits, const uint8_t *fn_name, size_t fn_len,
+                          const uint8_t *custom, size_t custom_len, uint8_t *outs, uint64_t out_stride, void *stream)
+{
+    if (n && !outs) return fail(CAPY_ERR_ARG, "null argument");
+    if (out_stride < l_bits / 8) return fail(CAPY_ERR_ARG, "out_stride shorter than the output");
+    return cshake_launch(d, n, view_dev(xs, offsets, uniform_len, msg_stride), l_bits, fn_name, fn_len, custom,
+                         custom_len, outs, out_stride, (hipStream_t)stream);
 }
 
 int capy_kmac_xof_batch_dev(int d, size_t n, const uint8_t *keys, size_t key_len, uint64_t key_stride,

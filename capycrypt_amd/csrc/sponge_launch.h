@@ -12,7 +12,7 @@ hipError_t launch_sponge_k1_full(int rw, int mode, const SpongeParams &p, hipStr
 // two lanes per sponge (small batches of long messages)
 hipError_t launch_sponge_k2(int rw, int mode, const SpongeParams &p, hipStream_t s);
 // tag + keystream sponges of sha3_encrypt / sha3_decrypt in one pass (sponge_fused.h); rw in {17, 19, 21}
-// one- and two-lane waves side by side, one phase of the rotating schedule (sponge_mixed.h); rw in {9,13,17,18,21}
+// one- and two-lane waves side by side, one phase of the rotating schedule (sponge_mixed.h); rw in {9,13,17,18,19,21}
 struct MixedParams;
 hipError_t launch_sponge_mixed(int rw, const MixedParams &q, unsigned waves, hipStream_t s);
 struct FusedParams;

@@ -12,6 +12,7 @@ hipError_t launch_sponge_mixed(int rw, const MixedParams &q, unsigned waves, hip
     case 13: hipLaunchKernelGGL(sponge_mixed_kernel<13>, grid, block, 0, s, q); break;
     case 17: hipLaunchKernelGGL(sponge_mixed_kernel<17>, grid, block, 0, s, q); break;
     case 18: hipLaunchKernelGGL(sponge_mixed_kernel<18>, grid, block, 0, s, q); break;
+    case 19: hipLaunchKernelGGL(sponge_mixed_kernel<19>, grid, block, 0, s, q); break;
     case 21: hipLaunchKernelGGL(sponge_mixed_kernel<21>, grid, block, 0, s, q); break;
     default: return hipErrorInvalidValue;
     }

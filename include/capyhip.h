@@ -59,6 +59,10 @@ int capy_sha3_batch_dev(int d, size_t n, const uint8_t *msgs, const uint64_t *of
 int capy_cshake_batch(int d, size_t n, const uint8_t *xs, const uint64_t *offsets, size_t l_bits,
                       const uint8_t *fn_name, size_t fn_len, const uint8_t *custom, size_t custom_len,
                       uint8_t *outs);
+/* Same on device buffers (layout as capy_sha3_batch_dev); output i at outs + i*out_stride. */
+int capy_cshake_batch_dev(int d, size_t n, const uint8_t *xs, const uint64_t *offsets, uint64_t uniform_len,
+                          uint64_t msg_stride, size_t l_bits, const uint8_t *fn_name, size_t fn_len,
+                          const uint8_t *custom, size_t custom_len, uint8_t *outs, uint64_t out_stride, void *stream);
 
 /* KMACXOF: out_i = kmac_xof(key_i, x_i, l_bits, S, d); keys are n fixed-length keys of key_len bytes.
  * Replaces kmac_xof(), src/sha3/shake_functions.rs:79-89 (pub), and

@@ -395,6 +395,57 @@ def test_rotating_schedule_matches_one_lane_kernel(capy, sponge_lanes, d, n, L, 
         assert hd[i * (d // 8):(i + 1) * (d // 8)] == h(m).digest(), i
 
 
+def test_cshake_dev_api_and_rotating_schedule(capy, O, sponge_lanes):
+    """capy_cshake_batch_dev: a small ragged-free batch against the oracle under every kernel choice, and (once) a
+    batch large enough for the rotating schedule, whose shared prefix arrives folded into the initial state."""
+    import torch
+
+    from capycrypt_amd import _lib
+
+    lib = _lib.lib()
+    n, L, stride = 300, 777, 784
+    msgs = _dev_rand(n * stride, 21)
+    host = bytes(msgs.cpu().numpy())
+    for d, lbits in ((256, 512), (512, 256), (224, 448), (384, 136 * 8 * 2)):
+        out = torch.zeros(n * (lbits // 8), dtype=torch.uint8, device="cuda")
+        _lib.check(lib.capy_cshake_batch_dev(d, n, msgs.data_ptr(), None, L, stride, lbits, b"FN", 2, b"custom", 6,
+                                             out.data_ptr(), lbits // 8, None))
+        torch.cuda.synchronize()
+        ho = bytes(out.cpu().numpy())
+        for i in (0, 1, 63, 64, n - 1):
+            assert ho[i * (lbits // 8):(i + 1) * (lbits // 8)] == O.cshake(host[i * stride:i * stride + L], lbits, b"FN",
+                                                                          b"custom", d), (d, i)
+    if sponge_lanes != 1:
+        return
+    n, L, stride = 40000, 150003, 150008
+    big = _dev_rand(n * stride, 22)
+    outs = []
+    for lanes in (1, 3):
+        _lib.check(lib.capy_set_sponge_lanes(lanes))
+        out = torch.zeros(n * 64, dtype=torch.uint8, device="cuda")
+        _lib.check(lib.capy_cshake_batch_dev(512, n, big.data_ptr(), None, L, stride, 512, b"", 0, b"S", 1,
+                                             out.data_ptr(), 64, None))
+        torch.cuda.synchronize()
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+    ho = bytes(outs[1].cpu().numpy())
+    for i in (0, 33, n - 1):
+        m = bytes(big[i * stride:i * stride + L].cpu().numpy())
+        assert ho[64 * i:64 * i + 64] == O.cshake(m, 512, b"", b"S", 512), i
+
+
+def test_device_fill_equals_host_harness_prng(capy, sponge_lanes):
+    """capy_fill_random_dev and capycrypt_amd.harness_prng produce the same stream (any shard's inputs
+    can be regenerated on either side)."""
+    from capycrypt_amd import harness_prng as H
+
+    if sponge_lanes != 1:
+        pytest.skip("independent of the sponge kernel choice")
+    for seed, nbytes in ((0, 64), (0xCA9C0001, 1 << 16), (2**64 - 5, 8 * 1000)):
+        t = _dev_rand(nbytes, seed)
+        assert bytes(t.cpu().numpy()) == H.fill(seed, nbytes)
+
+
 def test_concurrent_host_threads(capy, O):
     """include/capyhip.h promises thread safety: four host threads issue different batched calls at once
     (ctypes drops the GIL during the call) and every result must still be bit-exact."""

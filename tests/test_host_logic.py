@@ -99,3 +99,14 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(ImportError):
         _lib.lib()
+
+
+def test_harness_prng_reference_values_and_offsets():
+    """SplitMix64 counter mode: the first outputs for seed 0 are the published SplitMix64 sequence
+    (e220a8397b1dcdaf, 6e789e6aa1b965f4, 06c45d188009454f), and any byte range equals a slice of the whole."""
+    from capycrypt_amd import harness_prng as H
+
+    assert [int(x) for x in H.words(0, 3)] == [0xE220A8397B1DCDAF, 0x6E789E6AA1B965F4, 0x06C45D188009454F]
+    whole = H.fill(0xCA9C0001, 4096)
+    for off, n in ((0, 1), (3, 17), (8, 8), (1001, 2000), (4090, 6)):
+        assert H.fill(0xCA9C0001, n, off) == whole[off:off + n]
