@@ -1,0 +1,78 @@
+"""Seeded differential fuzz of the sponge path: random security parameters, batch sizes and ragged lengths (empty
+messages, lengths on and around every block boundary, unaligned starts) through the host-buffer C ABI under each
+kernel choice; every output must equal the CPU oracle's (reference quirks on), and encrypt -> decrypt must round-trip.
+Sizes are small enough for the oracle to finish in seconds."""
+import random
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RATES = {224: (144, 172), 256: (136, 168), 384: (104, 152), 512: (72, 136)}  # (sha3 rate, cshake/kmac rate) bytes
+
+
+def _lengths(rng, n, d):
+    r1, r2 = RATES[d]
+    special = [0, 1, 7, 8, 9, r1 - 2, r1 - 1, r1, r1 + 1, r2 - 4, r2 - 3, r2 - 2, r2 - 1, r2, r2 + 1, 2 * r1 - 1, 2 * r1,
+               2 * r2 - 3, 135, 136, 167, 168, 3 * r2]
+    out = []
+    for _ in range(n):
+        c = rng.random()
+        if c < 0.45:
+            out.append(rng.choice(special))
+        elif c < 0.9:
+            out.append(rng.randrange(0, 700))
+        else:
+            out.append(rng.randrange(700, 5000))
+    return out
+
+
+@pytest.mark.parametrize("lanes", [0, 1, 2, 2 | (1 << 8), 1 | (1 << 16)],
+                         ids=["auto", "one-lane", "two-lane", "two-lane,no-uniform", "one-lane,two-pass"])
+@pytest.mark.parametrize("seed", list(range(1, 9)))
+def test_sponge_fuzz_against_oracle(lanes, seed):
+    from capycrypt_amd import _lib, ops
+    from oracle import oracle as O
+
+    rng = random.Random(0xF022 + seed)
+    _lib.check(_lib.lib().capy_set_sponge_lanes(lanes))
+    try:
+        for d in (224, 256, 384, 512):
+            n = rng.choice([1, 2, 31, 33, 63, 65, 100, 130])
+            lens = _lengths(rng, n, d)
+            msgs = [rng.randbytes(x) for x in lens]
+            picks = sorted(set([0, n - 1] + [rng.randrange(n) for _ in range(10)]))
+
+            got = ops.sha3_batch(msgs, d)
+            for i in picks:
+                assert got[i] == O.sha3(msgs[i], d), ("sha3", d, lens[i])
+
+            lbits = rng.choice([8, 448, 512, 1088, 1600, 8 * 400])
+            cs = rng.randbytes(rng.randrange(0, 40))
+            got = ops.cshake_batch(msgs, lbits, b"FN", cs, d)
+            for i in picks:
+                assert got[i] == O.cshake(msgs[i], lbits, b"FN", cs, d), ("cshake", d, lens[i], lbits)
+
+            klen = rng.choice([0, 1, 32, 56, 64, 130, 200])
+            keys = [rng.randbytes(klen) for _ in range(n)]
+            got = ops.kmac_xof_batch(keys, msgs, lbits, cs, d)
+            for i in picks:
+                assert got[i] == O.kmac_xof(keys[i], msgs[i], lbits, cs, d), ("kmac", d, klen, lens[i], lbits)
+
+            pws = [rng.randbytes(klen) for _ in range(n)]
+            zs = [rng.randbytes(512) for _ in range(n)]
+            cts, tags = ops.sha3_encrypt_batch(pws, zs, msgs, d)
+            for i in picks:
+                ect, etag = O.sha3_encrypt(pws[i], zs[i], msgs[i], d)
+                assert cts[i] == ect and tags[i] == etag, ("encrypt", d, klen, lens[i])
+            bad = rng.randrange(n)
+            tags2 = list(tags)
+            tags2[bad] = bytes([tags[bad][0] ^ 0x40]) + tags[bad][1:]
+            pts, ok = ops.sha3_decrypt_batch(pws, zs, cts, tags2, d)
+            for i in range(n):
+                if i == bad:
+                    assert not ok[i] and pts[i] == cts[i]  # failure keeps the ciphertext (encryptable.rs:77-82)
+                else:
+                    assert ok[i] and pts[i] == msgs[i], ("decrypt", d, lens[i])
+    finally:
+        _lib.check(_lib.lib().capy_set_sponge_lanes(0))
