@@ -11,6 +11,13 @@
 
 namespace capy {
 
+// unroll factor of the doubling loop inside a window (1 = rolled: smallest code; see DESIGN.md for the measurements)
+#ifndef CAPY_ED448_DBL_UNROLL
+#define CAPY_ED448_DBL_UNROLL 1
+#endif
+#define CAPY_PRAGMA_(x) _Pragma(#x)
+#define CAPY_UNROLL(n) CAPY_PRAGMA_(unroll n)
+
 constexpr int VB_TABLE_DWORDS = TAB_ENTRIES * 64;  // per item: entries x (X, Y, Z, dT) x 16 limbs
 constexpr int FB_ROWS = NWIN + 1;                  // one row per window plus the recoding carry
 constexpr int FB_ENTRY_DWORDS = 48;                // (x, y, d*x*y) x 16 limbs
@@ -79,7 +86,7 @@ CAPY_HD inline Pt vb_scalarmul(const uint8_t *k_be, const Pt &P, uint32_t *tab)
     for (int i = 0; i < NWIN; i++) {
         // one doubling body keeps the loop inside the I-cache; the compiler sinks the T product (dead in all but
         // the last trip) out of the loop, so this runs 4S+3M per doubling plus one multiplication per window
-#pragma unroll 1
+        CAPY_UNROLL(CAPY_ED448_DBL_UNROLL)
         for (int j = 0; j < WBITS; j++) acc = pt_dbl<true>(acc);
         acc = vb_add_digit(acc, tab, sc_next_digit_msb(w));
     }
