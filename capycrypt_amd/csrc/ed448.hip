@@ -128,17 +128,17 @@ static int ensure_gtab(const uint32_t **out)
     if (dev < 0 || dev >= 64) return fail(CAPY_ERR_ARG, "device index out of range");
     std::lock_guard<std::mutex> lk(g_gtab_mu);
     if (!g_gtab[dev]) {
-        const size_t n = (size_t)FB_ROWS * TAB_ENTRIES;
+        const size_t n = (size_t)FB_ROWS * FB_TAB_ENTRIES;
         std::vector<uint8_t> sc(n * 56), pts(n * 112);
-        uint32_t pw[14] = {1};  // 2^(WBITS row) mod r
+        uint32_t pw[14] = {1};  // 2^(FB_WBITS row) mod r
         for (int row = 0; row < FB_ROWS; row++) {
             uint32_t acc[14] = {0};
-            for (int j = 0; j < TAB_ENTRIES; j++) {
-                sc_to_be(sc.data() + (size_t)(row * TAB_ENTRIES + j) * 56, acc);
-                memcpy(pts.data() + (size_t)(row * TAB_ENTRIES + j) * 112, G_XY, 112);
+            for (int j = 0; j < FB_TAB_ENTRIES; j++) {
+                sc_to_be(sc.data() + (size_t)(row * FB_TAB_ENTRIES + j) * 56, acc);
+                memcpy(pts.data() + (size_t)(row * FB_TAB_ENTRIES + j) * 112, G_XY, 112);
                 sc_add_mod(acc, pw);
             }
-            for (int d = 0; d < WBITS; d++) sc_dbl_mod(pw);
+            for (int d = 0; d < FB_WBITS; d++) sc_dbl_mod(pw);
         }
         DevBuf dsc, dpts, dout, dtab;
         CAPY_HIP(dsc.alloc(sc.size()));

@@ -4,8 +4,9 @@
 // /root/reference/src/sha3/aux_functions.rs:102-106), per-item table {0..2^(WBITS-1)}P in "cached" extended form
 // kept in HBM (lane-major so every lane streams whole 128-B lines), uniform control flow (every window does WBITS
 // doublings + 1 complete addition; the digit only selects the table row and a sign).
-// Fixed base: (NWIN+1) x TAB_ENTRIES affine table of j*2^(WBITS i)*G shared by all lanes, NWIN+1 mixed additions,
-// no doublings.  WBITS = 5: 90 windows, 17 entries (4352 B per item); measured against WBITS = 4 in profiles/.
+// Fixed base: (FbWin::NWIN+1) x FbWin::ENTRIES affine table of j*2^(FB_WBITS i)*G shared by all lanes, one mixed
+// addition per window, no doublings.  WBITS = 5: 90 windows, 17 entries (4352 B per item); FB_WBITS = 8: 56 windows,
+// 57 x 129 entries (1.41 MB, L2-resident; every lane of a wave reads the same row).
 #pragma once
 #include "ed448_dev.h"
 
@@ -19,9 +20,10 @@ namespace capy {
 #define CAPY_UNROLL(n) CAPY_PRAGMA_(unroll n)
 
 constexpr int VB_TABLE_DWORDS = TAB_ENTRIES * 64;  // per item: entries x (X, Y, Z, dT) x 16 limbs
-constexpr int FB_ROWS = NWIN + 1;                  // one row per window plus the recoding carry
+constexpr int FB_ROWS = FbWin::NWIN + 1;           // one row per window plus the recoding carry
+constexpr int FB_TAB_ENTRIES = FbWin::ENTRIES;
 constexpr int FB_ENTRY_DWORDS = 48;                // (x, y, d*x*y) x 16 limbs
-constexpr int FB_TABLE_DWORDS = FB_ROWS * TAB_ENTRIES * FB_ENTRY_DWORDS;
+constexpr int FB_TABLE_DWORDS = FB_ROWS * FB_TAB_ENTRIES * FB_ENTRY_DWORDS;
 
 CAPY_HD inline void store_fe(uint32_t *dst, const Fe &a)
 {
@@ -79,8 +81,8 @@ CAPY_HD inline Pt vb_scalarmul(const uint8_t *k_be, const Pt &P, uint32_t *tab)
     vb_build_table(tab, P);
     uint32_t k[14], w[15];
     sc_from_be(k, k_be);
-    const uint32_t top = sc_recode_signed(w, k);
-    sc_msb_align(w);
+    const uint32_t top = sc_recode_signed<WBITS>(w, k);
+    sc_msb_align<WBITS>(w);
     Pt acc = vb_add_digit(pt_identity(), tab, (int)top);
 #pragma unroll 1
     for (int i = 0; i < NWIN; i++) {
@@ -88,7 +90,7 @@ CAPY_HD inline Pt vb_scalarmul(const uint8_t *k_be, const Pt &P, uint32_t *tab)
         // the last trip) out of the loop, so this runs 4S+3M per doubling plus one multiplication per window
         CAPY_UNROLL(CAPY_ED448_DBL_UNROLL)
         for (int j = 0; j < WBITS; j++) acc = pt_dbl<true>(acc);
-        acc = vb_add_digit(acc, tab, sc_next_digit_msb(w));
+        acc = vb_add_digit(acc, tab, sc_next_digit_msb<WBITS>(w));
     }
     return acc;
 }
@@ -98,7 +100,7 @@ CAPY_HD inline Pt fb_add_digit(const Pt &acc, const uint32_t *gtab, int row, int
 {
     const bool neg = digit < 0;
     const int idx = neg ? -digit : digit;
-    const uint32_t *e = gtab + (row * TAB_ENTRIES + idx) * FB_ENTRY_DWORDS;
+    const uint32_t *e = gtab + (row * FB_TAB_ENTRIES + idx) * FB_ENTRY_DWORDS;
     Fe x2 = load_fe(e), y2 = load_fe(e + 16), td2 = load_fe(e + 32);
     x2 = fe_select(neg, x2, fe_neg_nr(x2));
     td2 = fe_select(neg, td2, fe_neg_nr(td2));
@@ -110,15 +112,15 @@ CAPY_HD inline Pt fb_scalarmul(const uint8_t *k_be, const uint32_t *gtab)
 {
     uint32_t k[14], w[15];
     sc_from_be(k, k_be);
-    const uint32_t top = sc_recode_signed(w, k);
-    Pt acc = fb_add_digit(pt_identity(), gtab, NWIN, (int)top);
+    const uint32_t top = sc_recode_signed<FB_WBITS>(w, k);
+    Pt acc = fb_add_digit(pt_identity(), gtab, FbWin::NWIN, (int)top);
 #pragma unroll 1
-    for (int i = 0; i < NWIN; i++) acc = fb_add_digit(acc, gtab, i, sc_next_digit_lsb(w));
+    for (int i = 0; i < FbWin::NWIN; i++) acc = fb_add_digit(acc, gtab, i, sc_next_digit_lsb<FB_WBITS>(w));
     return acc;
 }
 
 // [a]G + [b]P in one pass (Straus): the doublings of the variable-base loop are shared; the G part
-// uses row 0 of the fixed-base table (j*G, j = 0..8).
+// uses row 0 of the fixed-base table (j*G, j = 0..2^(FB_WBITS-1), of which the WBITS-wide digits reach 0..2^(WBITS-1)).
 CAPY_HD inline Pt double_scalarmul(const uint8_t *a_be, const uint8_t *b_be, const Pt &P, uint32_t *tab,
                                    const uint32_t *gtab)
 {
@@ -126,17 +128,17 @@ CAPY_HD inline Pt double_scalarmul(const uint8_t *a_be, const uint8_t *b_be, con
     uint32_t ka[14], kb[14], wa[15], wb[15];
     sc_from_be(ka, a_be);
     sc_from_be(kb, b_be);
-    const uint32_t topa = sc_recode_signed(wa, ka), topb = sc_recode_signed(wb, kb);
-    sc_msb_align(wa);
-    sc_msb_align(wb);
+    const uint32_t topa = sc_recode_signed<WBITS>(wa, ka), topb = sc_recode_signed<WBITS>(wb, kb);
+    sc_msb_align<WBITS>(wa);
+    sc_msb_align<WBITS>(wb);
     Pt acc = vb_add_digit(pt_identity(), tab, (int)topb);
     acc = fb_add_digit(acc, gtab, 0, (int)topa);
 #pragma unroll 1
     for (int i = 0; i < NWIN; i++) {
 #pragma unroll 1
         for (int j = 0; j < WBITS; j++) acc = pt_dbl<true>(acc);
-        acc = vb_add_digit(acc, tab, sc_next_digit_msb(wb));
-        acc = fb_add_digit(acc, gtab, 0, sc_next_digit_msb(wa));
+        acc = vb_add_digit(acc, tab, sc_next_digit_msb<WBITS>(wb));
+        acc = fb_add_digit(acc, gtab, 0, sc_next_digit_msb<WBITS>(wa));
     }
     return acc;
 }

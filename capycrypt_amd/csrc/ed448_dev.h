@@ -521,43 +521,63 @@ CAPY_HD inline void sc_to_be(uint8_t *out, const uint32_t w[14])
     }
 }
 
-// Signed fixed-window recoding, window width WBITS (radix 2^WBITS), NWIN windows cover the 448 scalar bits:
-//     k = sum_{i<NWIN} (dig_i - HALF) 2^(WBITS i) + top 2^(WBITS NWIN),   dig_i = WBITS-bit digits of k' = k + OFFSET,
-// OFFSET = sum_i HALF 2^(WBITS i), HALF = 2^(WBITS-1), top = bit WBITS*NWIN of k'.  Digits lie in [-HALF, HALF), so a
+// Signed fixed-window recoding, window width W (radix 2^W), NWIN windows cover the 448 scalar bits:
+//     k = sum_{i<NWIN} (dig_i - HALF) 2^(W i) + top 2^(W NWIN),   dig_i = W-bit digits of k' = k + OFFSET,
+// OFFSET = sum_i HALF 2^(W i), HALF = 2^(W-1), top = bit W*NWIN of k'.  Digits lie in [-HALF, HALF), so a
 // table of {0..HALF} P plus a sign serves every window with the same control flow.
+// Two widths are in use: WBITS for the per-item tables of the variable-base path (table build cost grows with
+// 2^W), FB_WBITS for the shared fixed-base table (built once per device, so as wide as the L2 comfortably holds).
 #ifndef CAPY_ED448_WBITS
 #define CAPY_ED448_WBITS 5
 #endif
+#ifndef CAPY_ED448_FB_WBITS
+#define CAPY_ED448_FB_WBITS 8
+#endif
+template <int W>
+struct Win {
+    static_assert(W >= 2 && W <= 10, "window width");
+    static constexpr int BITS = W;
+    static constexpr int NWIN = (448 + W - 1) / W;
+    static constexpr int HALF = 1 << (W - 1);
+    static constexpr int ENTRIES = HALF + 1;
+    static constexpr int TOP_BIT = W * NWIN;  // >= 448, < 480
+    static_assert(TOP_BIT < 480, "the recoded scalar must fit 15 words");
+};
 constexpr int WBITS = CAPY_ED448_WBITS;
-constexpr int NWIN = (448 + WBITS - 1) / WBITS;
-constexpr int WHALF = 1 << (WBITS - 1);
-constexpr int TAB_ENTRIES = WHALF + 1;
-constexpr int TOP_BIT = WBITS * NWIN;  // >= 448, < 480
+constexpr int FB_WBITS = CAPY_ED448_FB_WBITS;
+static_assert(FB_WBITS >= WBITS, "row 0 of the fixed-base table also serves the variable-base digits (Straus)");
+using VbWin = Win<WBITS>;
+using FbWin = Win<FB_WBITS>;
+constexpr int NWIN = VbWin::NWIN;
+constexpr int WHALF = VbWin::HALF;
+constexpr int TAB_ENTRIES = VbWin::ENTRIES;
 
+template <int W>
 CAPY_HD constexpr uint32_t sc_recode_offset_word(int j)
 {
     uint32_t w = 0;
-    for (int i = 0; i < NWIN; i++) {
-        const int pos = WBITS * i + WBITS - 1;
+    for (int i = 0; i < Win<W>::NWIN; i++) {
+        const int pos = W * i + W - 1;
         if (pos / 32 == j) w |= 1u << (pos % 32);
     }
     return w;
 }
 
 // in: 14 words of k (LE).  out: 15 words of k' (LE).  returns top.
+template <int W>
 CAPY_HD inline uint32_t sc_recode_signed(uint32_t kp[15], const uint32_t k[14])
 {
     uint64_t c = 0;
 #pragma unroll
     for (int i = 0; i < 15; i++) {
-        const uint64_t v = (uint64_t)(i < 14 ? k[i] : 0u) + sc_recode_offset_word(i) + c;
+        const uint64_t v = (uint64_t)(i < 14 ? k[i] : 0u) + sc_recode_offset_word<W>(i) + c;
         kp[i] = (uint32_t)v;
         c = v >> 32;
     }
-    return (kp[14] >> (TOP_BIT - 448)) & 1u;
+    return (kp[14] >> (Win<W>::TOP_BIT - 448)) & 1u;
 }
 
-// most-significant digit first: after sc_msb_align the current digit is the top WBITS bits of kp[14]
+// most-significant digit first: after sc_msb_align the current digit is the top W bits of kp[14]
 CAPY_HD inline void sc_shl(uint32_t kp[15], int s)  // 1 <= s <= 32
 {
     if (s == 32) {
@@ -570,20 +590,26 @@ CAPY_HD inline void sc_shl(uint32_t kp[15], int s)  // 1 <= s <= 32
         kp[0] <<= s;
     }
 }
-CAPY_HD inline void sc_msb_align(uint32_t kp[15]) { sc_shl(kp, 480 - TOP_BIT); }
+template <int W>
+CAPY_HD inline void sc_msb_align(uint32_t kp[15])
+{
+    sc_shl(kp, 480 - Win<W>::TOP_BIT);
+}
+template <int W>
 CAPY_HD inline int sc_next_digit_msb(uint32_t kp[15])
 {
-    const int dig = (int)(kp[14] >> (32 - WBITS)) - WHALF;
-    sc_shl(kp, WBITS);
+    const int dig = (int)(kp[14] >> (32 - W)) - Win<W>::HALF;
+    sc_shl(kp, W);
     return dig;
 }
 // least-significant digit first
+template <int W>
 CAPY_HD inline int sc_next_digit_lsb(uint32_t kp[15])
 {
-    const int dig = (int)(kp[0] & ((1u << WBITS) - 1u)) - WHALF;
+    const int dig = (int)(kp[0] & ((1u << W) - 1u)) - Win<W>::HALF;
 #pragma unroll
-    for (int t = 0; t < 14; t++) kp[t] = (kp[t] >> WBITS) | (kp[t + 1] << (32 - WBITS));
-    kp[14] >>= WBITS;
+    for (int t = 0; t < 14; t++) kp[t] = (kp[t] >> W) | (kp[t + 1] << (32 - W));
+    kp[14] >>= W;
     return dig;
 }
 

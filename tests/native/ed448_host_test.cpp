@@ -70,20 +70,20 @@ void ht_build_gtab(const uint8_t *g_xy)
 {
     g_tab.assign(FB_TABLE_DWORDS + 4, 0);
     uint32_t *t = (uint32_t *)gtab_aligned();
-    Pt base = pt_from_affine_bytes(g_xy);  // 2^(WBITS row) * G
+    Pt base = pt_from_affine_bytes(g_xy);  // 2^(FB_WBITS row) * G
     for (int row = 0; row < FB_ROWS; row++) {
         Pt acc = pt_identity();
-        for (int j = 0; j < TAB_ENTRIES; j++) {
+        for (int j = 0; j < FB_TAB_ENTRIES; j++) {
             uint8_t xy[112];
             pt_to_affine_bytes(xy, acc);
             Fe x = fe_from_bytes(xy), y = fe_from_bytes(xy + 56);
-            uint32_t *e = t + (row * TAB_ENTRIES + j) * FB_ENTRY_DWORDS;
+            uint32_t *e = t + (row * FB_TAB_ENTRIES + j) * FB_ENTRY_DWORDS;
             store_fe(e, x);
             store_fe(e + 16, y);
             store_fe(e + 32, fe_mul_d(fe_mul(x, y)));
             acc = pt_add(acc, base);
         }
-        for (int d = 0; d < WBITS; d++) base = pt_dbl<true>(base);
+        for (int d = 0; d < FB_WBITS; d++) base = pt_dbl<true>(base);
     }
 }
 void ht_basemul(const uint8_t *k_be, uint8_t *out_xy) { pt_to_affine_bytes(out_xy, fb_scalarmul(k_be, gtab_aligned())); }
