@@ -147,8 +147,7 @@ CAPY_HD inline Pt double_scalarmul(const uint8_t *a_be, const uint8_t *b_be, con
 // r = 2^446 - 0x8335dc163bb124b65129c96fde933d8d723a70aadc873d6d54a7bb0d, as 14 LE words.
 // The curve crate's Scalar ops (`mul_mod`, `*`, `-`; call sites /root/reference/src/ecc/keypair.rs:43,
 // signable.rs:42,46,54, encryptable.rs:36,77) are taken as arithmetic mod r with reduced results
-// (assumption (iii)).  These run once or twice per signature, so they are simple
-// bit-serial routines without dynamically indexed register arrays.
+// (assumption (iii)).  Statically indexed register arrays throughout.
 CAPY_HD inline uint32_t sc_r_word(int i)
 {
     constexpr uint32_t R[14] = {0xab5844f3u, 0x2378c292u, 0x8dc58f55u, 0x216cc272u, 0xaed63690u,
@@ -201,33 +200,120 @@ CAPY_HD inline void sc_add_mod(uint32_t x[14], const uint32_t y[14])
     sc_cond_sub_r(x);
 }
 
-// out = a * b mod r (inputs: arbitrary 448-bit values)
+// 2^448 mod r = 4c for r = 2^446 - c: 226 bits, nine 28-bit limbs
+CAPY_HD inline uint32_t sc_c4_limb(int i)
+{
+    constexpr uint32_t C4[9] = {0x29eec34u, 0x1cf5b55u, 0x9c2ab72u, 0xf635c8eu, 0x5bf7a4cu,
+                                0xd944a72u, 0x8eec492u, 0x0cd7705u, 0x2u};
+    return C4[i];
+}
+
+// 14 x 32-bit words -> 16 x 28-bit limbs and back
+CAPY_HD inline void sc_to_limbs28(uint32_t l[16], const uint32_t w[14])
+{
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const int bit = 28 * i, j = bit >> 5, sh = bit & 31;
+        uint64_t v = (uint64_t)w[j] >> sh;
+        if (sh > 4 && j + 1 < 14) v |= (uint64_t)w[j + 1] << (32 - sh);
+        l[i] = (uint32_t)v & 0x0fffffffu;
+    }
+}
+CAPY_HD inline void sc_from_limbs28(uint32_t w[14], const uint32_t l[16])
+{
+#pragma unroll
+    for (int j = 0; j < 14; j++) {
+        const int bit = 32 * j, i = bit / 28, sh = bit - 28 * i;
+        uint64_t v = (uint64_t)l[i] >> sh;
+        v |= (uint64_t)l[i + 1] << (28 - sh);
+        if (56 - sh < 32 && i + 2 < 16) v |= (uint64_t)l[i + 2] << (56 - sh);
+        w[j] = (uint32_t)v;
+    }
+}
+
+// out = a * b mod r (inputs: arbitrary 448-bit values).  Schoolbook product on 28-bit limbs (columns < 2^60), then
+// the high half is folded down with 2^448 = 4c (mod r): 896 -> 675 -> 454 -> 449 -> 448 bits, and at most four
+// conditional subtractions of r finish (2^448 < 5r).
 CAPY_HD inline void sc_mul_mod(uint32_t out[14], const uint32_t a_in[14], const uint32_t b_in[14])
 {
-    uint32_t a[14], b[14], acc[14];
+    constexpr uint32_t M = 0x0fffffffu;
+    uint32_t a[16], b[16];
+    sc_to_limbs28(a, a_in);
+    sc_to_limbs28(b, b_in);
+    uint32_t x[32];
+    {
+        uint64_t col[31];
 #pragma unroll
-    for (int i = 0; i < 14; i++) {
-        a[i] = a_in[i];
-        b[i] = b_in[i];
-        acc[i] = 0;
+        for (int k = 0; k < 31; k++) col[k] = 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+#pragma unroll
+            for (int j = 0; j < 16; j++) col[i + j] += (uint64_t)a[i] * b[j];
+        uint64_t c = 0;
+#pragma unroll
+        for (int k = 0; k < 31; k++) {
+            const uint64_t v = col[k] + c;
+            x[k] = (uint32_t)v & M;
+            c = v >> 28;
+        }
+        x[31] = (uint32_t)c;  // < 2^28: the product is below 2^896
     }
-    sc_reduce(b);
+    // fold 1: limbs 16..31 (448 bits) x 4c -> 25 limbs
+    uint32_t y[26];
+    {
+        uint64_t col[26];
+#pragma unroll
+        for (int k = 0; k < 26; k++) col[k] = k < 16 ? x[k] : 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+#pragma unroll
+            for (int j = 0; j < 9; j++) col[i + j] += (uint64_t)x[16 + i] * sc_c4_limb(j);
+        uint64_t c = 0;
+#pragma unroll
+        for (int k = 0; k < 26; k++) {
+            const uint64_t v = col[k] + c;
+            y[k] = (uint32_t)v & M;
+            c = v >> 28;
+        }
+    }
+    // fold 2: limbs 16..25 (< 2^228) x 4c -> 19 limbs, + low 16 limbs
+    uint32_t z[20];
+    {
+        uint64_t col[20];
+#pragma unroll
+        for (int k = 0; k < 20; k++) col[k] = k < 16 ? y[k] : 0;
+#pragma unroll
+        for (int i = 0; i < 10; i++)
+#pragma unroll
+            for (int j = 0; j < 9; j++) col[i + j] += (uint64_t)y[16 + i] * sc_c4_limb(j);
+        uint64_t c = 0;
+#pragma unroll
+        for (int k = 0; k < 20; k++) {
+            const uint64_t v = col[k] + c;
+            z[k] = (uint32_t)v & M;
+            c = v >> 28;
+        }
+    }
+    // folds 3 and 4: what is left above 2^448 is < 2^7, then 0 or 1 (a set bit after fold 3 means the low part
+    // wrapped, so adding 4c once more cannot carry out again)
+    uint32_t r16[17];
+#pragma unroll
+    for (int k = 0; k < 17; k++) r16[k] = z[k];
+    // z[17..19] are zero: the value after fold 2 is below 2^448 + 2^(228+226)
 #pragma unroll 1
-    for (int bit = 0; bit < 448; bit++) {
-        sc_dbl_mod(acc);
-        const bool one = (a[13] >> 31) != 0;
+    for (int pass = 0; pass < 2; pass++) {
+        const uint32_t h = r16[16];
+        uint64_t c = 0;
 #pragma unroll
-        for (int i = 13; i > 0; i--) a[i] = (a[i] << 1) | (a[i - 1] >> 31);
-        a[0] <<= 1;
-        uint32_t t[14];
-#pragma unroll
-        for (int i = 0; i < 14; i++) t[i] = acc[i];
-        sc_add_mod(t, b);
-#pragma unroll
-        for (int i = 0; i < 14; i++) acc[i] = one ? t[i] : acc[i];
+        for (int k = 0; k < 16; k++) {
+            const uint64_t v = (uint64_t)r16[k] + (k < 9 ? (uint64_t)h * sc_c4_limb(k) : 0) + c;
+            r16[k] = (uint32_t)v & M;
+            c = v >> 28;
+        }
+        r16[16] = (uint32_t)c;
     }
-#pragma unroll
-    for (int i = 0; i < 14; i++) out[i] = acc[i];
+    sc_from_limbs28(out, r16);
+    sc_reduce(out);
 }
 
 // out = 4 a mod r

@@ -104,9 +104,11 @@ def test_lazy_reduction_bounds_hold(L):
 
 def test_scalar_field(L):
     rng = random.Random(8)
-    for i in range(10):
-        a = [0, E.R, E.R - 1, 2**448 - 1][i] if i < 4 else rng.getrandbits(448)
-        b = rng.getrandbits(448)
+    edge = [0, 1, E.R, E.R - 1, E.R + 1, 2**448 - 1, 2**446, 2**446 - 1, 2**447, 2**224, 4 * E.R + 123, 2**448 - 2**226]
+    pairs = [(a, b) for a in edge for b in edge]
+    pairs += [(rng.getrandbits(448), rng.getrandbits(448)) for _ in range(300)]
+    pairs += [(rng.getrandbits(rng.randrange(1, 449)), rng.getrandbits(rng.randrange(1, 449))) for _ in range(200)]
+    for a, b in pairs:
         assert call(L, "ht_sc_mul_mod", E.sc_to_bytes(a), E.sc_to_bytes(b)) == E.sc_to_bytes(a * b % E.R)
         assert call(L, "ht_sc_sub_mod", E.sc_to_bytes(a), E.sc_to_bytes(b)) == E.sc_to_bytes((a - b) % E.R)
         assert call(L, "ht_sc_mul4_mod", E.sc_to_bytes(a)) == E.sc_to_bytes(4 * a % E.R)
