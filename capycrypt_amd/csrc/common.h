@@ -57,6 +57,10 @@ struct PackedBatch {
     std::vector<uint64_t> h_starts, h_lens;
     uint64_t total = 0;
     bool repacked = false;
+    // set when every message has the same length and the starts are equally spaced: the kernels then take the
+    // wave-uniform addressing path (and the rotating schedule) exactly as for a strided device batch
+    bool uniform = false;
+    uint64_t uniform_len = 0, uniform_stride = 0;
     int upload(size_t n, const uint8_t *host_msgs, const uint64_t *host_offsets);
     // copy message bytes back into the caller's packed layout
     int download(size_t n, uint8_t *host_msgs, const uint64_t *host_offsets) const;

@@ -672,6 +672,12 @@ int PackedBatch::upload(size_t n, const uint8_t *host_msgs, const uint64_t *host
             if (h_lens[i]) memcpy(staging.data() + h_starts[i], host_msgs + host_offsets[i], h_lens[i]);
         src = staging.data();
     }
+    uniform = n > 0;
+    uniform_len = n ? h_lens[0] : 0;
+    uniform_stride = n > 1 ? h_starts[1] - h_starts[0] : (uniform_len + 7) & ~7ULL;
+    for (size_t i = 0; i < n && uniform; i++)
+        uniform = h_lens[i] == uniform_len && h_starts[i] == i * uniform_stride;
+    if ((uniform_stride & 7) || uniform_stride < uniform_len) uniform = false;
     CAPY_HIP(msgs.alloc(total + 16));
     CAPY_HIP(starts.alloc((n + 1) * 8));
     CAPY_HIP(lens.alloc((n ? n : 1) * 8));
@@ -699,9 +705,14 @@ MsgView view_of(const PackedBatch &b)
 {
     MsgView m;
     m.msgs = b.msgs.as<uint8_t>();
-    m.offsets = b.starts.as<uint64_t>();
-    m.lens = b.lens.as<uint64_t>();
     m.aligned8 = true;  // PackedBatch keeps or makes every start 8-byte aligned
+    if (b.uniform) {
+        m.uniform_len = b.uniform_len;
+        m.msg_stride = b.uniform_stride;
+    } else {
+        m.offsets = b.starts.as<uint64_t>();
+        m.lens = b.lens.as<uint64_t>();
+    }
     return m;
 }
 
