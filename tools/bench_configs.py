@@ -45,8 +45,9 @@ def emit(**kw):
 n = 1 << 20
 keys = rand(n * 64, 2)
 out = torch.empty(n * 1024, dtype=torch.uint8, device=dev)
+# a 1.2-1.5 ms launch: 3 repetitions only see the clock settle (686-743 M units/s); 30 reach the steady state
 s = timeit(lambda: _lib.check(lib.capy_kmac_xof_batch_dev(512, n, keys.data_ptr(), 64, 64, None, None, 0, 0, 8192,
-                                                          b"SKE", 3, out.data_ptr(), 1024, sp)))
+                                                          b"SKE", 3, out.data_ptr(), 1024, sp)), reps=30)
 emit(config=2, what="2^20 x KMACXOF256 1 KiB squeeze (64-B keys)", seconds=s, units_per_s=n / s,
      out_GBps=n * 1024 / s / 1e9,
      # 9 permutations run on the device per unit: 2 absorb (key block, suffix block) + 7 between the 8 squeeze blocks;
