@@ -249,7 +249,7 @@ struct MixedPlan {
 static bool mixed_plan(int rw, const SpongeParams &p, bool forced, MixedPlan &m)
 {
     const uint32_t rb = (uint32_t)rw * 8;
-    if (p.out_mode != 0 || !p.absorb_body || p.offsets || p.mask || p.pre_len || p.head_len || p.stride_bytes != rb) return false;
+    if (p.out_mode != 0 || !p.absorb_body || p.offsets || p.mask || p.pre_len || p.head_len % rb || p.stride_bytes != rb) return false;
     if ((((uintptr_t)p.msgs | p.msg_stride) & 7) || p.msg_stride * 64 >= 0xfff00000ULL || p.msg_stride < p.uniform_len) return false;
     const uint64_t S = device_simds(), n = p.n;
     m.nf = p.uniform_len / rb;
@@ -284,8 +284,17 @@ static int try_launch_mixed(int rw, const SpongeParams &p, bool forced, hipStrea
     memcpy(q.init_state, p.init_state, sizeof q.init_state);
     q.k1_count = m.nb1;
     q.k2_count = m.nb2;
+    const uint32_t hb = p.head_len / ((uint32_t)rw * 8);
+    if (hb) {
+        // per-item head blocks (KMAC keys) first: a head-only launch of the one-lane kernel seeds the state buffer
+        SpongeParams h = p;
+        h.debug_flags = g_debug_flags.load();
+        h.head_state = state;
+        h.resume_pad = n_pad;
+        CAPY_HIP(launch_sponge_k1_lat(rw, 0, h, s));
+    }
     for (uint64_t ph = 0; ph < m.P; ph++) {
-        q.load_state = ph ? 1 : 0;
+        q.load_state = (ph || hb) ? 1 : 0;
         q.k2_begin = ph * m.gs;
         q.k2_end = std::min(n, (ph + 1) * m.gs);
         q.k2_waves = (uint32_t)((q.k2_end - q.k2_begin + 31) / 32);
@@ -303,7 +312,7 @@ static int try_launch_mixed(int rw, const SpongeParams &p, bool forced, hipStrea
     r.debug_flags = g_debug_flags.load();
     r.resume_state = state;
     r.resume_pad = n_pad;
-    r.resume_blocks = (uint32_t)m.nf;
+    r.resume_blocks = hb + (uint32_t)m.nf;
     CAPY_HIP(launch_sponge_k1_lat(rw, 0, r, s));
     return 1;
 }

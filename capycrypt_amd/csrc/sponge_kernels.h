@@ -135,6 +135,14 @@ __global__ __launch_bounds__(64, FULLCHIP ? CAPY_FULLCHIP_WAVES : 2) void sponge
         }
     }
 
+    if (p.head_state != nullptr) {  // wave-uniform
+        if (active) {
+#pragma unroll
+            for (int i = 0; i < 25; i++) p.head_state[(uint64_t)i * p.resume_pad + item] = state_word(a, i);
+        }
+        return;
+    }
+
     // per-lane element offsets of the cooperative transfers (uniform path): element i = 64k + lane
     auto elem_offset = [&](int k) -> uint32_t {
         const uint32_t i = k * 64 + lane;

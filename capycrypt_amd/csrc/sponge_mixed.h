@@ -10,9 +10,10 @@
 // blocks, nb2 / nb1 = the measured speed ratio, so all waves of a phase finish together.  Expected gain over the
 // one-lane kernel = (ratio + P - 1) / P: 1.16x at P = 3 (49 152 sponges on 1024 SIMDs).
 //
-// Scope: the uniform digest absorb only (equal lengths, fixed stride, 8-byte aligned, no per-item head); the tail,
-// padding and squeeze are finished by sponge_kernel<RW, false, 0> resuming from the state buffer
-// (SpongeParams::resume_state).  Everything else takes the generic kernels.
+// Scope: the uniform digest absorb only (equal lengths, fixed stride, 8-byte aligned).  Per-item head blocks (KMAC
+// keys) are absorbed first by a head-only launch of sponge_kernel<RW, false, 0> (SpongeParams::head_state); the tail,
+// padding and squeeze are finished by the same kernel resuming from the state buffer (SpongeParams::resume_state).
+// Everything else takes the generic kernels.
 #pragma once
 #include "sponge_kernels_k2.h"
 

@@ -44,6 +44,9 @@ struct SpongeParams {
     const uint64_t *resume_state;
     uint64_t resume_pad;
     uint32_t resume_blocks;
+    // head-only launch (one-lane digest kernel only): absorb the per-item head blocks, write the states word-major
+    // to head_state[25][resume_pad] and stop (the body then goes through sponge_mixed_kernel)
+    uint64_t *head_state;
     uint64_t n;
 };
 

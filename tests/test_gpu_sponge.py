@@ -434,6 +434,34 @@ def test_cshake_dev_api_and_rotating_schedule(capy, O, sponge_lanes):
         assert ho[64 * i:64 * i + 64] == O.cshake(m, 512, b"", b"S", 512), i
 
 
+def test_kmac_rotating_schedule_with_per_item_keys(capy, O, sponge_lanes):
+    """compute_tagged_hash-sized batches (hashable.rs:33-35): per-item key blocks go through a head-only launch,
+    the body through the rotating schedule, tail and squeeze through the resume launch."""
+    import torch
+
+    from capycrypt_amd import _lib
+
+    if sponge_lanes != 1:
+        pytest.skip("sets the kernel choice itself")
+    lib = _lib.lib()
+    for d, n, L, stride, klen in ((512, 40000, 150003, 150008, 64), (256, 36000, 180001, 180008, 200)):
+        msgs = _dev_rand(n * stride, 31)
+        keys = _dev_rand(n * klen, 32)
+        outs = []
+        for lanes in (1, 3):
+            _lib.check(lib.capy_set_sponge_lanes(lanes))
+            out = torch.zeros(n * 64, dtype=torch.uint8, device="cuda")
+            _lib.check(lib.capy_kmac_xof_batch_dev(d, n, keys.data_ptr(), klen, klen, msgs.data_ptr(), None, L, stride, 512,
+                                                   b"T", 1, out.data_ptr(), 64, None))
+            torch.cuda.synchronize()
+            outs.append(out)
+        assert torch.equal(outs[0], outs[1])
+        ho, hk = bytes(outs[1].cpu().numpy()), bytes(keys.cpu().numpy())
+        for i in (0, 32, n // 2, n - 1):
+            m = bytes(msgs[i * stride:i * stride + L].cpu().numpy())
+            assert ho[64 * i:64 * i + 64] == O.kmac_xof(hk[klen * i:klen * (i + 1)], m, 512, b"T", d), (d, i)
+
+
 def test_device_fill_equals_host_harness_prng(capy, sponge_lanes):
     """capy_fill_random_dev and capycrypt_amd.harness_prng produce the same stream (any shard's inputs
     can be regenerated on either side)."""
