@@ -53,7 +53,8 @@ void *workspace(hipStream_t stream, WsSlot slot, size_t bytes);  // nullptr on a
 // packed buffer is copied as is; otherwise it is re-laid out so that every message starts on a
 // 16-byte boundary (the kernels' coalesced fast path needs 8-byte aligned message starts).
 struct PackedBatch {
-    DevBuf msgs, starts, lens;           // device: bytes, n+1 starts, n lengths
+    DevBuf msgs, starts, lens, order;    // device: bytes, n+1 starts, n lengths, processing order (ragged only)
+    bool has_order = false;
     std::vector<uint64_t> h_starts, h_lens;
     uint64_t total = 0;
     bool repacked = false;

@@ -364,6 +364,7 @@ static void body_args(SpongeParams &p, const MsgView &m)
     p.lens = m.lens;
     p.uniform_len = m.uniform_len;
     p.msg_stride = m.msg_stride;
+    p.order = m.order;
 }
 
 // Stage the (D224-only) raw prefix bytes with the stream-ordered allocator, launch, release.
@@ -583,6 +584,7 @@ int symmetric_crypt_dev(bool encrypt, int d, size_t n, const uint8_t *keka, size
         fp.msgs = const_cast<uint8_t *>(m.msgs);
         fp.offsets = m.offsets;
         fp.lens = m.lens;
+        fp.order = m.order;
         fp.msg_stride = m.msg_stride;
         fp.uniform_len = m.uniform_len;
         fp.tag_stride = tag_len;
@@ -687,6 +689,17 @@ int PackedBatch::upload(size_t n, const uint8_t *host_msgs, const uint64_t *host
     for (size_t i = 0; i < n && uniform; i++)
         uniform = h_lens[i] == uniform_len && h_starts[i] == i * uniform_stride;
     if ((uniform_stride & 7) || uniform_stride < uniform_len) uniform = false;
+    // Ragged batch: process the items longest-first.  All lanes of a wave run until the wave's longest message is
+    // done, so grouping similar lengths removes the idle lanes (and the longest waves start first).
+    has_order = !uniform && n >= 128 && n <= 0xffffffffULL && !(g_debug_flags.load() & 4);  // debug bit 2: A/B switch
+    std::vector<uint32_t> h_order;
+    if (has_order) {
+        h_order.resize(n);
+        for (size_t i = 0; i < n; i++) h_order[i] = (uint32_t)i;
+        std::stable_sort(h_order.begin(), h_order.end(), [&](uint32_t a, uint32_t b) { return h_lens[a] > h_lens[b]; });
+        CAPY_HIP(order.alloc(n * 4));
+        CAPY_HIP(hipMemcpy(order.p, h_order.data(), n * 4, hipMemcpyHostToDevice));
+    }
     CAPY_HIP(msgs.alloc(total + 16));
     CAPY_HIP(starts.alloc((n + 1) * 8));
     CAPY_HIP(lens.alloc((n ? n : 1) * 8));
@@ -721,6 +734,7 @@ MsgView view_of(const PackedBatch &b)
     } else {
         m.offsets = b.starts.as<uint64_t>();
         m.lens = b.lens.as<uint64_t>();
+        if (b.has_order) m.order = b.order.as<uint32_t>();
     }
     return m;
 }

@@ -38,6 +38,7 @@ struct FusedParams {
     uint64_t tag_stride;
     uint32_t tag_len;
     uint32_t decrypt;
+    const uint32_t *order;  // optional processing order, see SpongeParams::order
     uint64_t n;
 };
 
@@ -54,8 +55,9 @@ __global__ __launch_bounds__(64) void sponge_fused_crypt_kernel(const FusedParam
     const uint32_t lane = threadIdx.x;
     const uint32_t h = lane & 1, role = (lane >> 1) & 1, q = lane >> 2;  // role 0 = tag sponge, 1 = keystream sponge
     const uint32_t hmask = 0u - h;
-    const uint64_t item = (uint64_t)blockIdx.x * NIT + q;
-    const bool active = item < fp.n;
+    const uint64_t slot = (uint64_t)blockIdx.x * NIT + q;
+    const bool active = slot < fp.n;
+    const uint64_t item = active ? (fp.order ? (uint64_t)fp.order[slot] : slot) : fp.n;
 
     // Both sponges are described with the generic stream machinery (sponge_params.h): the tag sponge absorbs
     // head || msg || 00 01 04 || pad, the keystream sponge absorbs head || 00 01 04 || pad.
@@ -120,7 +122,8 @@ __global__ __launch_bounds__(64) void sponge_fused_crypt_kernel(const FusedParam
 
     // ---- full blocks, one pass
     if (lane < NIT) {
-        const uint64_t it = (uint64_t)blockIdx.x * NIT + lane;
+        const uint64_t sl = (uint64_t)blockIdx.x * NIT + lane;
+        const uint64_t it = sl < fp.n ? (fp.order ? (uint64_t)fp.order[sl] : sl) : fp.n;
         uint64_t base = 0;
         uint32_t nf = 0;
         if (it < fp.n) {

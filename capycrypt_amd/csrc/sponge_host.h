@@ -10,6 +10,7 @@ struct MsgView {
     const uint64_t *offsets = nullptr;  // n+1 starts (or null: uniform)
     const uint64_t *lens = nullptr;     // optional n lengths (re-packed batches)
     uint64_t uniform_len = 0, msg_stride = 0;
+    const uint32_t *order = nullptr;  // optional processing order (SpongeParams::order)
     bool aligned8 = false;  // every message start is known to be 8-byte aligned
 };
 

@@ -72,8 +72,9 @@ __global__ __launch_bounds__(64, FULLCHIP ? CAPY_FULLCHIP_WAVES : 2) void sponge
 
     const uint32_t lane = threadIdx.x;
     const uint64_t item0 = (uint64_t)blockIdx.x * 64;
-    const uint64_t item = item0 + lane;
-    const bool active = item < p.n && (p.mask == nullptr || p.mask[item] != 0);
+    const bool in_range = item0 + lane < p.n;
+    const uint64_t item = in_range ? (p.order ? (uint64_t)p.order[item0 + lane] : item0 + lane) : p.n;
+    const bool active = in_range && (p.mask == nullptr || p.mask[item] != 0);
 
     ItemCtx c;
     c.key = nullptr;
@@ -106,7 +107,8 @@ __global__ __launch_bounds__(64, FULLCHIP ? CAPY_FULLCHIP_WAVES : 2) void sponge
 
     // Wave-uniform fast addressing: a full wave of equally long, equally strided, 8-byte aligned messages whose
     // 64 blocks sit within 4 GiB of the wave's first message.
-    const bool uniform = !(p.debug_flags & 1) && p.offsets == nullptr && p.mask == nullptr && item0 + 64 <= p.n && grid_aligned &&
+    const bool uniform = !(p.debug_flags & 1) && p.offsets == nullptr && p.mask == nullptr && p.order == nullptr && item0 + 64 <= p.n &&
+                         grid_aligned &&
                          (((uintptr_t)p.msgs | p.msg_stride) & 7) == 0 && p.msg_stride * 64 < 0xfff00000ULL;
     const uint8_t *wave_base = p.msgs + item0 * p.msg_stride;  // SGPR pair
 

@@ -115,8 +115,10 @@ __global__ __launch_bounds__(64) void sponge_kernel_k2(const SpongeParams p)
     const uint32_t lane = threadIdx.x;
     const uint32_t h = lane & 1, j = lane >> 1;
     const uint32_t hmask = 0u - h;
-    const uint64_t item = (uint64_t)blockIdx.x * NSP + j;
-    const bool active = item < p.n && (p.mask == nullptr || p.mask[item] != 0);
+    const uint64_t slot = (uint64_t)blockIdx.x * NSP + j;
+    const bool in_range = slot < p.n;
+    const uint64_t item = in_range ? (p.order ? (uint64_t)p.order[slot] : slot) : p.n;
+    const bool active = in_range && (p.mask == nullptr || p.mask[item] != 0);
 
     ItemCtx c;
     c.key = nullptr;

@@ -38,6 +38,9 @@ struct SpongeParams {
     uint64_t out_stride;
     uint32_t out_len;
     const int32_t *mask;  // optional: only items with mask[i] != 0 are processed
+    // optional processing order (ragged batches): slot k of the grid works on item order[k].  The launcher sorts by
+    // length so that the lanes of a wave finish together; outputs stay at the item's own index.
+    const uint32_t *order;
     uint32_t debug_flags;  // bit 0: do not use the wave-uniform addressing path (A/B measurements)
     // resume (one-lane digest kernel only): the first resume_blocks blocks were absorbed by sponge_mixed_kernel,
     // whose states sit word-major in resume_state[25][resume_pad]; only the tail blocks and the squeeze remain
