@@ -346,6 +346,30 @@ static int launch_sponge(int rw, const SpongeParams &p, hipStream_t s)
         if (m < 0) return m;
         if (m > 0) return CAPY_OK;
     }
+    // Wave quantisation between one and two one-lane waves per SIMD: a uniform batch of 64 S + rem sponges would run
+    // at the two-waves-per-SIMD time (1.96x) although most SIMDs hold one wave.  Launch the first 64 S on their own
+    // (1.0x) and the remainder with whatever suits its size (two-lane 0.68x, rotating schedule 0.8-0.92x).
+    if (forced == 0 && !p.offsets && !p.mask && !p.order && p.n > 64 * simds && p.n < 128 * simds) {
+        auto subrange = [&](uint64_t first, uint64_t count) {
+            SpongeParams r = p;
+            r.msgs = p.msgs ? p.msgs + first * p.msg_stride : nullptr;
+            r.keys = p.keys ? p.keys + first * p.key_stride : nullptr;
+            r.out = p.out ? p.out + first * p.out_stride : nullptr;
+            r.n = count;
+            return r;
+        };
+        const uint64_t head_n = 64 * simds;
+        const SpongeParams tail = subrange(head_n, p.n - head_n);
+        MixedPlan mp;
+        if (tail.n <= 32 * simds || (g_mixed_enabled.load() && mixed_plan(rw, tail, false, mp))) {
+            SpongeParams head = subrange(0, head_n);
+            head.debug_flags = q.debug_flags;
+            e = launch_sponge_k1_lat(rw, (int)p.out_mode, head, s);
+            if (e == hipErrorInvalidValue) return fail(CAPY_ERR_ARG, "internal: no kernel instance for this rate / mode");
+            CAPY_HIP(e);
+            return launch_sponge(rw, tail, s);
+        }
+    }
     if (forced == 2 || ((forced == 0 || forced == 3) && p.n <= 32 * simds))
         e = launch_sponge_k2(rw, (int)p.out_mode, p2, s);
     else if (p.n > 128 * simds && !(q.debug_flags & 2))  // debug bit 1: latency-tuned instance at every size (A/B)

@@ -300,7 +300,7 @@ def _dev_rand(nbytes, seed):
     return t
 
 
-@pytest.mark.parametrize("n,L", [(100, 1000), (4100, 2731 * 8), (140000, 304)])
+@pytest.mark.parametrize("n,L", [(100, 1000), (4100, 2731 * 8), (70000, 1000), (140000, 304)])
 def test_dev_api_uniform_batches_all_instances(capy, O, n, L):
     """Uniformly strided device batches (the bench layout) through sha3 / kmac_xof / sha3_encrypt / sha3_decrypt:
     n = 100 and 4100 use the small-batch kernels (two-lane or latency-tuned, fused encrypt), n = 140000 the
@@ -460,6 +460,46 @@ def test_kmac_rotating_schedule_with_per_item_keys(capy, O, sponge_lanes):
         for i in (0, 32, n // 2, n - 1):
             m = bytes(msgs[i * stride:i * stride + L].cpu().numpy())
             assert ho[64 * i:64 * i + 64] == O.kmac_xof(hk[klen * i:klen * (i + 1)], m, 512, b"T", d), (d, i)
+
+
+def test_wave_quantisation_split_matches_one_lane(capy, O, sponge_lanes):
+    """Uniform batches between 64 and 128 sponges per SIMD are launched as a full-chip head + a remainder
+    (sponge.hip: launch_sponge).  Automatic choice vs forced one-lane kernel: digests, KMAC outputs and the two-pass
+    encrypt (keystream XOR mode) must agree for every item, and with the oracle for a sample."""
+    import torch
+
+    from capycrypt_amd import _lib
+
+    if sponge_lanes != 1:
+        pytest.skip("sets the kernel choice itself")
+    lib = _lib.lib()
+    n, L, stride = 70003, 1000, 1008
+    msgs = _dev_rand(n * stride, 41)
+    keys = _dev_rand(n * 64, 42)
+    zs = _dev_rand(n * 512, 43)
+    res = []
+    for lanes in (1, 0):
+        _lib.check(lib.capy_set_sponge_lanes(lanes))
+        dig = torch.zeros(n * 32, dtype=torch.uint8, device="cuda")
+        out = torch.zeros(n * 64, dtype=torch.uint8, device="cuda")
+        work = msgs.clone()
+        tags = torch.zeros(n * 64, dtype=torch.uint8, device="cuda")
+        _lib.check(lib.capy_sha3_batch_dev(256, n, msgs.data_ptr(), None, L, stride, dig.data_ptr(), None))
+        _lib.check(lib.capy_kmac_xof_batch_dev(512, n, keys.data_ptr(), 64, 64, msgs.data_ptr(), None, L, stride, 512,
+                                               b"T", 1, out.data_ptr(), 64, None))
+        _lib.check(lib.capy_sha3_encrypt_batch_dev(512, n, keys.data_ptr(), 64, zs.data_ptr(), work.data_ptr(), None, L,
+                                                   stride, tags.data_ptr(), None))
+        torch.cuda.synchronize()
+        res.append((dig, out, work, tags))
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b)
+    host, hk, hz = bytes(msgs.cpu().numpy()), bytes(keys.cpu().numpy()), bytes(zs.cpu().numpy())
+    hd, hc, ht = (bytes(t.cpu().numpy()) for t in (res[1][0], res[1][2], res[1][3]))
+    for i in (0, 65535, 65536, 65537, n - 1):
+        m = host[i * stride:i * stride + L]
+        assert hd[32 * i:32 * i + 32] == O.sha3(m, 256), i
+        ect, etag = O.sha3_encrypt(hk[64 * i:64 * i + 64], hz[512 * i:512 * i + 512], m, 512)
+        assert hc[i * stride:i * stride + L] == ect and ht[64 * i:64 * i + 64] == etag, i
 
 
 def test_device_fill_equals_host_harness_prng(capy, sponge_lanes):
