@@ -206,7 +206,8 @@ static const size_t FUSED_MAX_ITEMS = 16384;  // 16 items per wave x one wave pe
 // Kernel choice by batch size relative to the device's SIMD count S (1024 on MI355X; measured crossovers, profiles/):
 //   n <= 32 S        two lanes per sponge, at most one wave per SIMD
 //   32 S < n < 64 S  rotating one-lane / two-lane schedule when eligible (sponge_mixed.h), else one lane
-//   n <= 128 S       one lane per sponge, latency-tuned instance
+//   n <= 128 S       one lane per sponge, latency-tuned instance; uniform batches above 64 S are launched as a
+//                    head of 64 S + a remainder that follows the rules above (wave quantisation)
 //   above            one lane per sponge, issue-tuned instance (> 2 waves per SIMD)
 
 static std::atomic<bool> g_mixed_enabled{true};
