@@ -254,7 +254,7 @@ static bool mixed_plan(int rw, const SpongeParams &p, bool forced, MixedPlan &m)
     if ((((uintptr_t)p.msgs | p.msg_stride) & 7) || p.msg_stride * 64 >= 0xfff00000ULL || p.msg_stride < p.uniform_len) return false;
     const uint64_t S = device_simds(), n = p.n;
     m.nf = p.uniform_len / rb;
-    if (n <= 32 * S || n >= 64 * S || m.nf < 1024) return false;
+    if (n <= 32 * S || n >= 64 * S || m.nf < 256) return false;  // below ~35 KB per message the phase launches eat the gain
     const uint64_t spare = 64 * S - n;        // sponges' worth of idle lanes under the one-lane kernel
     uint64_t P = (n + spare - 1) / spare;     // phases = groups
     if (P < 2) P = 2;
