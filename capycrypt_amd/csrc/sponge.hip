@@ -689,6 +689,7 @@ int PackedBatch::upload(size_t n, const uint8_t *host_msgs, const uint64_t *host
         if ((host_offsets[i] - host_offsets[0]) & 7) aligned = false;
         h_lens[i] = host_offsets[i + 1] - host_offsets[i];
     }
+    if (!host_msgs && n && host_offsets[n] != host_offsets[0]) return fail(CAPY_ERR_ARG, "null message buffer");
     repacked = !aligned;
     std::vector<uint8_t> staging;
     const uint8_t *src = host_msgs ? host_msgs + (n ? host_offsets[0] : 0) : nullptr;
