@@ -187,6 +187,85 @@ class Message:
             raise OperationError("KeyDecryptionError")
 
 
+    # ---------------- on-disk format (src/lib.rs:63-108: #[derive(Serialize, Deserialize)] + serde_json)
+    # serde_json's derive layout is fixed by the reference's own struct: fields in declaration order, Vec<u8> as an
+    # array of numbers, Option as null or the value, the unit-variant enum SecParam as its variant name.  Exact for
+    # the sponge-side fields (msg, d, sym_nonce, digest, kem_ciphertext).  `asym_nonce` (ExtendedPoint) and `sig.z`
+    # (Scalar) belong to the absent curve crate, whose serde layout cannot be checked here: values read from a file
+    # are kept verbatim and written back unchanged; values produced here are written as byte arrays (affine x||y,
+    # big-endian z) under the same keys and flagged by `capyhip_curve_layout`, which the reference would reject.
+    def to_json(self):
+        import json
+
+        def arr(b):
+            return None if b is None else list(bytes(b))
+
+        doc = {
+            "msg": arr(self.msg),
+            "d": None if self.d is None else "D%d" % int(self.d),
+            "sym_nonce": arr(self.sym_nonce),
+            "asym_nonce": None,
+            "digest": arr(self.digest),
+            "sig": None,
+            "kem_ciphertext": arr(self.kem_ciphertext),
+        }
+        foreign = getattr(self, "_foreign", {})
+        ours = False
+        if "asym_nonce" in foreign:
+            doc["asym_nonce"] = foreign["asym_nonce"]
+        elif self.asym_nonce is not None:
+            doc["asym_nonce"] = arr(self.asym_nonce)
+            ours = True
+        if "sig" in foreign:
+            doc["sig"] = foreign["sig"]
+        elif self.sig is not None:
+            doc["sig"] = {"h": arr(self.sig.h), "z": arr(self.sig.z)}
+            ours = True
+        if ours:
+            doc["capyhip_curve_layout"] = "bytes"
+        return json.dumps(doc, separators=(",", ":"))
+
+    @staticmethod
+    def from_json(text):
+        import json
+
+        doc = json.loads(text)
+        m = Message(bytes(doc["msg"]))
+        if doc.get("d") is not None:
+            name = doc["d"]
+            if not (isinstance(name, str) and name[:1] == "D" and name[1:].isdigit()):
+                raise ValueError("d: expected a SecParam variant name")
+            m.d = SecParam.try_from(int(name[1:]))
+        m.sym_nonce = None if doc.get("sym_nonce") is None else bytes(doc["sym_nonce"])
+        m.digest = bytes(doc.get("digest") or [])
+        kc = doc.get("kem_ciphertext")
+        m.kem_ciphertext = None if kc is None else bytes(kc)
+        ours = doc.get("capyhip_curve_layout") == "bytes"
+        m._foreign = {}
+        if doc.get("asym_nonce") is not None:
+            if ours:
+                m.asym_nonce = bytes(doc["asym_nonce"])
+            else:
+                m._foreign["asym_nonce"] = doc["asym_nonce"]  # the curve crate's layout: kept verbatim
+        if doc.get("sig") is not None:
+            if ours:
+                m.sig = Signature(bytes(doc["sig"]["h"]), bytes(doc["sig"]["z"]))
+            else:
+                m._foreign["sig"] = doc["sig"]
+        return m
+
+    def write_to_file(self, filename):
+        """src/lib.rs:96-99"""
+        with open(filename, "w") as f:
+            f.write(self.to_json())
+
+    @staticmethod
+    def read_from_file(filename):
+        """src/lib.rs:101-108"""
+        with open(filename) as f:
+            return Message.from_json(f.read())
+
+
 def _append_shake_padding(msg, d):
     """The caller-visible mutation of shake(): suffix byte, then pad10*1 only when unaligned."""
     msg.append(0x86 if 136 - len(msg) % 136 == 1 else 0x06)

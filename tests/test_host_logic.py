@@ -110,3 +110,41 @@ def test_harness_prng_reference_values_and_offsets():
     whole = H.fill(0xCA9C0001, 4096)
     for off, n in ((0, 1), (3, 17), (8, 8), (1001, 2000), (4090, 6)):
         assert H.fill(0xCA9C0001, n, off) == whole[off:off + n]
+
+
+def test_message_json_layout_is_serde_jsons_for_the_sponge_side_fields(tmp_path):
+    """src/lib.rs:63-108: serde_json of the derive layout.  A document written the way serde_json writes the reference's
+    struct (field order, Vec<u8> as number arrays, Option as null, SecParam by variant name) must load, round-trip
+    byte-identically for the sponge-side fields, and keep curve-typed values of unknown layout verbatim."""
+    import json
+
+    from capycrypt_amd.message import Message, SecParam
+
+    ref_doc = ('{"msg":[1,2,255],"d":"D512","sym_nonce":[9,8,7],"asym_nonce":null,"digest":[0,17],"sig":null,'
+               '"kem_ciphertext":[]}')
+    m = Message.from_json(ref_doc)
+    assert bytes(m.msg) == b"\x01\x02\xff" and m.d == SecParam.D512 and m.sym_nonce == b"\x09\x08\x07"
+    assert m.digest == b"\x00\x11" and m.sig is None and m.asym_nonce is None and m.kem_ciphertext == b""
+    assert m.to_json() == ref_doc
+    fresh = Message(b"abc")  # Message::new: d None, nonces None, digest empty, kem_ciphertext Some(vec![])
+    assert fresh.to_json() == ('{"msg":[97,98,99],"d":null,"sym_nonce":null,"asym_nonce":null,"digest":[],"sig":null,'
+                               '"kem_ciphertext":[]}')
+    foreign = json.loads(ref_doc)
+    foreign["sig"] = {"h": [1, 2], "z": {"val": "00ff"}}  # whatever the curve crate writes: opaque here
+    foreign["asym_nonce"] = {"X": [1], "Y": [2], "Z": [3], "T": [4]}
+    m2 = Message.from_json(json.dumps(foreign))
+    assert json.loads(m2.to_json()) == foreign
+    p = tmp_path / "m.json"
+    m.write_to_file(str(p))
+    assert Message.read_from_file(str(p)).to_json() == ref_doc
+    from capycrypt_amd.message import Signature
+
+    own = Message(b"x")
+    own.sig = Signature(bytes(range(56)), bytes(range(56, 112)))
+    own.asym_nonce = bytes(112)
+    back = Message.from_json(own.to_json())
+    assert back.sig.h == own.sig.h and back.sig.z == own.sig.z and back.asym_nonce == own.asym_nonce
+    import pytest
+
+    with pytest.raises(Exception):
+        Message.from_json(ref_doc.replace('"D512"', '"D500"'))
