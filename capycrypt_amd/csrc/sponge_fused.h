@@ -155,13 +155,13 @@ __global__ __launch_bounds__(64) void sponge_fused_crypt_kernel(const FusedParam
             lim[k] = in ? s_nfull[in ? m : 0] : 0;
             dst[k] = reinterpret_cast<uint8_t *>(in ? s_base[in ? m : 0] : 0) + 8 * w;
         }
-        uint8_t *safe = fp.msgs;
         uint64_t pf[NLOAD];
         auto coop_load = [&](uint32_t t) {
 #pragma unroll
             for (int k = 0; k < NLOAD; k++) {
-                const uint8_t *src = t < lim[k] ? dst[k] + (uint64_t)t * RB : safe;
-                pf[k] = *reinterpret_cast<const uint64_t *>(src);
+                uint64_t v = 0;
+                if (t < lim[k]) v = *reinterpret_cast<const uint64_t *>(dst[k] + (uint64_t)t * RB);
+                pf[k] = v;
             }
         };
         coop_load(0);

@@ -212,13 +212,14 @@ __global__ __launch_bounds__(64, FULLCHIP ? CAPY_FULLCHIP_WAVES : 2) void sponge
                     lim[k] = s_nfull[m];
                     src[k] = reinterpret_cast<const uint8_t *>(s_base[m]) + 8 * w;
                 }
-                const uint8_t *safe = p.msgs;  // readable whenever any message of this wave has a full block
+                // lanes whose message has run out do not load (a shared fallback address would be one hot L2 line)
                 uint64_t pf[RW];
                 auto coop_load = [&](uint32_t t) {
 #pragma unroll
                     for (int k = 0; k < RW; k++) {
-                        const uint8_t *q = t < lim[k] ? src[k] + (uint64_t)t * RB : safe;
-                        pf[k] = *reinterpret_cast<const uint64_t *>(q);
+                        uint64_t v = 0;
+                        if (t < lim[k]) v = *reinterpret_cast<const uint64_t *>(src[k] + (uint64_t)t * RB);
+                        pf[k] = v;
                     }
                 };
                 coop_load(0);
@@ -244,9 +245,10 @@ __global__ __launch_bounds__(64, FULLCHIP ? CAPY_FULLCHIP_WAVES : 2) void sponge
                 for (int k = 0; k < RW; k++) {
                     const uint32_t i = k * 64 + lane;
                     const uint32_t m = i / RW, w = i - m * RW;
-                    const uint8_t *q = t < s_nfull[m] ? reinterpret_cast<const uint8_t *>(s_base[m]) + (uint64_t)t * RB + 8 * w
-                                                      : p.msgs;
-                    s_stage[i] = *reinterpret_cast<const uint64_t *>(q);
+                    uint64_t v = 0;
+                    if (t < s_nfull[m])
+                        v = *reinterpret_cast<const uint64_t *>(reinterpret_cast<const uint8_t *>(s_base[m]) + (uint64_t)t * RB + 8 * w);
+                    s_stage[i] = v;
                 }
                 __syncthreads();
                 if (t < nfull) {
@@ -333,9 +335,10 @@ __global__ __launch_bounds__(64, FULLCHIP ? CAPY_FULLCHIP_WAVES : 2) void sponge
                 for (int k = 0; k < RW; k++) {
                     const uint32_t i = k * 64 + lane;
                     const uint32_t m = i / RW, w = i - m * RW;
-                    const uint8_t *q = t < s_nfull[m] ? reinterpret_cast<const uint8_t *>(s_base[m]) + (uint64_t)t * RB + 8 * w
-                                                      : p.msgs;
-                    s_stage[i] = *reinterpret_cast<const uint64_t *>(q);
+                    uint64_t v = 0;
+                    if (t < s_nfull[m])
+                        v = *reinterpret_cast<const uint64_t *>(reinterpret_cast<const uint8_t *>(s_base[m]) + (uint64_t)t * RB + 8 * w);
+                    s_stage[i] = v;
                 }
                 __syncthreads();
                 if (t < xfull) {
