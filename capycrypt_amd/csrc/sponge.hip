@@ -333,12 +333,22 @@ static int sponge_plan(int rw, const SpongeParams &p, int *phases)
     return p.n > 128 * simds ? 4 : 1;
 }
 
+static int device_order(const uint64_t *offsets, const uint64_t *lens, size_t n, hipStream_t s, const uint32_t **out);
+static bool wants_device_order(const uint64_t *offsets, const uint32_t *order, uint64_t n)
+{
+    return offsets && !order && n >= 128 && n <= 0xffffffffULL && !(g_debug_flags.load() & 4);
+}
+
 static int launch_sponge(int rw, const SpongeParams &p, hipStream_t s)
 {
     if (p.n == 0) return CAPY_OK;
     const int forced = g_lanes_per_sponge.load();
     SpongeParams q = p;
     q.debug_flags = g_debug_flags.load();
+    if (wants_device_order(p.offsets, p.order, p.n)) {  // ragged device batch: longest first
+        const int rc = device_order(p.offsets, p.lens, p.n, s, &q.order);
+        if (rc) return rc;
+    }
     const SpongeParams &p2 = q;
     hipError_t e;
     const size_t simds = device_simds();
@@ -516,6 +526,62 @@ void tag_compare_launch(const uint8_t *a, uint64_t a_stride, const uint8_t *b, u
                        b_stride, status, (uint64_t)n);
 }
 
+// ---- longest-first processing order for ragged DEVICE batches (host batches are sorted on upload): a counting sort
+// by a 512-step logarithmic length scale; the order inside a bucket is arbitrary, results do not depend on it.
+constexpr int ORDER_BUCKETS = 512;
+__device__ __forceinline__ uint32_t len_bucket_desc(uint64_t len)
+{
+    uint32_t b;
+    if (len < 8) {
+        b = (uint32_t)len;
+    } else {
+        const int e = 63 - __clzll((long long)len);  // >= 3
+        b = (uint32_t)(e - 2) * 8 + (uint32_t)((len >> (e - 3)) & 7);
+    }
+    return ORDER_BUCKETS - 1 - b;  // b <= 495
+}
+__device__ __forceinline__ uint64_t item_len(const uint64_t *offsets, const uint64_t *lens, uint64_t i)
+{
+    return lens ? lens[i] : offsets[i + 1] - offsets[i];
+}
+__global__ void order_hist_kernel(const uint64_t *offsets, const uint64_t *lens, uint64_t n, uint32_t *hist)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) atomicAdd(&hist[len_bucket_desc(item_len(offsets, lens, i))], 1u);
+}
+__global__ void order_scan_kernel(uint32_t *hist)  // one block of ORDER_BUCKETS threads: counts -> start cursors
+{
+    __shared__ uint32_t sh[ORDER_BUCKETS];
+    const uint32_t t = threadIdx.x;
+    sh[t] = hist[t];
+    __syncthreads();
+    for (uint32_t off = 1; off < ORDER_BUCKETS; off <<= 1) {
+        const uint32_t v = t >= off ? sh[t - off] : 0;
+        __syncthreads();
+        sh[t] += v;
+        __syncthreads();
+    }
+    hist[t] = sh[t] - hist[t];  // exclusive
+}
+__global__ void order_scatter_kernel(const uint64_t *offsets, const uint64_t *lens, uint64_t n, uint32_t *cursor,
+                                     uint32_t *order)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) order[atomicAdd(&cursor[len_bucket_desc(item_len(offsets, lens, i))], 1u)] = (uint32_t)i;
+}
+static int device_order(const uint64_t *offsets, const uint64_t *lens, size_t n, hipStream_t s, const uint32_t **out)
+{
+    CAPY_WS(order, uint32_t *, s, WS_ORDER, n * 4);
+    CAPY_WS(hist, uint32_t *, s, WS_HIST, ORDER_BUCKETS * 4);
+    CAPY_HIP(hipMemsetAsync(hist, 0, ORDER_BUCKETS * 4, s));
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    hipLaunchKernelGGL(order_hist_kernel, grid, block, 0, s, offsets, lens, (uint64_t)n, hist);
+    hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(ORDER_BUCKETS), 0, s, hist);
+    hipLaunchKernelGGL(order_scatter_kernel, grid, block, 0, s, offsets, lens, (uint64_t)n, hist, order);
+    CAPY_HIP(hipGetLastError());
+    *out = order;
+    return CAPY_OK;
+}
 // SplitMix64 counter-mode fill (harness PRNG)
 __global__ void fill_random_kernel(uint64_t *dst, uint64_t nwords, uint64_t seed)
 {
@@ -610,6 +676,10 @@ int symmetric_crypt_dev(bool encrypt, int d, size_t n, const uint8_t *keka, size
         fp.offsets = m.offsets;
         fp.lens = m.lens;
         fp.order = m.order;
+        if (wants_device_order(m.offsets, m.order, n)) {
+            const int orc = device_order(m.offsets, m.lens, n, s, &fp.order);
+            if (orc) return orc;
+        }
         fp.msg_stride = m.msg_stride;
         fp.uniform_len = m.uniform_len;
         fp.tag_stride = tag_len;
