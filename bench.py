@@ -115,8 +115,24 @@ def cpu_baseline_ed448(seconds):
 
 def main():
     a = parse()
-    import torch
-    import torch.distributed as dist
+    # the first `import torch` on a fresh box pages the image in (minutes on a bad day): heartbeat on stderr
+    import threading
+
+    _done = threading.Event()
+
+    def _beat():
+        t0 = time.time()
+        while not _done.wait(30):
+            print("[bench] importing torch ... %d s" % (time.time() - t0), file=sys.stderr, flush=True)
+
+    _th = threading.Thread(target=_beat, daemon=True)
+    _th.start()
+    try:
+        import torch
+        import torch.distributed as dist
+    finally:
+        _done.set()
+        _th.join()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
