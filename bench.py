@@ -20,6 +20,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MSG_BYTES = 5242880  # benches/benchmark_sha3.rs:17
+# Messages sit MSG_STRIDE apart in HBM: with a stride of exactly 5 MiB every in-flight 128-B line of the chip maps to
+# the same few L2 sets (fabric reads 1.41x the message bytes, profiles/r01_l2_set_aliasing.txt); one extra line of
+# padding per message spreads them (1.03x).  Speed is the same either way (the kernel is VALU-bound).
+MSG_STRIDE = MSG_BYTES + 128
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # Integer-VALU ceiling for keccak-f[1600] on MI355X, MEASURED (profiles/r01_keccak_loop_forms.txt): a
 # register-resident loop of nothing but permutations tops out at 10.68e9 permutations/s (16k waves, best loop
@@ -163,17 +167,17 @@ def main():
     # ---- synthetic inputs resident in HBM
     B = a.batch
     free, _total = torch.cuda.mem_get_info()
-    fit = int((free - (14 << 30)) // MSG_BYTES)  # leave room for the Ed448 leg (table scratch) and torch itself
+    fit = int((free - (14 << 30)) // MSG_STRIDE)  # leave room for the Ed448 leg (table scratch) and torch itself
     if B > fit:
         B = max(64, fit // 2048 * 2048)
     _lib.check(lib.capy_set_sponge_lanes(a.lanes))
-    msgs = torch.empty(B * MSG_BYTES, dtype=torch.uint8, device=dev)
+    msgs = torch.empty(B * MSG_STRIDE, dtype=torch.uint8, device=dev)
     digests = torch.empty(B * 32, dtype=torch.uint8, device=dev)
-    _lib.check(lib.capy_fill_random_dev(msgs.data_ptr(), B * MSG_BYTES, 0xCA9C0001 + rank, sp))
+    _lib.check(lib.capy_fill_random_dev(msgs.data_ptr(), B * MSG_STRIDE, 0xCA9C0001 + rank, sp))
     torch.cuda.synchronize()
 
     def step():
-        _lib.check(lib.capy_sha3_batch_dev(256, B, msgs.data_ptr(), None, MSG_BYTES, MSG_BYTES, digests.data_ptr(), sp))
+        _lib.check(lib.capy_sha3_batch_dev(256, B, msgs.data_ptr(), None, MSG_BYTES, MSG_STRIDE, digests.data_ptr(), sp))
 
     def barrier():
         torch.cuda.synchronize()
@@ -207,7 +211,7 @@ def main():
 
     dig = digests.cpu().numpy().tobytes()
     for i in sorted({0, B // 2, B - 1}):
-        m = msgs[i * MSG_BYTES:(i + 1) * MSG_BYTES].cpu().numpy().tobytes()
+        m = msgs[i * MSG_STRIDE:i * MSG_STRIDE + MSG_BYTES].cpu().numpy().tobytes()
         assert dig[32 * i:32 * i + 32] == hashlib.sha3_256(m).digest(), "digest %d mismatch" % i
 
     # ---- secondary: Ed448 variable-base scalar mults (config 4)
@@ -252,7 +256,7 @@ def main():
 
     # which kernel the library picked for this shape (one launch per step, or P phase launches of the mixed kernel)
     kind, phases = C.c_int(0), C.c_int(1)
-    _lib.check(lib.capy_sha3_launch_plan(256, B, MSG_BYTES, MSG_BYTES, C.byref(kind), C.byref(phases)))
+    _lib.check(lib.capy_sha3_launch_plan(256, B, MSG_BYTES, MSG_STRIDE, C.byref(kind), C.byref(phases)))
     kname = {1: "sponge_kernel<17, false, 0>", 2: "sponge_kernel_k2<17, 0>", 3: "sponge_mixed_kernel<17>",
              4: "sponge_kernel<17, true, 0>"}[kind.value]
     launches = phases.value
@@ -295,12 +299,13 @@ def main():
             "dtype": "u64",
             "data": "synthetic",
             "config": {"workload": "sha3_256_batch: %d x 5 MiB messages per GPU, resident in HBM" % B,
-                       "batch_per_gpu": B, "msg_bytes": MSG_BYTES,
+                       "batch_per_gpu": B, "msg_bytes": MSG_BYTES, "msg_stride": MSG_STRIDE,
                        "parallelism": "batch-sharded x%d, no collective" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_note": "bytes per launch from profiles/r01_pmc_summary.json (rocprofv3 PMC, x2 read "
-                                         "correction: upper bound for 8-B/lane loads); algorithmic per launch = %d"
+                         "traffic_note": "bytes per launch from profiles/r01_pmc_summary.json (rocprofv3 PMC: FETCH_SIZE x2 "
+                                         "= TCC_EA0_RDREQ x 128 B, all requests are 128-B; + WRITE_SIZE); "
+                                         "algorithmic per launch = %d"
                                          % algo_bytes,
                          "kernel": kname, "launches_per_step": launches, "kernel_ms": launch_ms,
                          "valu_ceiling_GBs": VALU_CEIL_GBS, "frac_of_valu_ceiling": achieved / VALU_CEIL_GBS},

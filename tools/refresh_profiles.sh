@@ -20,6 +20,8 @@ for C in "FETCH_SIZE" "WRITE_SIZE" \
 done
 B=$(python -c "import json;print(json.load(open('profiles/${R}_bench_line.json'))['config']['batch_per_gpu'])")
 CAPY_PMC_ITEMS=$B python tools/summarize_pmc.py profiles/${R}_pmc_summary.json $OUT/pmc_${R}_FETCH_SIZE $OUT/pmc_${R}_WRITE_SIZE $OUT/pmc_${R}_SQ_WAVES
+# the contract line last: bench.py reads the traffic figure from the summary written above
+python bench.py --steps 5 --warmup 1 > $OUT/bench.json 2> $OUT/bench.err && tail -1 $OUT/bench.json > profiles/${R}_bench_line.json
 python tools/bench_configs.py 2> /dev/null > $OUT/configs.jsonl && cp $OUT/configs.jsonl profiles/${R}_configs_2_to_5.jsonl
 python - <<PY
 import csv
