@@ -1,5 +1,5 @@
 import ctypes as C, sys, random, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import ed448_ref as E
 L=C.CDLL('/tmp/libed448host_asan.so')
 rng=random.Random(3)

@@ -1,7 +1,7 @@
 import ctypes, sys, os, random, hashlib
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import oracle.oracle as O
-O._SO = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'oracle', 'libcapyoracle_asan.so')
+O._SO = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), 'oracle', 'libcapyoracle_asan.so')
 O.build = lambda force=False: O._SO
 O._lib = None
 rng = random.Random(1)
