@@ -39,6 +39,79 @@ __global__ __launch_bounds__(64, CAPY_ED448_WAVES) void fb_kernel(uint64_t n, co
     pt_to_affine_bytes(out_xy + i * 112, fb_scalarmul(scalars_be + i * 56, gtab));
 }
 
+// Two items per lane sharing one inversion (pt_pair_to_affine_bytes): a wave takes 128 consecutive items, lane l the
+// items base + l and base + 64 + l.  The first result waits in LDS (one column per lane) while the second is computed
+// by the same loop body, so the code is not duplicated.  Used when the batch still fills the chip at half the waves.
+struct PtXYZ {
+    uint32_t w[48][64];  // X, Y, Z limbs x lanes
+};
+__device__ __forceinline__ void park_xyz(PtXYZ &s, const Pt &p)
+{
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        s.w[i][threadIdx.x] = p.X.l[i];
+        s.w[16 + i][threadIdx.x] = p.Y.l[i];
+        s.w[32 + i][threadIdx.x] = p.Z.l[i];
+    }
+}
+__device__ __forceinline__ Pt unpark_xyz(const PtXYZ &s)
+{
+    Pt p;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        p.X.l[i] = s.w[i][threadIdx.x];
+        p.Y.l[i] = s.w[16 + i][threadIdx.x];
+        p.Z.l[i] = s.w[32 + i][threadIdx.x];
+        p.T.l[i] = 0;
+    }
+    return p;
+}
+
+__global__ __launch_bounds__(64, CAPY_ED448_WAVES) void vb2_kernel(uint64_t n, const uint8_t *scalars_be, uint64_t scalar_stride,
+                                                 const uint8_t *points_xy, uint64_t point_stride, uint8_t *out_xy,
+                                                 uint32_t *table_ws)
+{
+    __shared__ PtXYZ parked;
+    const uint64_t base = (uint64_t)blockIdx.x * 128 + threadIdx.x;
+    if (base >= n) return;
+    Pt r = pt_identity();
+#pragma unroll 1
+    for (int j = 0; j < 2; j++) {
+        // the second item of a ragged last wave repeats the first (its result is not written)
+        const uint64_t i = (j == 1 && base + 64 < n) ? base + 64 : base;
+        const Pt P = pt_from_affine_bytes(points_xy + i * point_stride);
+        r = vb_scalarmul(scalars_be + i * scalar_stride, P, table_ws + i * VB_TABLE_DWORDS);
+        if (j == 0) park_xyz(parked, r);
+    }
+    const Pt r0 = unpark_xyz(parked);
+    if (base + 64 < n) {
+        pt_pair_to_affine_bytes(out_xy + base * 112, out_xy + (base + 64) * 112, r0, r);
+    } else {
+        pt_to_affine_bytes(out_xy + base * 112, r0);
+    }
+}
+
+__global__ __launch_bounds__(64, CAPY_ED448_WAVES) void fb2_kernel(uint64_t n, const uint8_t *scalars_be, uint8_t *out_xy,
+                                                 const uint32_t *gtab)
+{
+    __shared__ PtXYZ parked;
+    const uint64_t base = (uint64_t)blockIdx.x * 128 + threadIdx.x;
+    if (base >= n) return;
+    Pt r = pt_identity();
+#pragma unroll 1
+    for (int j = 0; j < 2; j++) {
+        const uint64_t i = (j == 1 && base + 64 < n) ? base + 64 : base;
+        r = fb_scalarmul(scalars_be + i * 56, gtab);
+        if (j == 0) park_xyz(parked, r);
+    }
+    const Pt r0 = unpark_xyz(parked);
+    if (base + 64 < n) {
+        pt_pair_to_affine_bytes(out_xy + base * 112, out_xy + (base + 64) * 112, r0, r);
+    } else {
+        pt_to_affine_bytes(out_xy + base * 112, r0);
+    }
+}
+
 __global__ __launch_bounds__(64, CAPY_ED448_WAVES) void dsm_kernel(uint64_t n, const uint8_t *a_be, const uint8_t *b_be,
                                                  const uint8_t *points_xy, uint8_t *out_xy, uint32_t *table_ws,
                                                  const uint32_t *gtab)
@@ -97,13 +170,35 @@ __global__ void sc_sign_z_kernel(uint64_t n, const uint8_t *k_be, const uint8_t 
 // ------------------------------------------------------------------ launchers
 static inline dim3 grid64(size_t n) { return dim3((unsigned)((n + 63) / 64)); }
 
+// Two items per lane (one shared inversion) once the batch still gives every SIMD two waves at half the wave count:
+// 2 waves x 4 SIMDs x CUs x 128 items = 262 144 on MI355X.  CAPY_ED448_PAIR=0/1 forces it off / on (A/B).
+static size_t pair_min_items()
+{
+    static const size_t v = [] {
+        const char *e = getenv("CAPY_ED448_PAIR");
+        if (e && e[0] == '0') return (size_t)-1;
+        if (e && e[0] == '1') return (size_t)128;
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+        return (size_t)cus * 4 * 2 * 128;
+    }();
+    return v;
+}
+
 static int vb_launch(size_t n, const uint8_t *scalars, uint64_t scalar_stride, const uint8_t *points,
                      uint64_t point_stride, uint8_t *out, hipStream_t s)
 {
     if (!n) return CAPY_OK;
     CAPY_WS(tab, uint32_t *, s, WS_TABLE, n * VB_TABLE_DWORDS * 4);
-    hipLaunchKernelGGL(vb_kernel, grid64(n), dim3(64), 0, s, (uint64_t)n, scalars, scalar_stride, points, point_stride,
-                       out, tab);
+    if (n >= pair_min_items()) {
+        hipLaunchKernelGGL(vb2_kernel, dim3((unsigned)((n + 127) / 128)), dim3(64), 0, s, (uint64_t)n, scalars, scalar_stride,
+                           points, point_stride, out, tab);
+    } else {
+        hipLaunchKernelGGL(vb_kernel, grid64(n), dim3(64), 0, s, (uint64_t)n, scalars, scalar_stride, points, point_stride,
+                           out, tab);
+    }
     CAPY_HIP(hipGetLastError());
     return CAPY_OK;
 }
@@ -167,7 +262,10 @@ static int fb_launch(size_t n, const uint8_t *scalars, uint8_t *out, hipStream_t
     const uint32_t *gt = nullptr;
     int rc = ensure_gtab(&gt);
     if (rc) return rc;
-    hipLaunchKernelGGL(fb_kernel, grid64(n), dim3(64), 0, s, (uint64_t)n, scalars, out, gt);
+    if (n >= pair_min_items())
+        hipLaunchKernelGGL(fb2_kernel, dim3((unsigned)((n + 127) / 128)), dim3(64), 0, s, (uint64_t)n, scalars, out, gt);
+    else
+        hipLaunchKernelGGL(fb_kernel, grid64(n), dim3(64), 0, s, (uint64_t)n, scalars, out, gt);
     CAPY_HIP(hipGetLastError());
     return CAPY_OK;
 }

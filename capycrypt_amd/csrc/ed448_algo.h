@@ -76,7 +76,7 @@ CAPY_HD inline Pt vb_add_digit(const Pt &acc, const uint32_t *tab, int digit)
 }
 
 // [k]P, k = 56 big-endian bytes (all 448 bits used), tab = VB_TABLE_DWORDS of scratch for this item.
-CAPY_HD inline Pt vb_scalarmul(const uint8_t *k_be, const Pt &P, uint32_t *tab)
+CAPY_HD_INLINE Pt vb_scalarmul(const uint8_t *k_be, const Pt &P, uint32_t *tab)
 {
     vb_build_table(tab, P);
     uint32_t k[14], w[15];
@@ -108,7 +108,7 @@ CAPY_HD inline Pt fb_add_digit(const Pt &acc, const uint32_t *gtab, int row, int
 }
 
 // [k]G from the shared table gtab[FB_TABLE_DWORDS]
-CAPY_HD inline Pt fb_scalarmul(const uint8_t *k_be, const uint32_t *gtab)
+CAPY_HD_INLINE Pt fb_scalarmul(const uint8_t *k_be, const uint32_t *gtab)
 {
     uint32_t k[14], w[15];
     sc_from_be(k, k_be);
@@ -121,7 +121,7 @@ CAPY_HD inline Pt fb_scalarmul(const uint8_t *k_be, const uint32_t *gtab)
 
 // [a]G + [b]P in one pass (Straus): the doublings of the variable-base loop are shared; the G part
 // uses row 0 of the fixed-base table (j*G, j = 0..2^(FB_WBITS-1), of which the WBITS-wide digits reach 0..2^(WBITS-1)).
-CAPY_HD inline Pt double_scalarmul(const uint8_t *a_be, const uint8_t *b_be, const Pt &P, uint32_t *tab,
+CAPY_HD_INLINE Pt double_scalarmul(const uint8_t *a_be, const uint8_t *b_be, const Pt &P, uint32_t *tab,
                                    const uint32_t *gtab)
 {
     vb_build_table(tab, P);

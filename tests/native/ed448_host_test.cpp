@@ -40,6 +40,14 @@ void ht_scalarmul(const uint8_t *k_be, const uint8_t *p_xy, uint8_t *out_xy)
 }
 void ht_add(const uint8_t *p, const uint8_t *q, uint8_t *out) { pt_to_affine_bytes(out, pt_add(pt_from_affine_bytes(p), pt_from_affine_bytes(q))); }
 void ht_dbl(const uint8_t *p, uint8_t *out) { pt_to_affine_bytes(out, pt_dbl<true>(pt_from_affine_bytes(p))); }
+// projective (X, Y, Z) x 2 as raw field bytes -> two affine points through the shared inversion; out = 224 bytes
+void ht_pair_affine(const uint8_t *xyz0, const uint8_t *xyz1, uint8_t *out)
+{
+    Pt p0, p1;
+    p0.X = fe_from_bytes(xyz0); p0.Y = fe_from_bytes(xyz0 + 56); p0.Z = fe_from_bytes(xyz0 + 112); p0.T = fe_zero();
+    p1.X = fe_from_bytes(xyz1); p1.Y = fe_from_bytes(xyz1 + 56); p1.Z = fe_from_bytes(xyz1 + 112); p1.T = fe_zero();
+    pt_pair_to_affine_bytes(out, out + 112, p0, p1);
+}
 void ht_sc_mul_mod(const uint8_t *a, const uint8_t *b, uint8_t *out)
 {
     uint32_t x[14], y[14], r[14];

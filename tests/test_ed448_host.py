@@ -112,3 +112,33 @@ def test_scalar_field(L):
         assert call(L, "ht_sc_mul_mod", E.sc_to_bytes(a), E.sc_to_bytes(b)) == E.sc_to_bytes(a * b % E.R)
         assert call(L, "ht_sc_sub_mod", E.sc_to_bytes(a), E.sc_to_bytes(b)) == E.sc_to_bytes((a - b) % E.R)
         assert call(L, "ht_sc_mul4_mod", E.sc_to_bytes(a)) == E.sc_to_bytes(4 * a % E.R)
+
+
+def test_pair_affine_shares_one_inversion(L):
+    """pt_pair_to_affine_bytes == two independent conversions, for random projective representatives, Z = 1, Z = p
+    (non-canonical zero) and Z = 0 (an invalid point must not spoil its partner and still yields (0, 0))."""
+    rng = random.Random(9)
+    P = E.P
+
+    def proj(pt, z):
+        x, y = pt
+        return fb(x * z) + fb(y * z) + int(z % 2**448).to_bytes(56, "little")
+
+    def affine_bytes(pt):
+        return fb(pt[0]) + fb(pt[1])
+
+    pts = [E.scalarmul(rng.getrandbits(446), E.G) for _ in range(6)]
+    for i in range(0, 6, 2):
+        z0, z1 = rng.randrange(1, P), rng.randrange(1, P)
+        out = call(L, "ht_pair_affine", proj(pts[i], z0), proj(pts[i + 1], z1), outlen=224)
+        assert out == affine_bytes(pts[i]) + affine_bytes(pts[i + 1])
+    out = call(L, "ht_pair_affine", proj(pts[0], 1), proj(pts[1], P - 1), outlen=224)
+    assert out == affine_bytes(pts[0]) + affine_bytes(pts[1])
+    for bad_z in (0, P):  # P is the non-canonical encoding of zero
+        bad = fb(5) + fb(7) + int(bad_z).to_bytes(56, "little")
+        out = call(L, "ht_pair_affine", bad, proj(pts[2], 12345), outlen=224)
+        assert out == bytes(112) + affine_bytes(pts[2])
+        out = call(L, "ht_pair_affine", proj(pts[3], 99), bad, outlen=224)
+        assert out == affine_bytes(pts[3]) + bytes(112)
+    out = call(L, "ht_pair_affine", fb(5) + fb(7) + bytes(56), fb(1) + fb(2) + bytes(56), outlen=224)
+    assert out == bytes(224)
