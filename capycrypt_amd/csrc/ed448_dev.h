@@ -194,6 +194,66 @@ inline void fe_check_sqr(const Fe &a)
 // r = a * b mod p.  256 MADs.  Exact while 38 * max_limb(a) * max_limb(b) < 2^64: with bs = b0 + b1 <= 2 Lb, column
 // hi[k] collects (k+1) pairs of (a0 b1 + a1 bs) <= 3 La Lb, (7-k) pairs of (a0 b0 + a1 b1) <= 2 La Lb and qh[k] of
 // (7-k) pairs <= 3 La Lb: at most (38 - 2k) La Lb.  Output limbs <= 2^28 + 2^9.
+// 1: Karatsuba multiplication / squaring (default: +5 % variable base, +10 % fixed base on MI355X, because the Ed448
+// kernels are power-limited and a 32x32->64 multiply-add costs more energy than the additions that replace it);
+// 0: the plain 256 / 136-MAD forms (same instruction count within 10 %).
+#ifndef CAPY_ED448_KARATSUBA
+#define CAPY_ED448_KARATSUBA 1
+#endif
+#if CAPY_ED448_KARATSUBA
+// Karatsuba over the Goldilocks split: AA = a0 b0, BB = a1 b1, CC = (a0 + a1)(b0 + b1);
+//   lo[k] = AA[k] + BB[k] + CC[k+8] - AA[k+8]      hi[k] = BB[k+8] + CC[k] + CC[k+8] - AA[k]
+// 192 MADs instead of 256, for 16 limb sums, 30 64-bit subtractions and 14 additions: about the same instruction count,
+// but a quarter fewer multiplies, which is what the power-limited Ed448 kernels pay for.  Everything is arithmetic
+// mod 2^64; the final columns are the same sums as in the plain form, so the same operand bound makes them exact.
+CAPY_HD CAPY_NOINLINE inline Fe fe_mul(const Fe a, const Fe b)
+{
+    CAPY_FE_CHECK_MUL(a, b);
+    uint32_t as[8], bs[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        as[j] = a.l[j] + a.l[8 + j];
+        bs[j] = b.l[j] + b.l[8 + j];
+    }
+    uint64_t aa[15], lo[8], hi[8], cch[7];
+#pragma unroll
+    for (int k = 0; k < 15; k++) aa[k] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) aa[i + j] += (uint64_t)a.l[i] * b.l[j];
+    // lo starts from AA[k], hi from 0; BB then lands on lo (k < 8) / hi (k >= 8), CC on hi (k < 8) / cch (k >= 8)
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        lo[k] = aa[k];
+        hi[k] = 0;
+    }
+#pragma unroll
+    for (int k = 0; k < 7; k++) cch[k] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int k = i + j;
+            const uint64_t bb = (uint64_t)a.l[8 + i] * b.l[8 + j], cc = (uint64_t)as[i] * bs[j];
+            if (k < 8) {
+                lo[k] += bb;
+                hi[k] += cc;
+            } else {
+                hi[k - 8] += bb;
+                cch[k - 8] += cc;
+            }
+        }
+#pragma unroll
+    for (int k = 0; k < 8; k++) hi[k] -= aa[k];
+#pragma unroll
+    for (int k = 0; k < 7; k++) {
+        lo[k] += cch[k] - aa[k + 8];
+        hi[k] += cch[k];
+    }
+    return fe_from_columns(lo, hi);
+}
+#else
 CAPY_HD CAPY_NOINLINE inline Fe fe_mul(const Fe a, const Fe b)
 {
     CAPY_FE_CHECK_MUL(a, b);
@@ -234,6 +294,60 @@ CAPY_HD CAPY_NOINLINE inline Fe fe_mul(const Fe a, const Fe b)
     return fe_from_columns(lo, hi);
 }
 
+#endif
+
+#if CAPY_ED448_KARATSUBA
+// r = a^2 mod p, Karatsuba as in fe_mul with AA = a0^2, BB = a1^2, CC = (a0 + a1)^2: 3 x 36 = 108 MADs instead of 136.
+CAPY_HD CAPY_NOINLINE inline Fe fe_sqr(const Fe a)
+{
+    CAPY_FE_CHECK_SQR(a);
+    uint32_t as[8], d0[8], d1[8], ds[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        as[j] = a.l[j] + a.l[8 + j];  // < 2^31 under the operand bound
+        d0[j] = 2 * a.l[j];
+        d1[j] = 2 * a.l[8 + j];
+        ds[j] = 2 * as[j];
+    }
+    uint64_t aa[15], lo[8], hi[8], cch[7];
+#pragma unroll
+    for (int k = 0; k < 15; k++) aa[k] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int j = i; j < 8; j++) aa[i + j] += (uint64_t)(i < j ? d0[i] : a.l[i]) * a.l[j];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        lo[k] = aa[k];
+        hi[k] = 0;
+    }
+#pragma unroll
+    for (int k = 0; k < 7; k++) cch[k] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int j = i; j < 8; j++) {
+            const int k = i + j;
+            const uint64_t bb = (uint64_t)(i < j ? d1[i] : a.l[8 + i]) * a.l[8 + j];
+            const uint64_t cc = (uint64_t)(i < j ? ds[i] : as[i]) * as[j];
+            if (k < 8) {
+                lo[k] += bb;
+                hi[k] += cc;
+            } else {
+                hi[k - 8] += bb;
+                cch[k - 8] += cc;
+            }
+        }
+#pragma unroll
+    for (int k = 0; k < 8; k++) hi[k] -= aa[k];
+#pragma unroll
+    for (int k = 0; k < 7; k++) {
+        lo[k] += cch[k] - aa[k + 8];
+        hi[k] += cch[k];
+    }
+    return fe_from_columns(lo, hi);
+}
+#else
 // r = a^2 mod p.  P = a0^2 + a1^2 ; Q = a1 (2 a0 + a1).  136 MADs.
 CAPY_HD CAPY_NOINLINE inline Fe fe_sqr(const Fe a)
 {
@@ -280,6 +394,8 @@ CAPY_HD CAPY_NOINLINE inline Fe fe_sqr(const Fe a)
     }
     return fe_from_columns(lo, hi);
 }
+
+#endif
 
 // a * k for a small constant k < 2^17
 CAPY_HD inline Fe fe_mul_small(const Fe &a, uint32_t k)

@@ -13,18 +13,20 @@ from oracle import ed448_ref as E
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "native", "ed448_host_test.cpp")
-SO = os.path.join(HERE, "native", "libed448host.so")
+# CAPY_ED448_TEST_DEFS="-DCAPY_ED448_KARATSUBA=1 ..." builds (and tests) a variant of the device code
+DEFS = os.environ.get("CAPY_ED448_TEST_DEFS", "").split()
+SO = os.path.join(HERE, "native", "libed448host%s.so" % ("_variant" if DEFS else ""))
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 
 @pytest.fixture(scope="module")
 def L():
     deps = [SRC] + [os.path.join(HERE, "..", "capycrypt_amd", "csrc", f) for f in ("ed448_dev.h", "ed448_algo.h")]
-    if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):
+    if DEFS or not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):
         if not os.path.exists(HIPCC):
             pytest.skip("hipcc not available")
-        subprocess.check_call([HIPCC, "-O2", "-std=c++17", "-fPIC", "-shared", "-x", "hip", "--offload-arch=gfx950",
-                               "-o", SO, SRC])
+        subprocess.check_call([HIPCC, "-O2", "-std=c++17", "-fPIC", "-shared", "-x", "hip", "--offload-arch=gfx950"] + DEFS +
+                              ["-o", SO, SRC])
     return C.CDLL(SO)
 
 
