@@ -220,3 +220,30 @@ def test_dev_api_protocols_roundtrip(capy, O):
                                               tags.data_ptr(), st.data_ptr(), None))
     torch.cuda.synchronize()
     assert not st.cpu().numpy().any() and bytes(work.cpu().numpy()) == hm
+
+
+def test_full_batch_pair_inversion_kernels(capy, O):
+    """2^18 + 77 items (BASELINE config 4 size, ragged last wave): from 262 144 items two items per lane share one
+    inversion (ed448.hip: vb2_kernel / fb2_kernel).  Size-independent property: [k]G by the fixed-base kernel equals
+    [k]G by the variable-base kernel for every item; a sample is checked against the oracle."""
+    import ctypes as C
+
+    import torch
+
+    from capycrypt_amd import _lib
+
+    lib = _lib.lib()
+    n = (1 << 18) + 77
+    sc = torch.empty(n * 56, dtype=torch.uint8, device="cuda")
+    _lib.check(lib.capy_fill_random_dev(sc.data_ptr(), n * 56, 0xCA9C0004, None))
+    G = O.ed448_generator()
+    gs = torch.tensor(list(G), dtype=torch.uint8, device="cuda").repeat(n)
+    fb = torch.zeros(n * 112, dtype=torch.uint8, device="cuda")
+    vb = torch.zeros(n * 112, dtype=torch.uint8, device="cuda")
+    _lib.check(lib.capy_ed448_basemul_batch_dev(n, sc.data_ptr(), fb.data_ptr(), None))
+    _lib.check(lib.capy_ed448_scalarmul_batch_dev(n, sc.data_ptr(), gs.data_ptr(), vb.data_ptr(), None))
+    torch.cuda.synchronize()
+    hf, hv, hs = bytes(fb.cpu().numpy()), bytes(vb.cpu().numpy()), bytes(sc.cpu().numpy())
+    assert hf == hv
+    for i in (0, 63, 64, 127, 128, n // 2, n - 78, n - 77, n - 14, n - 1):
+        assert hf[112 * i:112 * i + 112] == O.ed448_basemul(hs[56 * i:56 * i + 56]), i
