@@ -671,12 +671,12 @@ CAPY_HD inline void sc_to_be(uint8_t *out, const uint32_t w[14])
 // OFFSET = sum_i HALF 2^(W i), HALF = 2^(W-1), top = bit W*NWIN of k'.  Digits lie in [-HALF, HALF), so a
 // table of {0..HALF} P plus a sign serves every window with the same control flow.
 // Two widths are in use: WBITS for the per-item tables of the variable-base path (table build cost grows with
-// 2^W), FB_WBITS for the shared fixed-base table (built once per device, so as wide as the L2 comfortably holds).
+// 2^W), FB_WBITS for the shared fixed-base table (built once per device, so as wide as the caches comfortably hold).
 #ifndef CAPY_ED448_WBITS
 #define CAPY_ED448_WBITS 5
 #endif
 #ifndef CAPY_ED448_FB_WBITS
-#define CAPY_ED448_FB_WBITS 8
+#define CAPY_ED448_FB_WBITS 10
 #endif
 template <int W>
 struct Win {
