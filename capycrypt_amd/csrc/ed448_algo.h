@@ -120,27 +120,18 @@ CAPY_HD_INLINE Pt fb_scalarmul(const uint8_t *k_be, const uint32_t *gtab)
     return acc;
 }
 
-// [a]G + [b]P in one pass (Straus): the doublings of the variable-base loop are shared; the G part
-// uses row 0 of the fixed-base table (j*G, j = 0..2^(FB_WBITS-1), of which the WBITS-wide digits reach 0..2^(WBITS-1)).
+// [a]G + [b]P: the variable-base window loop for [b]P, then [a]G added from the shared fixed-base table (46 mixed
+// additions with 10-bit digits; interleaving 5-bit digits of `a` into the doubling chain, Straus style, costs 91).
 CAPY_HD_INLINE Pt double_scalarmul(const uint8_t *a_be, const uint8_t *b_be, const Pt &P, uint32_t *tab,
                                    const uint32_t *gtab)
 {
-    vb_build_table(tab, P);
-    uint32_t ka[14], kb[14], wa[15], wb[15];
+    Pt acc = vb_scalarmul(b_be, P, tab);
+    uint32_t ka[14], wa[15];
     sc_from_be(ka, a_be);
-    sc_from_be(kb, b_be);
-    const uint32_t topa = sc_recode_signed<WBITS>(wa, ka), topb = sc_recode_signed<WBITS>(wb, kb);
-    sc_msb_align<WBITS>(wa);
-    sc_msb_align<WBITS>(wb);
-    Pt acc = vb_add_digit(pt_identity(), tab, (int)topb);
-    acc = fb_add_digit(acc, gtab, 0, (int)topa);
+    const uint32_t topa = sc_recode_signed<FB_WBITS>(wa, ka);
+    acc = fb_add_digit(acc, gtab, FbWin::NWIN, (int)topa);
 #pragma unroll 1
-    for (int i = 0; i < NWIN; i++) {
-#pragma unroll 1
-        for (int j = 0; j < WBITS; j++) acc = pt_dbl<true>(acc);
-        acc = vb_add_digit(acc, tab, sc_next_digit_msb<WBITS>(wb));
-        acc = fb_add_digit(acc, gtab, 0, sc_next_digit_msb<WBITS>(wa));
-    }
+    for (int i = 0; i < FbWin::NWIN; i++) acc = fb_add_digit(acc, gtab, i, sc_next_digit_lsb<FB_WBITS>(wa));
     return acc;
 }
 
