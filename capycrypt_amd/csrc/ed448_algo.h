@@ -5,9 +5,9 @@
 // kept in HBM (lane-major so every lane streams whole 128-B lines), uniform control flow (every window does WBITS
 // doublings + 1 complete addition; the digit only selects the table row and a sign).
 // Fixed base: (FbWin::NWIN+1) x FbWin::ENTRIES affine table of j*2^(FB_WBITS i)*G shared by all lanes, one mixed
-// addition per window, no doublings.  WBITS = 5: 90 windows, 17 entries (4352 B per item); FB_WBITS = 10: 45 windows,
-// 46 x 513 entries (4.5 MB: L2 / Infinity Cache; every lane of a wave reads the same row).  Measured 8 / 9 / 10 bits:
-// 1.56 / 1.43 / 1.33 ms per 2^18 fixed-base multiplications.
+// addition per window, no doublings.  WBITS = 5: 90 windows, 17 entries (4352 B per item); FB_WBITS = 12: 38 windows,
+// 39 x 2049 entries (15.3 MB: L2 / Infinity Cache; every lane of a wave reads the same row).  Measured
+// 8 / 9 / 10 / 11 / 12 bits: 1.56 / 1.43 / 1.33 / 1.24 / 1.19 ms per 2^18 fixed-base multiplications.
 #pragma once
 #include "ed448_dev.h"
 
@@ -120,8 +120,8 @@ CAPY_HD_INLINE Pt fb_scalarmul(const uint8_t *k_be, const uint32_t *gtab)
     return acc;
 }
 
-// [a]G + [b]P: the variable-base window loop for [b]P, then [a]G added from the shared fixed-base table (46 mixed
-// additions with 10-bit digits; interleaving 5-bit digits of `a` into the doubling chain, Straus style, costs 91).
+// [a]G + [b]P: the variable-base window loop for [b]P, then [a]G added from the shared fixed-base table (39 mixed
+// additions with 12-bit digits; interleaving 5-bit digits of `a` into the doubling chain, Straus style, costs 91).
 CAPY_HD_INLINE Pt double_scalarmul(const uint8_t *a_be, const uint8_t *b_be, const Pt &P, uint32_t *tab,
                                    const uint32_t *gtab)
 {

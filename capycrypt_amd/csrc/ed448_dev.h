@@ -676,11 +676,11 @@ CAPY_HD inline void sc_to_be(uint8_t *out, const uint32_t w[14])
 #define CAPY_ED448_WBITS 5
 #endif
 #ifndef CAPY_ED448_FB_WBITS
-#define CAPY_ED448_FB_WBITS 10
+#define CAPY_ED448_FB_WBITS 12
 #endif
 template <int W>
 struct Win {
-    static_assert(W >= 2 && W <= 10, "window width");
+    static_assert(W >= 2 && W <= 12, "window width");
     static constexpr int BITS = W;
     static constexpr int NWIN = (448 + W - 1) / W;
     static constexpr int HALF = 1 << (W - 1);

@@ -80,16 +80,29 @@ void ht_build_gtab(const uint8_t *g_xy)
     uint32_t *t = (uint32_t *)gtab_aligned();
     Pt base = pt_from_affine_bytes(g_xy);  // 2^(FB_WBITS row) * G
     for (int row = 0; row < FB_ROWS; row++) {
+        // the row's entries j * base, j = 0 .. 2^(FB_WBITS-1), to affine with one inversion (Montgomery's trick)
+        std::vector<Pt> pts(FB_TAB_ENTRIES);
+        std::vector<Fe> prefix(FB_TAB_ENTRIES);
         Pt acc = pt_identity();
+        Fe run = fe_one();
         for (int j = 0; j < FB_TAB_ENTRIES; j++) {
+            pts[j] = acc;
+            run = fe_mul(run, acc.Z);
+            prefix[j] = run;
+            acc = pt_add(acc, base);
+        }
+        Fe inv = fe_inv(run);
+        for (int j = FB_TAB_ENTRIES - 1; j >= 0; j--) {
+            const Fe zi = j ? fe_mul(inv, prefix[j - 1]) : inv;
+            inv = fe_mul(inv, pts[j].Z);
             uint8_t xy[112];
-            pt_to_affine_bytes(xy, acc);
+            fe_to_bytes(xy, fe_mul(pts[j].X, zi));
+            fe_to_bytes(xy + 56, fe_mul(pts[j].Y, zi));
             Fe x = fe_from_bytes(xy), y = fe_from_bytes(xy + 56);
             uint32_t *e = t + (row * FB_TAB_ENTRIES + j) * FB_ENTRY_DWORDS;
             store_fe(e, x);
             store_fe(e + 16, y);
             store_fe(e + 32, fe_mul_d(fe_mul(x, y)));
-            acc = pt_add(acc, base);
         }
         for (int d = 0; d < FB_WBITS; d++) base = pt_dbl<true>(base);
     }
