@@ -176,6 +176,8 @@ inline void fe_check_mul(const Fe &a, const Fe &b)
     }
     const long double prod = 38.0L * (long double)ma * (long double)mb;
     if (prod >= 18446744073709551616.0L) capy_fe_bound_violation("fe_mul", (double)prod);
+    // Karatsuba adds the halves of BOTH operands in 32 bits: a0 + a1 < 2^32 needs limbs < 2^31
+    if (ma >= (1ull << 31) || mb >= (1ull << 31)) capy_fe_bound_violation("fe_mul operand sum", (double)(ma > mb ? ma : mb));
 }
 inline void fe_check_sqr(const Fe &a)
 {
@@ -183,6 +185,8 @@ inline void fe_check_sqr(const Fe &a)
     for (int i = 0; i < 16; i++) ma = a.l[i] > ma ? a.l[i] : ma;
     const long double prod = 40.0L * (long double)ma * (long double)ma;
     if (prod >= 18446744073709551616.0L) capy_fe_bound_violation("fe_sqr", (double)prod);
+    // Karatsuba squaring doubles a0 + a1 in 32 bits: 2 (a0 + a1) < 2^32 needs limbs < 2^30
+    if (ma >= (1ull << 30)) capy_fe_bound_violation("fe_sqr operand sum", (double)ma);
 }
 #define CAPY_FE_CHECK_MUL(a, b) fe_check_mul(a, b)
 #define CAPY_FE_CHECK_SQR(a) fe_check_sqr(a)
