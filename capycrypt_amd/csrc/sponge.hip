@@ -797,11 +797,13 @@ int PackedBatch::upload(size_t n, const uint8_t *host_msgs, const uint64_t *host
         CAPY_HIP(hipMemcpy(order.p, h_order.data(), n * 4, hipMemcpyHostToDevice));
     }
     CAPY_HIP(msgs.alloc(total + 16));
-    CAPY_HIP(starts.alloc((n + 1) * 8));
-    CAPY_HIP(lens.alloc((n ? n : 1) * 8));
     if (total) CAPY_HIP(bulk_copy(msgs.p, src, total, hipMemcpyHostToDevice));
-    CAPY_HIP(hipMemcpy(starts.p, h_starts.data(), (n + 1) * 8, hipMemcpyHostToDevice));
-    CAPY_HIP(hipMemcpy(lens.p, h_lens.data(), (n ? n : 1) * 8, hipMemcpyHostToDevice));
+    if (!uniform) {  // a uniform batch is described by (length, stride) alone
+        CAPY_HIP(starts.alloc((n + 1) * 8));
+        CAPY_HIP(lens.alloc((n ? n : 1) * 8));
+        CAPY_HIP(hipMemcpy(starts.p, h_starts.data(), (n + 1) * 8, hipMemcpyHostToDevice));
+        CAPY_HIP(hipMemcpy(lens.p, h_lens.data(), (n ? n : 1) * 8, hipMemcpyHostToDevice));
+    }
     return CAPY_OK;
 }
 
