@@ -567,6 +567,32 @@ def test_dev_api_ragged_offsets_longest_first(capy, O):
     assert hp == bytes(ref)
 
 
+def test_ragged_device_batch_on_the_issue_tuned_instance(capy):
+    """150 000 short ragged messages given as device offsets: above 128 sponges per SIMD the one-lane choice is the
+    issue-tuned instance (its ragged path, with the longest-first order); every 97th digest is checked with hashlib
+    (SHA3-256 is FIPS 202 at every length) and the two kernel families must agree on all of them."""
+    import numpy as np
+    import torch
+
+    from capycrypt_amd import _lib
+
+    lib = _lib.lib()
+    n = 150000
+    rng = np.random.default_rng(5)
+    lens = (rng.integers(0, 60, n) * 8).astype(np.int64)  # device offsets imply lengths: multiples of 8 here
+    lens[::1000] = 4096
+    offs = np.zeros(n + 1, dtype=np.int64)
+    offs[1:] = np.cumsum(lens)
+    data = _dev_rand(int(offs[-1]) + 8, 61)
+    d_offs = torch.from_numpy(offs).cuda()
+    dig = torch.zeros(n * 32, dtype=torch.uint8, device="cuda")
+    _lib.check(lib.capy_sha3_batch_dev(256, n, data.data_ptr(), d_offs.data_ptr(), 0, 0, dig.data_ptr(), None))
+    torch.cuda.synchronize()
+    host, hd = bytes(data.cpu().numpy()), bytes(dig.cpu().numpy())
+    for i in range(0, n, 97):
+        assert hd[32 * i:32 * i + 32] == hashlib.sha3_256(host[offs[i]:offs[i + 1]]).digest(), i
+
+
 def test_device_fill_equals_host_harness_prng(capy, sponge_lanes):
     """capy_fill_random_dev and capycrypt_amd.harness_prng produce the same stream (any shard's inputs
     can be regenerated on either side)."""
