@@ -6,10 +6,9 @@
 //
 // Field element: 16 limbs of 28 bits in 16 VGPRs (radix 2^28, little endian).  Products are
 // accumulated with v_mad_u64_u32 (32x32+64 -> 64 in one instruction; measured 1.2x the cost of
-// v_mul_lo_u32 on gfx950, tools/microbench.hip), schoolbook over the Goldilocks split
-// a = a0 + a1*phi, phi = 2^224, phi^2 = phi + 1:
-//     a*b = (a0b0 + a1b1) + (a0b1 + a1(b0+b1)) phi          -> 256 MADs, no 64-bit Karatsuba subtractions
-// north_star suggests u64 limbs with __umul64hi; on gfx950 a 64x64 product is 4 MADs plus carry
+// v_mul_lo_u32 on gfx950, tools/microbench.hip) over the Goldilocks split a = a0 + a1*phi, phi = 2^224,
+// phi^2 = phi + 1, in Karatsuba form by default (192 MADs, fe_mul below; the plain 256-MAD form is kept behind
+// CAPY_ED448_KARATSUBA=0).  north_star suggests u64 limbs with __umul64hi; on gfx950 a 64x64 product is 4 MADs plus carry
 // adds, so 28-bit limbs with lazy carries do the same multiplication in fewer, cheaper instructions.
 //
 // Everything is __host__ __device__ so the same code is unit-tested on the CPU (tests/test_ed448_host.py).

@@ -198,7 +198,7 @@ static void kmac_head(int d, size_t key_len, SpongeParams &p)
 }
 
 // Lanes per sponge: 1 fills the chip once there are >= ~64k independent sponges; below that the
-// two-lane kernel is 1.5x faster per sponge (sponge_kernels_k2.h).  0 = choose by batch size.
+// two-lane kernel is 1.48x faster per sponge (sponge_kernels_k2.h).  0 = choose by batch size, 3 = rotating schedule.
 static std::atomic<int> g_lanes_per_sponge{0};
 static std::atomic<unsigned> g_debug_flags{0};
 static std::atomic<bool> g_fused_enabled{true};

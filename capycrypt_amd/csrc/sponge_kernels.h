@@ -57,7 +57,7 @@ __device__ __forceinline__ void xor_word(KState &a, int w, uint64_t v)
 }
 __device__ __forceinline__ uint64_t state_word(const KState &a, int w) { return ((uint64_t)a.hi[w] << 32) | a.lo[w]; }
 
-// register budget: the latency-tuned instance must still fit two waves per SIMD (it serves up to 131072 items);
+// register budget: the latency-tuned instance must still fit two waves per SIMD (it serves up to 128 items per SIMD);
 // the issue-tuned instance is held to 128 VGPRs for four.
 #ifndef CAPY_FULLCHIP_WAVES
 #define CAPY_FULLCHIP_WAVES 4
