@@ -10,6 +10,14 @@ def _d(d):
     return int(getattr(d, "value", d))
 
 
+def _same_len(items, what, expect=None):
+    """All byte strings of one batch argument share a length (the C ABI takes one length per call)."""
+    n = expect if expect is not None else (len(items[0]) if items else 0)
+    if any(len(x) != n for x in items):
+        raise ValueError("%s of one batch must all be %s bytes long" % (what, n if expect is not None else "equally many"))
+    return n
+
+
 def sha3_batch(msgs, d):
     """SHA3-d of each message (shake(), /root/reference/src/sha3/shake_functions.rs:24-32)."""
     d = _d(d)
@@ -39,9 +47,10 @@ def kmac_xof_batch(keys, xs, l_bits, s_str, d):
     """kmac_xof(), /root/reference/src/sha3/shake_functions.rs:79-89; all keys must have one length."""
     d = _d(d)
     n = len(keys)
-    assert len(xs) == n
+    if len(xs) != n:
+        raise ValueError("keys and messages differ in count")
     klen = len(keys[0]) if n else 0
-    assert all(len(k) == klen for k in keys), "keys of one batch must share a length"
+    _same_len(keys, "keys")
     data, offs = L.pack(xs)
     ol = l_bits // 8
     out = (C.c_uint8 * max(1, n * ol))()
@@ -57,7 +66,8 @@ def sha3_encrypt_batch(pws, zs, msgs, d):
     d = _d(d)
     n = len(msgs)
     plen = len(pws[0]) if n else 0
-    assert all(len(p) == plen for p in pws) and all(len(z) == 512 for z in zs)
+    _same_len(pws, "passwords")
+    _same_len(zs, "nonces", 512)
     data, offs = L.pack(msgs)
     tags = (C.c_uint8 * max(1, 64 * n))()
     L.check(L.lib().capy_sha3_encrypt_batch(d, n, L.buf(b"".join(map(bytes, pws))), plen,
@@ -71,7 +81,7 @@ def sha3_decrypt_batch(pws, zs, cts, tags, d):
     d = _d(d)
     n = len(cts)
     plen = len(pws[0]) if n else 0
-    assert all(len(p) == plen for p in pws)
+    _same_len(pws, "passwords")
     data, offs = L.pack(cts)
     status = (C.c_int32 * max(1, n))()
     L.check(L.lib().capy_sha3_decrypt_batch(d, n, L.buf(b"".join(map(bytes, pws))), plen,
@@ -86,7 +96,8 @@ def kem_sponge_encrypt_batch(secrets, zs, msgs, d):
     d = _d(d)
     n = len(msgs)
     slen = len(secrets[0]) if n else 0
-    assert all(len(p) == slen for p in secrets) and all(len(z) == 512 for z in zs)
+    _same_len(secrets, "secrets")
+    _same_len(zs, "nonces", 512)
     data, offs = L.pack(msgs)
     tags = (C.c_uint8 * max(1, 64 * n))()
     L.check(L.lib().capy_kem_sponge_encrypt_batch(d, n, L.buf(b"".join(map(bytes, secrets))), slen,
@@ -149,7 +160,7 @@ def keypair_batch(pws, d):
     d = _d(d)
     n = len(pws)
     plen = len(pws[0]) if n else 0
-    assert all(len(p) == plen for p in pws)
+    _same_len(pws, "passwords")
     out = (C.c_uint8 * max(1, 112 * n))()
     L.check(L.lib().capy_keypair_batch(d, n, L.buf(b"".join(map(bytes, pws))), plen, out))
     raw = bytes(out)
@@ -160,7 +171,7 @@ def schnorr_sign_batch(pws, msgs, d):
     d = _d(d)
     n = len(msgs)
     plen = len(pws[0]) if n else 0
-    assert all(len(p) == plen for p in pws)
+    _same_len(pws, "passwords")
     data, offs = L.pack(msgs)
     h = (C.c_uint8 * max(1, 56 * n))()
     z = (C.c_uint8 * max(1, 56 * n))()
@@ -197,7 +208,7 @@ def key_decrypt_batch(pws, zxys, cts, tags, d):
     d = _d(d)
     n = len(cts)
     plen = len(pws[0]) if n else 0
-    assert all(len(p) == plen for p in pws)
+    _same_len(pws, "passwords")
     data, offs = L.pack(cts)
     status = (C.c_int32 * max(1, n))()
     L.check(L.lib().capy_key_decrypt_batch(d, n, L.buf(b"".join(map(bytes, pws))), plen,
