@@ -28,7 +28,7 @@ import csv
 rows = list(csv.DictReader(open("$OUT/prof_$R/bench_kernel_trace.csv")))
 with open("profiles/${R}_bench_sponge_dispatches.txt", "w") as f:
     f.write("# per-dispatch durations (ms) of the sponge kernels in the kernel-trace run of bench.py --steps 5 --warmup 1\n"
-            "# (the first mixed launch of the process is cold; it belongs to the warm-up step and to the stats average)\n")
+            "# (bench.py ramps the clocks with unrelated work first, so the warm-up step's launches are like the timed ones)\n")
     for r in rows:
         if "sponge" in r["Kernel_Name"]:
             f.write("%-45s %10.3f\n" % (r["Kernel_Name"].split("(")[0][5:],
