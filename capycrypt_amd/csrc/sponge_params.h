@@ -94,10 +94,30 @@ __device__ __forceinline__ uint32_t stream_byte(const SpongeParams &p, const Ite
 __device__ __forceinline__ uint64_t stream_word(const SpongeParams &p, const ItemCtx &c, uint64_t pos)
 {
     const uint64_t body0 = (uint64_t)p.pre_len + p.head_len;
-    // whole word inside the body and 8-byte aligned in memory: one load
-    if (pos >= body0 && pos + 8 <= body0 + c.len) {
+    if (pos >= body0) {
+        const uint64_t body_end = body0 + c.len;
         const uint8_t *a = c.msg + (pos - body0);
-        if (((uintptr_t)a & 7) == 0) return *reinterpret_cast<const uint64_t *>(a);
+        const bool aligned = ((uintptr_t)a & 7) == 0;
+        if (pos + 8 <= body_end) {
+            // whole word inside the body and 8-byte aligned in memory: one load
+            if (aligned) return *reinterpret_cast<const uint64_t *>(a);
+        } else if (pos >= body_end || aligned) {
+            // trailer word: the last 1..7 body bytes (if any), then suffix bytes, zeros and the final pad bit, built
+            // without a byte loop.  The 8-byte load stays inside the aligned word that holds the last body byte.
+            uint64_t v = 0;
+            uint32_t off = 0;
+            if (pos < body_end) {
+                off = (uint32_t)(body_end - pos);
+                v = *reinterpret_cast<const uint64_t *>(a) & ((1ULL << (8 * off)) - 1);
+            }
+            const uint64_t s0 = pos > body_end ? pos - body_end : 0;
+            if (s0 < p.suffix_len) {
+                const uint64_t sfx = p.suffix_len >= 8 ? c.suffix : (c.suffix & ((1ULL << (8 * p.suffix_len)) - 1));
+                v |= (sfx >> (8 * s0)) << (8 * off);
+            }
+            if (c.pad80 && pos + 8 == c.padded) v |= 0x80ULL << 56;
+            return v;
+        }
     }
     // whole word inside the per-item key (any alignment) or inside the head's zero fill
     if (pos >= (uint64_t)p.pre_len + p.hdr_len && pos + 8 <= body0) {
@@ -111,8 +131,6 @@ __device__ __forceinline__ uint64_t stream_word(const SpongeParams &p, const Ite
             return w;
         }
     }
-    // whole word inside the zero fill (between suffix and the final pad byte)
-    if (pos >= body0 + c.len + p.suffix_len && pos + 8 < c.padded) return 0;
     uint64_t w = 0;
 #pragma unroll
     for (int j = 0; j < 8; j++) w |= (uint64_t)stream_byte(p, c, pos + j) << (8 * j);
