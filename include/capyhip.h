@@ -16,6 +16,8 @@
  *   *_dev        same operation on buffers already resident in device memory, enqueued on `stream`
  *                (a hipStream_t passed as void*, NULL = default stream), no host synchronisation.
  *                Message starts that are 8-byte aligned take the coalesced fast path (any alignment is correct).
+ *                The kernels read whole aligned 8-byte words: up to 7 bytes past the end of an 8-byte aligned
+ *                message are read (never written, never past the aligned word that holds its last byte).
  * All entry points are thread safe; no pointer is retained after return.  Randomness (nonces) is
  * always an input so results are reproducible.
  */
