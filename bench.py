@@ -45,6 +45,17 @@ def parse():
     return ap.parse_args()
 
 
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown cpu"
+
+
 def cpu_baseline(seconds):
     """The oracle's scalar C SHA3-256 (a port of the reference algorithm; the Rust reference cannot
     be built here) timed on one host core over a bounded sample of the same workload."""
@@ -96,7 +107,8 @@ def cpu_baseline(seconds):
         "unit": "GiB/s",
         "cores": 1,
         "kind": "port",
-        "sample": "%d x 5 MiB SHA3-256 on 1 host thread (%.1f s); host has %d cpus" % (n, el, os.cpu_count()),
+        "sample": "%d x 5 MiB SHA3-256 on 1 host thread (%.1f s); host has %d cpus (%s)" % (n, el, os.cpu_count(),
+                                                                                            _cpu_model()),
         "multi_thread": {"value": sum(counts) * MSG_BYTES / 2**30 / el_mt, "unit": "GiB/s", "cores": nthr,
                          "sample": "%d x 5 MiB over %d threads (%.1f s)" % (sum(counts), nthr, el_mt)},
     }
