@@ -280,6 +280,34 @@ __global__ __launch_bounds__(64, FULLCHIP ? CAPY_FULLCHIP_WAVES : 2) void sponge
     if constexpr (MODE == 0) {
         uint8_t *o = active ? p.out + item * p.out_stride : nullptr;
         uint32_t produced = 0;
+        // Long outputs (XOF squeezes of at least one rate block per item): whole blocks leave through LDS so that 17..21
+        // consecutive lanes write one item's 136..168 contiguous bytes, instead of every lane writing 8 bytes to its own
+        // row (config 2: 1.37x write amplification, 64-byte fabric writes).  Needs a full wave of in-order items, rows
+        // 8-byte aligned and the squeeze width equal to the rate (cSHAKE / KMAC).
+        const bool coop_out = p.sq_words == (uint32_t)RW && p.out_len >= RB && item0 + 64 <= p.n && p.order == nullptr &&
+                              p.mask == nullptr && (((uintptr_t)p.out | p.out_stride) & 7) == 0 && p.out_stride * 64 < 0xfff00000ULL;
+        if (coop_out) {
+            uint32_t ooff[RW];
+#pragma unroll
+            for (int k = 0; k < RW; k++) {
+                const uint32_t i = k * 64 + lane;
+                const uint32_t m = i / RW, w = i - m * RW;
+                ooff[k] = m * (uint32_t)p.out_stride + 8 * w;
+            }
+            uint8_t *wave_out = p.out + item0 * p.out_stride;  // SGPR pair
+            const uint32_t nblk = p.out_len / RB;
+            for (uint32_t t = 0; t < nblk; t++) {
+#pragma unroll
+                for (int w = 0; w < RW; w++) s_stage[lane * RW + w] = state_word(a, w);
+                __syncthreads();
+                uint8_t *bt = wave_out + (uint64_t)t * RB;
+#pragma unroll
+                for (int k = 0; k < RW; k++) *reinterpret_cast<uint64_t *>(bt + ooff[k]) = s_stage[k * 64 + lane];
+                __syncthreads();
+                produced += RB;
+                if (produced < p.out_len) keccak_hot<FULLCHIP>(a);
+            }
+        }
         while (produced < p.out_len) {
 #pragma unroll
             for (int w = 0; w < 25; w++) {
