@@ -125,6 +125,7 @@ __device__ __forceinline__ uint64_t stream_word(const SpongeParams &p, const Ite
         if (k >= p.key_len) return 0;
         if (k + 8 <= p.key_len) {
             const uint8_t *a = c.key + k;
+            if (((uintptr_t)a & 7) == 0) return *reinterpret_cast<const uint64_t *>(a);
             uint64_t w = 0;
 #pragma unroll
             for (int j = 0; j < 8; j++) w |= (uint64_t)a[j] << (8 * j);
