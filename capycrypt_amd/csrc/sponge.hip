@@ -527,8 +527,14 @@ void tag_compare_launch(const uint8_t *a, uint64_t a_stride, const uint8_t *b, u
 }
 
 // ---- longest-first processing order for ragged DEVICE batches (host batches are sorted on upload): a counting sort
-// by a 512-step logarithmic length scale; the order inside a bucket is arbitrary, results do not depend on it.
+// by a 512-step logarithmic length scale WITHIN chunks of ORDER_CHUNK consecutive items.  Sorting the whole batch
+// scatters the messages of a wave all over the buffer, which costs short messages more than the idle lanes it saves
+// (2^21 messages of 0..2 KiB: 11.0 ms globally sorted, 4.4 ms unsorted); inside a 4096-item neighbourhood the lanes of
+// a wave still get near-equal lengths and their messages stay within a few MB.  The order inside a bucket is
+// arbitrary; results do not depend on it.
 constexpr int ORDER_BUCKETS = 512;
+constexpr int ORDER_CHUNK_SHIFT = 12;
+constexpr uint64_t ORDER_CHUNK = 1ull << ORDER_CHUNK_SHIFT;
 __device__ __forceinline__ uint32_t len_bucket_desc(uint64_t len)
 {
     uint32_t b;
@@ -544,16 +550,33 @@ __device__ __forceinline__ uint64_t item_len(const uint64_t *offsets, const uint
 {
     return lens ? lens[i] : offsets[i + 1] - offsets[i];
 }
+// Within a full chunk the 64 groups of 64 length-sorted items are laid out in a scrambled order (bit-reversed rank,
+// rotated by a hash of the chunk index): a monotone order would hand the workgroups with the same index modulo 64 -- which the dispatcher
+// tends to place on the same SIMDs -- the longest groups of every chunk.
+__host__ __device__ __forceinline__ uint32_t order_spread(uint32_t pos, uint64_t n)
+{
+    const uint32_t c = pos >> ORDER_CHUNK_SHIFT, base = c << ORDER_CHUNK_SHIFT;
+    if ((uint64_t)base + ORDER_CHUNK > n) return pos;  // partial last chunk: plain sorted order
+    const uint32_t r = pos - base;
+    uint32_t g = r >> 6, rev = 0;
+#pragma unroll
+    for (int b = 0; b < 6; b++) rev |= ((g >> b) & 1u) << (5 - b);
+    g = (rev + ((c * 0x9E3779B1u) >> 26)) & 63u;  // pseudo-random rotation per chunk
+    return base + (g << 6) + (r & 63u);
+}
+
 __global__ void order_hist_kernel(const uint64_t *offsets, const uint64_t *lens, uint64_t n, uint32_t *hist)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) atomicAdd(&hist[len_bucket_desc(item_len(offsets, lens, i))], 1u);
+    if (i < n) atomicAdd(&hist[(i >> ORDER_CHUNK_SHIFT) * ORDER_BUCKETS + len_bucket_desc(item_len(offsets, lens, i))], 1u);
 }
-__global__ void order_scan_kernel(uint32_t *hist)  // one block of ORDER_BUCKETS threads: counts -> start cursors
+// one block of ORDER_BUCKETS threads per chunk: counts -> start cursors (chunk base + exclusive prefix)
+__global__ void order_scan_kernel(uint32_t *hist)
 {
     __shared__ uint32_t sh[ORDER_BUCKETS];
+    uint32_t *h = hist + (uint64_t)blockIdx.x * ORDER_BUCKETS;
     const uint32_t t = threadIdx.x;
-    sh[t] = hist[t];
+    sh[t] = h[t];
     __syncthreads();
     for (uint32_t off = 1; off < ORDER_BUCKETS; off <<= 1) {
         const uint32_t v = t >= off ? sh[t - off] : 0;
@@ -561,27 +584,33 @@ __global__ void order_scan_kernel(uint32_t *hist)  // one block of ORDER_BUCKETS
         sh[t] += v;
         __syncthreads();
     }
-    hist[t] = sh[t] - hist[t];  // exclusive
+    h[t] = (uint32_t)((uint64_t)blockIdx.x << ORDER_CHUNK_SHIFT) + sh[t] - h[t];
 }
 __global__ void order_scatter_kernel(const uint64_t *offsets, const uint64_t *lens, uint64_t n, uint32_t *cursor,
                                      uint32_t *order)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) order[atomicAdd(&cursor[len_bucket_desc(item_len(offsets, lens, i))], 1u)] = (uint32_t)i;
+    if (i < n) {
+        uint32_t pos = atomicAdd(&cursor[(i >> ORDER_CHUNK_SHIFT) * ORDER_BUCKETS + len_bucket_desc(item_len(offsets, lens, i))], 1u);
+        pos = order_spread(pos, n);
+        order[pos] = (uint32_t)i;
+    }
 }
 static int device_order(const uint64_t *offsets, const uint64_t *lens, size_t n, hipStream_t s, const uint32_t **out)
 {
+    const size_t chunks = (n + ORDER_CHUNK - 1) >> ORDER_CHUNK_SHIFT;
     CAPY_WS(order, uint32_t *, s, WS_ORDER, n * 4);
-    CAPY_WS(hist, uint32_t *, s, WS_HIST, ORDER_BUCKETS * 4);
-    CAPY_HIP(hipMemsetAsync(hist, 0, ORDER_BUCKETS * 4, s));
+    CAPY_WS(hist, uint32_t *, s, WS_HIST, chunks * ORDER_BUCKETS * 4);
+    CAPY_HIP(hipMemsetAsync(hist, 0, chunks * ORDER_BUCKETS * 4, s));
     const dim3 grid((unsigned)((n + 255) / 256)), block(256);
     hipLaunchKernelGGL(order_hist_kernel, grid, block, 0, s, offsets, lens, (uint64_t)n, hist);
-    hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(ORDER_BUCKETS), 0, s, hist);
+    hipLaunchKernelGGL(order_scan_kernel, dim3((unsigned)chunks), dim3(ORDER_BUCKETS), 0, s, hist);
     hipLaunchKernelGGL(order_scatter_kernel, grid, block, 0, s, offsets, lens, (uint64_t)n, hist, order);
     CAPY_HIP(hipGetLastError());
     *out = order;
     return CAPY_OK;
 }
+
 // SplitMix64 counter-mode fill (harness PRNG)
 __global__ void fill_random_kernel(uint64_t *dst, uint64_t nwords, uint64_t seed)
 {
@@ -792,9 +821,14 @@ int PackedBatch::upload(size_t n, const uint8_t *host_msgs, const uint64_t *host
     if (has_order) {
         h_order.resize(n);
         for (size_t i = 0; i < n; i++) h_order[i] = (uint32_t)i;
-        std::stable_sort(h_order.begin(), h_order.end(), [&](uint32_t a, uint32_t b) { return h_lens[a] > h_lens[b]; });
+        // within neighbourhoods of 4096 items (see device_order): keeps a wave's messages close together in memory
+        for (size_t c0 = 0; c0 < n; c0 += 4096)
+            std::stable_sort(h_order.begin() + c0, h_order.begin() + std::min(n, c0 + 4096),
+                             [&](uint32_t a, uint32_t b) { return h_lens[a] > h_lens[b]; });
+        std::vector<uint32_t> spread(n);
+        for (size_t k = 0; k < n; k++) spread[order_spread((uint32_t)k, n)] = h_order[k];
         CAPY_HIP(order.alloc(n * 4));
-        CAPY_HIP(hipMemcpy(order.p, h_order.data(), n * 4, hipMemcpyHostToDevice));
+        CAPY_HIP(hipMemcpy(order.p, spread.data(), n * 4, hipMemcpyHostToDevice));
     }
     CAPY_HIP(msgs.alloc(total + 16));
     if (total) CAPY_HIP(bulk_copy(msgs.p, src, total, hipMemcpyHostToDevice));
