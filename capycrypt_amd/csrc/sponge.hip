@@ -384,7 +384,8 @@ static int launch_sponge(int rw, const SpongeParams &p, hipStream_t s)
     if (forced == 2 || ((forced == 0 || forced == 3) && p.n <= 32 * simds))
         e = launch_sponge_k2(rw, (int)p.out_mode, p2, s);
     else if (p.n > 128 * simds && !(q.debug_flags & 2))  // debug bit 1: latency-tuned instance at every size (A/B)
-        e = launch_sponge_k1_full(rw, (int)p.out_mode, p2, s);
+        e = (p2.offsets || p2.order) ? launch_sponge_k1_full_ragged(rw, (int)p.out_mode, p2, s)
+                                     : launch_sponge_k1_full(rw, (int)p.out_mode, p2, s);
     else
         e = launch_sponge_k1_lat(rw, (int)p.out_mode, p2, s);
     if (e == hipErrorInvalidValue) return fail(CAPY_ERR_ARG, "internal: no kernel instance for this rate / mode");

@@ -62,8 +62,11 @@ __device__ __forceinline__ uint64_t state_word(const KState &a, int w) { return 
 #ifndef CAPY_FULLCHIP_WAVES
 #define CAPY_FULLCHIP_WAVES 4
 #endif
-template <int RW, bool FULLCHIP, int MODE>
-__global__ __launch_bounds__(64, FULLCHIP ? CAPY_FULLCHIP_WAVES : 2) void sponge_kernel(const SpongeParams p)
+// WAVES = waves per SIMD the register budget is sized for.  The issue-tuned instance exists twice: 4 (128 VGPRs) for
+// uniformly strided batches and 3 (168 VGPRs) for ragged ones, whose per-item bookkeeping spills at 128
+// (2^22 ragged messages of 0..256 B: +19 %, 2^21 of 0..2 KiB: +6 %; uniform batches are 2-4 % faster at 4).
+template <int RW, bool FULLCHIP, int MODE, int WAVES = (FULLCHIP ? CAPY_FULLCHIP_WAVES : 2)>
+__global__ __launch_bounds__(64, WAVES) void sponge_kernel(const SpongeParams p)
 {
     constexpr uint32_t RB = RW * 8;
     __shared__ uint64_t s_stage[64 * RW];
