@@ -46,7 +46,7 @@ struct DevBuf {
 // enqueue on that stream, so reuse across calls is ordered by the stream itself; growing a slot
 // frees the old block with hipFree, which synchronises the device first.  (hipMallocAsync /
 // hipFreeAsync proved unreliable on the default stream of this ROCm build: results raced.)
-enum WsSlot { WS_PRE = 0, WS_ZPW, WS_KEKA, WS_TAG2, WS_A, WS_B, WS_C, WS_D, WS_E, WS_F, WS_TABLE, WS_STATE, WS_ORDER, WS_HIST, WS_NSLOTS };
+enum WsSlot { WS_PRE = 0, WS_ZPW, WS_KEKA, WS_TAG2, WS_A, WS_B, WS_C, WS_D, WS_E, WS_F, WS_TABLE, WS_STATE, WS_ORDER, WS_NSLOTS };
 void *workspace(hipStream_t stream, WsSlot slot, size_t bytes);  // nullptr on allocation failure
 
 // Messages of a host batch on the device.  If every message already starts on an 8-byte boundary the

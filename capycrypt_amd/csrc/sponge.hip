@@ -527,12 +527,11 @@ void tag_compare_launch(const uint8_t *a, uint64_t a_stride, const uint8_t *b, u
                        b_stride, status, (uint64_t)n);
 }
 
-// ---- longest-first processing order for ragged DEVICE batches (host batches are sorted on upload): a counting sort
+// ---- longest-first processing order for ragged DEVICE batches (host batches are sorted on upload): a stable sort
 // by a 512-step logarithmic length scale WITHIN chunks of ORDER_CHUNK consecutive items.  Sorting the whole batch
 // scatters the messages of a wave all over the buffer, which costs short messages more than the idle lanes it saves
 // (2^21 messages of 0..2 KiB: 11.0 ms globally sorted, 4.4 ms unsorted); inside a 4096-item neighbourhood the lanes of
-// a wave still get near-equal lengths and their messages stay within a few MB.  The order inside a bucket is
-// arbitrary; results do not depend on it.
+// a wave still get near-equal lengths and their messages stay within a few MB.
 constexpr int ORDER_BUCKETS = 512;
 constexpr int ORDER_CHUNK_SHIFT = 12;
 constexpr uint64_t ORDER_CHUNK = 1ull << ORDER_CHUNK_SHIFT;
@@ -566,47 +565,44 @@ __host__ __device__ __forceinline__ uint32_t order_spread(uint32_t pos, uint64_t
     return base + (g << 6) + (r & 63u);
 }
 
-__global__ void order_hist_kernel(const uint64_t *offsets, const uint64_t *lens, uint64_t n, uint32_t *hist)
+// One workgroup per neighbourhood: keys (length bucket << 12 | index in chunk) sorted ascending by a bitonic network
+// in LDS.  The index in the low bits makes the order stable: equal lengths keep their input order, so a batch of
+// equal-length messages given through offsets still reads memory sequentially (an atomic-cursor counting sort permuted
+// them at random inside each bucket: 2^21 x 1 KiB through offsets 2.5 -> 3.2 ms).
+__global__ __launch_bounds__(256) void order_chunk_sort_kernel(const uint64_t *offsets, const uint64_t *lens, uint64_t n,
+                                                               uint32_t *order)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) atomicAdd(&hist[(i >> ORDER_CHUNK_SHIFT) * ORDER_BUCKETS + len_bucket_desc(item_len(offsets, lens, i))], 1u);
-}
-// one block of ORDER_BUCKETS threads per chunk: counts -> start cursors (chunk base + exclusive prefix)
-__global__ void order_scan_kernel(uint32_t *hist)
-{
-    __shared__ uint32_t sh[ORDER_BUCKETS];
-    uint32_t *h = hist + (uint64_t)blockIdx.x * ORDER_BUCKETS;
-    const uint32_t t = threadIdx.x;
-    sh[t] = h[t];
-    __syncthreads();
-    for (uint32_t off = 1; off < ORDER_BUCKETS; off <<= 1) {
-        const uint32_t v = t >= off ? sh[t - off] : 0;
-        __syncthreads();
-        sh[t] += v;
-        __syncthreads();
+    __shared__ uint32_t key[ORDER_CHUNK];
+    const uint64_t base = (uint64_t)blockIdx.x << ORDER_CHUNK_SHIFT;
+    for (uint32_t r = threadIdx.x; r < ORDER_CHUNK; r += blockDim.x) {
+        const uint64_t i = base + r;
+        key[r] = i < n ? (len_bucket_desc(item_len(offsets, lens, i)) << ORDER_CHUNK_SHIFT) | r : 0xffffffffu;
     }
-    h[t] = (uint32_t)((uint64_t)blockIdx.x << ORDER_CHUNK_SHIFT) + sh[t] - h[t];
-}
-__global__ void order_scatter_kernel(const uint64_t *offsets, const uint64_t *lens, uint64_t n, uint32_t *cursor,
-                                     uint32_t *order)
-{
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) {
-        uint32_t pos = atomicAdd(&cursor[(i >> ORDER_CHUNK_SHIFT) * ORDER_BUCKETS + len_bucket_desc(item_len(offsets, lens, i))], 1u);
-        pos = order_spread(pos, n);
-        order[pos] = (uint32_t)i;
+    __syncthreads();
+    for (uint32_t k = 2; k <= ORDER_CHUNK; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = threadIdx.x; t < ORDER_CHUNK / 2; t += blockDim.x) {
+                const uint32_t lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;
+                const bool up = (lo & k) == 0;
+                const uint32_t a = key[lo], b = key[hi];
+                if ((a > b) == up) {
+                    key[lo] = b;
+                    key[hi] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t r = threadIdx.x; r < ORDER_CHUNK; r += blockDim.x) {
+        const uint64_t pos = base + r;
+        if (pos < n) order[order_spread((uint32_t)pos, n)] = (uint32_t)base + (key[r] & (uint32_t)(ORDER_CHUNK - 1));
     }
 }
 static int device_order(const uint64_t *offsets, const uint64_t *lens, size_t n, hipStream_t s, const uint32_t **out)
 {
     const size_t chunks = (n + ORDER_CHUNK - 1) >> ORDER_CHUNK_SHIFT;
     CAPY_WS(order, uint32_t *, s, WS_ORDER, n * 4);
-    CAPY_WS(hist, uint32_t *, s, WS_HIST, chunks * ORDER_BUCKETS * 4);
-    CAPY_HIP(hipMemsetAsync(hist, 0, chunks * ORDER_BUCKETS * 4, s));
-    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
-    hipLaunchKernelGGL(order_hist_kernel, grid, block, 0, s, offsets, lens, (uint64_t)n, hist);
-    hipLaunchKernelGGL(order_scan_kernel, dim3((unsigned)chunks), dim3(ORDER_BUCKETS), 0, s, hist);
-    hipLaunchKernelGGL(order_scatter_kernel, grid, block, 0, s, offsets, lens, (uint64_t)n, hist, order);
+    hipLaunchKernelGGL(order_chunk_sort_kernel, dim3((unsigned)chunks), dim3(256), 0, s, offsets, lens, (uint64_t)n, order);
     CAPY_HIP(hipGetLastError());
     *out = order;
     return CAPY_OK;
