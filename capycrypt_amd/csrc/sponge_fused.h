@@ -124,7 +124,7 @@ __global__ __launch_bounds__(64) void sponge_fused_crypt_kernel(const FusedParam
     if (lane < NIT) {
         const uint64_t sl = (uint64_t)blockIdx.x * NIT + lane;
         const uint64_t it = sl < fp.n ? (fp.order ? (uint64_t)fp.order[sl] : sl) : fp.n;
-        uint64_t base = 0;
+        uint64_t base = (uint64_t)(uintptr_t)fp.msgs;  // slots past the batch: any mapped address
         uint32_t nf = 0;
         if (it < fp.n) {
             uint64_t len;
@@ -153,15 +153,14 @@ __global__ __launch_bounds__(64) void sponge_fused_crypt_kernel(const FusedParam
             const uint32_t m = i / RW, w = i - m * RW;
             const bool in = m < NIT;
             lim[k] = in ? s_nfull[in ? m : 0] : 0;
-            dst[k] = reinterpret_cast<uint8_t *>(in ? s_base[in ? m : 0] : 0) + 8 * w;
+            dst[k] = in ? reinterpret_cast<uint8_t *>(s_base[m]) + 8 * w : fp.msgs;
         }
+        const uint8_t *last_word = batch_last_word(fp.msgs, fp.offsets, fp.n, fp.msg_stride, fp.uniform_len);
         uint64_t pf[NLOAD];
         auto coop_load = [&](uint32_t t) {
 #pragma unroll
             for (int k = 0; k < NLOAD; k++) {
-                uint64_t v = 0;
-                if (t < lim[k]) v = *reinterpret_cast<const uint64_t *>(dst[k] + (uint64_t)t * RB);
-                pf[k] = v;
+                pf[k] = load_global_u64(ragged_src(t < lim[k], dst[k], (uint64_t)t * RB, last_word));
             }
         };
         coop_load(0);
@@ -194,7 +193,7 @@ __global__ __launch_bounds__(64) void sponge_fused_crypt_kernel(const FusedParam
 #pragma unroll
             for (int k = 0; k < NLOAD; k++) {
                 const uint64_t v = s_stage[k * 64 + lane];
-                if (t < lim[k]) *reinterpret_cast<uint64_t *>(dst[k] + (uint64_t)t * RB) = v;
+                if (t < lim[k]) store_global_u64(dst[k] + (uint64_t)t * RB, v);
             }
             __syncthreads();
             if (t + 1 < max_full) coop_load(t + 1);

@@ -199,10 +199,11 @@ __global__ __launch_bounds__(64, WAVES) void sponge_kernel(const SpongeParams p)
             }
         }
     } else {
-        s_base[lane] = (uint64_t)(uintptr_t)c.msg;
+        s_base[lane] = (uint64_t)(uintptr_t)(c.msg ? c.msg : p.msgs);
         s_nfull[lane] = nfull;
         __syncthreads();
         const uint32_t max_full = wave_max_u32(nfull);
+        const uint8_t *last_word = batch_last_word(p.msgs, p.offsets, p.n, p.msg_stride, p.uniform_len);
         if constexpr (!FULLCHIP) {
             if (max_full) {
                 // source pointer and block limit of every (slot, lane) pair, hoisted out of the block loop
@@ -215,15 +216,11 @@ __global__ __launch_bounds__(64, WAVES) void sponge_kernel(const SpongeParams p)
                     lim[k] = s_nfull[m];
                     src[k] = reinterpret_cast<const uint8_t *>(s_base[m]) + 8 * w;
                 }
-                // lanes whose message has run out do not load (a shared fallback address would be one hot L2 line)
                 uint64_t pf[RW];
                 auto coop_load = [&](uint32_t t) {
 #pragma unroll
-                    for (int k = 0; k < RW; k++) {
-                        uint64_t v = 0;
-                        if (t < lim[k]) v = *reinterpret_cast<const uint64_t *>(src[k] + (uint64_t)t * RB);
-                        pf[k] = v;
-                    }
+                    for (int k = 0; k < RW; k++)
+                        pf[k] = load_global_u64(ragged_src(t < lim[k], src[k], (uint64_t)t * RB, last_word));
                 };
                 coop_load(0);
                 for (uint32_t t = 0; t < max_full; t++) {
@@ -248,10 +245,8 @@ __global__ __launch_bounds__(64, WAVES) void sponge_kernel(const SpongeParams p)
                 for (int k = 0; k < RW; k++) {
                     const uint32_t i = k * 64 + lane;
                     const uint32_t m = i / RW, w = i - m * RW;
-                    uint64_t v = 0;
-                    if (t < s_nfull[m])
-                        v = *reinterpret_cast<const uint64_t *>(reinterpret_cast<const uint8_t *>(s_base[m]) + (uint64_t)t * RB + 8 * w);
-                    s_stage[i] = v;
+                    s_stage[i] = load_global_u64(ragged_src(
+                        t < s_nfull[m], reinterpret_cast<const uint8_t *>(s_base[m]) + 8 * w, (uint64_t)t * RB, last_word));
                 }
                 __syncthreads();
                 if (t < nfull) {
@@ -357,8 +352,9 @@ __global__ __launch_bounds__(64, WAVES) void sponge_kernel(const SpongeParams p)
             }
         } else {
             __syncthreads();
-            s_base[lane] = (uint64_t)(uintptr_t)c.msg;
+            s_base[lane] = (uint64_t)(uintptr_t)(c.msg ? c.msg : p.msgs);
             s_nfull[lane] = xfull;
+            const uint8_t *last_word = batch_last_word(p.msgs, p.offsets, p.n, p.msg_stride, p.uniform_len);
             __syncthreads();
             const uint32_t max_x = wave_max_u32(xfull);
             for (uint32_t t = 0; t < max_x; t++) {
@@ -366,10 +362,8 @@ __global__ __launch_bounds__(64, WAVES) void sponge_kernel(const SpongeParams p)
                 for (int k = 0; k < RW; k++) {
                     const uint32_t i = k * 64 + lane;
                     const uint32_t m = i / RW, w = i - m * RW;
-                    uint64_t v = 0;
-                    if (t < s_nfull[m])
-                        v = *reinterpret_cast<const uint64_t *>(reinterpret_cast<const uint8_t *>(s_base[m]) + (uint64_t)t * RB + 8 * w);
-                    s_stage[i] = v;
+                    s_stage[i] = load_global_u64(ragged_src(
+                        t < s_nfull[m], reinterpret_cast<const uint8_t *>(s_base[m]) + 8 * w, (uint64_t)t * RB, last_word));
                 }
                 __syncthreads();
                 if (t < xfull) {
@@ -382,7 +376,7 @@ __global__ __launch_bounds__(64, WAVES) void sponge_kernel(const SpongeParams p)
                     const uint32_t i = k * 64 + lane;
                     const uint32_t m = i / RW, w = i - m * RW;
                     if (t < s_nfull[m])
-                        *reinterpret_cast<uint64_t *>(s_base[m] + (uint64_t)t * RB + 8 * w) = s_stage[i];
+                        store_global_u64(reinterpret_cast<uint8_t *>(s_base[m]) + (uint64_t)t * RB + 8 * w, s_stage[i]);
                 }
                 __syncthreads();
                 if (t < xfull && (uint64_t)(t + 1) * RB < tgt_len) keccak_hot<FULLCHIP>(a);

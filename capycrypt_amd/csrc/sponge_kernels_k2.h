@@ -168,9 +168,10 @@ __global__ __launch_bounds__(64) void sponge_kernel_k2(const SpongeParams p)
 
     // ---------------- phase B: whole-wave coalesced loads, one block ahead, source pointers hoisted
     if (h == 0) {
-        s_base[j] = (uint64_t)(uintptr_t)c.msg;
+        s_base[j] = (uint64_t)(uintptr_t)(c.msg ? c.msg : p.msgs);
         s_nfull[j] = nfull;
     }
+    const uint8_t *last_word = batch_last_word(p.msgs, p.offsets, p.n, p.msg_stride, p.uniform_len);
     __syncthreads();
     const uint32_t max_full = wave_max_u32(nfull);
     if (max_full) {
@@ -182,18 +183,13 @@ __global__ __launch_bounds__(64) void sponge_kernel_k2(const SpongeParams p)
             const uint32_t m = i / RW, w = i - m * RW;
             const bool in = m < NSP;
             lim[k] = in ? s_nfull[in ? m : 0] : 0;
-            src[k] = reinterpret_cast<const uint8_t *>(in ? s_base[in ? m : 0] : 0) + 8 * w;
+            src[k] = in ? reinterpret_cast<const uint8_t *>(s_base[m]) + 8 * w : p.msgs;
         }
-        // lanes whose message has run out do not load at all: pointing them at one shared "safe" address made every
-        // wave of a ragged batch hammer a single L2 line (57 vs 41 ms on a full chip of mixed lengths)
         uint64_t pf[NLOAD];
         auto coop_load = [&](uint32_t t) {
 #pragma unroll
-            for (int k = 0; k < NLOAD; k++) {
-                uint64_t v = 0;
-                if (t < lim[k]) v = *reinterpret_cast<const uint64_t *>(src[k] + (uint64_t)t * RB);
-                pf[k] = v;
-            }
+            for (int k = 0; k < NLOAD; k++)
+                pf[k] = load_global_u64(ragged_src(t < lim[k], src[k], (uint64_t)t * RB, last_word));
         };
         coop_load(0);
         const uint32_t *stage32 = reinterpret_cast<const uint32_t *>(s_stage);
@@ -262,15 +258,13 @@ __global__ __launch_bounds__(64) void sponge_kernel_k2(const SpongeParams p)
                 const uint32_t m = i / RW, w = i - m * RW;
                 const bool in = m < NSP;
                 lim[k] = in ? s_nfull[in ? m : 0] : 0;
-                dst[k] = reinterpret_cast<uint8_t *>(in ? s_base[in ? m : 0] : 0) + 8 * w;
+                dst[k] = in ? reinterpret_cast<uint8_t *>(s_base[m]) + 8 * w : const_cast<uint8_t *>(p.msgs);
             }
             uint64_t pf[NLOAD];
             auto coop_load = [&](uint32_t t) {
 #pragma unroll
                 for (int k = 0; k < NLOAD; k++) {
-                    uint64_t v = 0;
-                    if (t < lim[k]) v = *reinterpret_cast<const uint64_t *>(dst[k] + (uint64_t)t * RB);
-                    pf[k] = v;
+                    pf[k] = load_global_u64(ragged_src(t < lim[k], dst[k], (uint64_t)t * RB, last_word));
                 }
             };
             coop_load(0);
@@ -286,7 +280,7 @@ __global__ __launch_bounds__(64) void sponge_kernel_k2(const SpongeParams p)
 #pragma unroll
                 for (int k = 0; k < NLOAD; k++) {
                     const uint64_t v = s_stage[k * 64 + lane];
-                    if (t < lim[k]) *reinterpret_cast<uint64_t *>(dst[k] + (uint64_t)t * RB) = v;
+                    if (t < lim[k]) store_global_u64(dst[k] + (uint64_t)t * RB, v);
                 }
                 __syncthreads();
                 if (t + 1 < max_x) coop_load(t + 1);

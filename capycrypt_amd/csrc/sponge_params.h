@@ -138,6 +138,33 @@ __device__ __forceinline__ uint64_t stream_word(const SpongeParams &p, const Ite
     return w;
 }
 
+// Cooperative block loads of ragged batches are unconditional (17..21 back-to-back loads per block step; predicating
+// them serialised the loads behind exec-mask regions: the ragged issue-tuned instance waited 56 % of its cycles).  A slot
+// whose message has run out re-reads that message's own first bytes, clamped to the last 8 bytes of the batch buffer:
+// always mapped, and a different line for every message (one shared fallback address was a hot L2 line).
+__device__ __forceinline__ const uint8_t *batch_last_word(const uint8_t *msgs, const uint64_t *offsets, uint64_t n,
+                                                          uint64_t stride, uint64_t uniform_len)
+{
+    const uint64_t total = offsets ? offsets[n] : (n ? (n - 1) * stride + uniform_len : 0);
+    return msgs + (total >= 8 ? total - 8 : 0);
+}
+// 8-byte load through an explicitly GLOBAL pointer.  Message pointers rebuilt from integers (LDS tables, offsets) are
+// generic ("flat") pointers to the compiler, which then orders every such load against the LDS stores of the staging
+// buffer in between: load, wait, store, load, ... -- 17..21 serial round trips per block step.
+__device__ __forceinline__ uint64_t load_global_u64(const uint8_t *q)
+{
+    return *reinterpret_cast<const __attribute__((address_space(1))) uint64_t *>(reinterpret_cast<uintptr_t>(q));
+}
+__device__ __forceinline__ void store_global_u64(uint8_t *q, uint64_t v)
+{
+    *reinterpret_cast<__attribute__((address_space(1))) uint64_t *>(reinterpret_cast<uintptr_t>(q)) = v;
+}
+__device__ __forceinline__ const uint8_t *ragged_src(bool live, const uint8_t *base, uint64_t byte_off, const uint8_t *last_word)
+{
+    const uint8_t *fallback = base < last_word ? base : last_word;
+    return live ? base + byte_off : fallback;
+}
+
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 {
 #pragma unroll
