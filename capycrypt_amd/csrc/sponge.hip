@@ -208,7 +208,8 @@ static const size_t FUSED_MAX_ITEMS = 16384;  // 16 items per wave x one wave pe
 //   32 S < n < 64 S  rotating one-lane / two-lane schedule when eligible (sponge_mixed.h), else one lane
 //   n <= 128 S       one lane per sponge, latency-tuned instance; uniform batches above 64 S are launched as a
 //                    head of 64 S + a remainder that follows the rules above (wave quantisation)
-//   above            one lane per sponge, issue-tuned instance (> 2 waves per SIMD)
+//   above            one lane per sponge, issue-tuned instance (> 2 waves per SIMD); ragged batches stay on the
+//                    latency-tuned instance
 
 static std::atomic<bool> g_mixed_enabled{true};
 
@@ -383,9 +384,11 @@ static int launch_sponge(int rw, const SpongeParams &p, hipStream_t s)
     }
     if (forced == 2 || ((forced == 0 || forced == 3) && p.n <= 32 * simds))
         e = launch_sponge_k2(rw, (int)p.out_mode, p2, s);
-    else if (p.n > 128 * simds && !(q.debug_flags & 2))  // debug bit 1: latency-tuned instance at every size (A/B)
-        e = (p2.offsets || p2.order) ? launch_sponge_k1_full_ragged(rw, (int)p.out_mode, p2, s)
-                                     : launch_sponge_k1_full(rw, (int)p.out_mode, p2, s);
+    // ragged batches stay on the latency-tuned instance at every size: its ragged path keeps the source pointers in
+    // registers and prefetches a block ahead, which the 128-VGPR issue-tuned instance cannot afford (2^18 ragged
+    // messages of 0..64 KiB: 16.0 vs 13.6 ms; equal lengths given through offsets: 9.7 vs 8.1 ms)
+    else if (p.n > 128 * simds && !(q.debug_flags & 2) && !p2.offsets && !p2.order)  // debug bit 1: A/B switch
+        e = launch_sponge_k1_full(rw, (int)p.out_mode, p2, s);
     else
         e = launch_sponge_k1_lat(rw, (int)p.out_mode, p2, s);
     if (e == hipErrorInvalidValue) return fail(CAPY_ERR_ARG, "internal: no kernel instance for this rate / mode");

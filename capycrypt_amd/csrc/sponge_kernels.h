@@ -62,9 +62,9 @@ __device__ __forceinline__ uint64_t state_word(const KState &a, int w) { return 
 #ifndef CAPY_FULLCHIP_WAVES
 #define CAPY_FULLCHIP_WAVES 4
 #endif
-// WAVES = waves per SIMD the register budget is sized for.  The issue-tuned instance exists twice: 4 (128 VGPRs) for
-// uniformly strided batches and 3 (168 VGPRs) for ragged ones, whose per-item bookkeeping spills at 128
-// (2^22 ragged messages of 0..256 B: +19 %, 2^21 of 0..2 KiB: +6 %; uniform batches are 2-4 % faster at 4).
+// WAVES = waves per SIMD the register budget is sized for (2: latency-tuned, 256 VGPRs; 4: issue-tuned, 128 VGPRs).
+// A 3-wave copy of the issue-tuned instance for ragged batches was tried and dropped: the latency-tuned instance is
+// faster there (see launch_sponge in sponge.hip).
 template <int RW, bool FULLCHIP, int MODE, int WAVES = (FULLCHIP ? CAPY_FULLCHIP_WAVES : 2)>
 __global__ __launch_bounds__(64, WAVES) void sponge_kernel(const SpongeParams p)
 {

@@ -9,8 +9,6 @@ namespace capy {
 hipError_t launch_sponge_k1_lat(int rw, int mode, const SpongeParams &p, hipStream_t s);
 // one lane per sponge, issue-tuned instance (many waves per SIMD)
 hipError_t launch_sponge_k1_full(int rw, int mode, const SpongeParams &p, hipStream_t s);
-// the same with the register budget of three waves per SIMD (ragged batches: offsets / processing order)
-hipError_t launch_sponge_k1_full_ragged(int rw, int mode, const SpongeParams &p, hipStream_t s);
 // two lanes per sponge (small batches of long messages)
 hipError_t launch_sponge_k2(int rw, int mode, const SpongeParams &p, hipStream_t s);
 // tag + keystream sponges of sha3_encrypt / sha3_decrypt in one pass (sponge_fused.h); rw in {17, 19, 21}
