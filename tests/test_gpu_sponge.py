@@ -567,10 +567,10 @@ def test_dev_api_ragged_offsets_longest_first(capy, O):
     assert hp == bytes(ref)
 
 
-def test_ragged_device_batch_on_the_issue_tuned_instance(capy):
-    """150 000 short ragged messages given as device offsets: above 128 sponges per SIMD the one-lane choice is the
-    issue-tuned instance (its ragged path, with the longest-first order); every 97th digest is checked with hashlib
-    (SHA3-256 is FIPS 202 at every length) and the two kernel families must agree on all of them."""
+def test_ragged_device_batch_above_128_sponges_per_simd(capy):
+    """150 000 short ragged messages given as device offsets (more than 128 sponges per SIMD: ragged batches stay on
+    the latency-tuned one-lane instance, in longest-first order; the fixture also runs the two-lane kernel); every 97th
+    digest is checked with hashlib (SHA3-256 is FIPS 202 at every length)."""
     import numpy as np
     import torch
 
