@@ -553,19 +553,18 @@ __device__ __forceinline__ uint64_t item_len(const uint64_t *offsets, const uint
 {
     return lens ? lens[i] : offsets[i + 1] - offsets[i];
 }
-// Within a full chunk the 64 groups of 64 length-sorted items are laid out in a scrambled order (bit-reversed rank,
-// rotated by a hash of the chunk index): a monotone order would hand the workgroups with the same index modulo 64 -- which the dispatcher
-// tends to place on the same SIMDs -- the longest groups of every chunk.
+// Dispatch order of the 64-item groups: rank-major over the full neighbourhoods -- first every neighbourhood's longest
+// group, then every second-longest, ... -- so the grid as a whole starts its long groups first (longest-processing-time
+// first, what keeps the tail short when the groups do not all fit on the chip at once) while each group still reads
+// from one neighbourhood.  Groups of equal rank sit next to each other, so the workgroups that end up on one SIMD
+// (indices a multiple of the slot count apart) differ in rank as well.
 __host__ __device__ __forceinline__ uint32_t order_spread(uint32_t pos, uint64_t n)
 {
-    const uint32_t c = pos >> ORDER_CHUNK_SHIFT, base = c << ORDER_CHUNK_SHIFT;
-    if ((uint64_t)base + ORDER_CHUNK > n) return pos;  // partial last chunk: plain sorted order
-    const uint32_t r = pos - base;
-    uint32_t g = r >> 6, rev = 0;
-#pragma unroll
-    for (int b = 0; b < 6; b++) rev |= ((g >> b) & 1u) << (5 - b);
-    g = (rev + ((c * 0x9E3779B1u) >> 26)) & 63u;  // pseudo-random rotation per chunk
-    return base + (g << 6) + (r & 63u);
+    const uint32_t full = (uint32_t)(n >> ORDER_CHUNK_SHIFT);  // complete neighbourhoods
+    const uint32_t c = pos >> ORDER_CHUNK_SHIFT;
+    if (c >= full) return pos;  // partial last neighbourhood: plain sorted order, at the end
+    const uint32_t r = (pos >> 6) & 63u;
+    return ((r * full + c) << 6) + (pos & 63u);
 }
 
 // One workgroup per neighbourhood: keys (length bucket << 12 | index in chunk) sorted ascending by a bitonic network
