@@ -591,6 +591,13 @@ def test_ragged_device_batch_above_128_sponges_per_simd(capy):
     host, hd = bytes(data.cpu().numpy()), bytes(dig.cpu().numpy())
     for i in range(0, n, 97):
         assert hd[32 * i:32 * i + 32] == hashlib.sha3_256(host[offs[i]:offs[i + 1]]).digest(), i
+    # the processing order must be a permutation of the batch: every digest equals the input-order run's
+    flags = lib.capy_set_sponge_lanes  # (the fixture restores the setting afterwards)
+    _lib.check(flags(1 | (4 << 8)))
+    dig2 = torch.zeros(n * 32, dtype=torch.uint8, device="cuda")
+    _lib.check(lib.capy_sha3_batch_dev(256, n, data.data_ptr(), d_offs.data_ptr(), 0, 0, dig2.data_ptr(), None))
+    torch.cuda.synchronize()
+    assert torch.equal(dig, dig2)
 
 
 def test_device_fill_equals_host_harness_prng(capy, sponge_lanes):
