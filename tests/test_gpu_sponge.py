@@ -600,6 +600,21 @@ def test_ragged_device_batch_above_128_sponges_per_simd(capy):
     assert torch.equal(dig, dig2)
 
 
+def test_host_ragged_batch_larger_than_a_neighbourhood(capy):
+    """10 000 ragged messages through the host-buffer API (more than two 4096-item neighbourhoods of the processing
+    order, unaligned starts -> re-packed): every SHA3-256 digest against hashlib, KMAC outputs must be pairwise
+    consistent with a second call in reverse order."""
+    rng = random.Random(4242)
+    msgs = [rng.randbytes(rng.choice([0, 1, 7, 8, 135, 136, 137, 300, 1000]) if rng.random() < 0.4 else rng.randrange(0, 600))
+            for _ in range(10000)]
+    got = capy.ops.sha3_batch(msgs, 256)
+    assert got == [hashlib.sha3_256(m).digest() for m in msgs]
+    keys = [rng.randbytes(32) for _ in msgs]
+    a = capy.ops.kmac_xof_batch(keys, msgs, 256, b"T", 512)
+    b = capy.ops.kmac_xof_batch(keys[::-1], msgs[::-1], 256, b"T", 512)
+    assert a == b[::-1]
+
+
 def test_device_fill_equals_host_harness_prng(capy, sponge_lanes):
     """capy_fill_random_dev and capycrypt_amd.harness_prng produce the same stream (any shard's inputs
     can be regenerated on either side)."""
