@@ -10,6 +10,10 @@ namespace capy {
 hipError_t launch_sponge_k2(int rw, int mode, const SpongeParams &p, hipStream_t s)
 {
     const dim3 grid((unsigned)((p.n + 31) / 32)), block(64);
+    if ((p.debug_flags & 8) && rw == 17 && mode == 0) {  // A/B: rolled two-round body (profiles/r02_second_issue_slot.txt)
+        hipLaunchKernelGGL((sponge_kernel_k2<17, 0, 1>), grid, block, 0, s, p);
+        return hipGetLastError();
+    }
     switch (rw * 2 + mode) {
         CAPY_CASE(9, 0)
         CAPY_CASE(13, 0)

@@ -102,7 +102,31 @@ __device__ __forceinline__ void keccakf1600_k2(KHalf &s, uint32_t hmask)
     }
 }
 
-template <int RW, int MODE>
+// Rolled two-round body with the next pair of round constants fetched one trip ahead (the scalar-load latency never
+// sits between two rounds): ~2 KB of instructions instead of the 23 KB of the unrolled form.  The experiment of
+// profiles/r02_second_issue_slot.txt: does a second wave on the SIMD keep its issue rate when the body is small?
+__device__ __forceinline__ void keccakf1600_k2_pipelined(KHalf &s, uint32_t hmask)
+{
+    uint32_t c0 = KECCAK_RC32[0], c1 = KECCAK_RC32[1], c2 = KECCAK_RC32[2], c3 = KECCAK_RC32[3];
+#pragma unroll 1
+    for (int r = 0; r < 24; r += 2) {
+        const int nx = (r + 2 < 24) ? r + 2 : 0;
+        const uint32_t n0 = KECCAK_RC32[2 * nx], n1 = KECCAK_RC32[2 * nx + 1], n2 = KECCAK_RC32[2 * nx + 2],
+                       n3 = KECCAK_RC32[2 * nx + 3];
+        keccak_round_k2(s, c0, c0 ^ c1, hmask);
+        asm volatile(".p2align 3" : "+v"(s.a[0]));
+        keccak_round_k2(s, c2, c2 ^ c3, hmask);
+        asm volatile(".p2align 3" : "+v"(s.a[0]));
+        c0 = n0;
+        c1 = n1;
+        c2 = n2;
+        c3 = n3;
+    }
+}
+
+// BODY 0: fully unrolled permutation with literal round constants in the block loop (default);
+// BODY 1: the rolled two-round form above (A/B instance, selected by debug bit 3 of capy_set_sponge_lanes)
+template <int RW, int MODE, int BODY = 0>
 __global__ __launch_bounds__(64) void sponge_kernel_k2(const SpongeParams p)
 {
     constexpr uint32_t RB = RW * 8;
@@ -205,7 +229,10 @@ __global__ __launch_bounds__(64) void sponge_kernel_k2(const SpongeParams p)
             if (t < nfull) {
 #pragma unroll
                 for (int w = 0; w < RW; w++) a.a[w] ^= wv[w];
-                keccakf1600_k2_unrolled(a, hmask);
+                if constexpr (BODY == 1)
+                    keccakf1600_k2_pipelined(a, hmask);
+                else
+                    keccakf1600_k2_unrolled(a, hmask);
             }
         }
     }

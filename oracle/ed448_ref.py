@@ -111,3 +111,140 @@ def x448_u_from_edwards(pt):
     """RFC 7748 §4.2 birational map edwards448 -> curve448: u = y^2 / x^2."""
     x, y = pt
     return y * y % P * pow(x * x % P, -1, P) % P
+
+
+def rfc8032_decode(b):
+    """RFC 8032 §5.2.3 point decoding (57 bytes -> affine (x, y)), None if invalid."""
+    y = int.from_bytes(b, "little")
+    x0 = y >> 455
+    y &= (1 << 455) - 1
+    if y >= P:
+        return None
+    u = (y * y - 1) % P
+    v = (D * y * y - 1) % P
+    x = pow(u, 3, P) * v % P * pow(pow(u, 5, P) * pow(v, 3, P) % P, (P - 3) // 4, P) % P
+    if (v * x * x - u) % P:
+        return None
+    if x == 0 and x0:
+        return None
+    if (x & 1) != x0:
+        x = P - x
+    return (x, y)
+
+
+def _dom4(ctx):
+    return b"SigEd448" + bytes([0, len(ctx)]) + ctx
+
+
+def rfc8032_secret_scalar(sk):
+    import hashlib
+
+    h = hashlib.shake_256(sk).digest(114)
+    a = bytearray(h[:57])
+    a[0] &= 0xFC
+    a[55] |= 0x80
+    a[56] = 0
+    return int.from_bytes(a, "little"), h[57:]
+
+
+def rfc8032_challenge(sig_r, pk, msg, ctx=b""):
+    """k = SHAKE256(dom4(0, ctx) || R || A || M, 114) mod L (RFC 8032 §5.2.6 / §5.2.7)."""
+    import hashlib
+
+    return int.from_bytes(hashlib.shake_256(_dom4(ctx) + sig_r + pk + msg).digest(114), "little") % R
+
+
+def rfc8032_sign(sk, msg, ctx=b""):
+    """Deterministic Ed448 signature, RFC 8032 §5.2.6."""
+    import hashlib
+
+    s, prefix = rfc8032_secret_scalar(sk)
+    a_enc = rfc8032_encode(scalarmul(s, G))
+    r = int.from_bytes(hashlib.shake_256(_dom4(ctx) + prefix + msg).digest(114), "little") % R
+    r_enc = rfc8032_encode(scalarmul(r, G))
+    k = rfc8032_challenge(r_enc, a_enc, msg, ctx)
+    return r_enc + ((r + k * s) % R).to_bytes(57, "little")
+
+
+def rfc8032_verify(pk, msg, sig, ctx=b"", mul=scalarmul, addp=add):
+    """[S]B == R + [k]A (RFC 8032 §5.2.7, cofactorless form).  `mul` / `addp` let a test substitute the
+    implementation under test for the group operations."""
+    a_pt, r_pt = rfc8032_decode(pk), rfc8032_decode(sig[:57])
+    s = int.from_bytes(sig[57:], "little")
+    if a_pt is None or r_pt is None or s >= R:
+        return False
+    k = rfc8032_challenge(sig[:57], pk, msg, ctx)
+    return mul(s, G) == addp(r_pt, mul(k, a_pt))
+
+
+# --- RFC 7748: X448 by the Montgomery ladder (an algorithm independent of the Edwards group law above) ---
+A24 = 39081
+
+
+def x448_clamp(k_bytes):
+    kb = bytearray(k_bytes)
+    kb[0] &= 252
+    kb[55] |= 128
+    return int.from_bytes(kb, "little")
+
+
+def x448_ladder(k, u):
+    """u([k]Q) for Q = (u, .) on curve448 (or its twist), k a non-negative integer < 2^448; RFC 7748 §5."""
+    x1 = u % P
+    x2, z2, x3, z3, swap = 1, 0, x1, 1, 0
+    for t in range(447, -1, -1):
+        kt = (k >> t) & 1
+        swap ^= kt
+        if swap:
+            x2, x3, z2, z3 = x3, x2, z3, z2
+        swap = kt
+        a = (x2 + z2) % P
+        aa = a * a % P
+        b = (x2 - z2) % P
+        bb = b * b % P
+        e = (aa - bb) % P
+        c = (x3 + z3) % P
+        d = (x3 - z3) % P
+        da = d * a % P
+        cb = c * b % P
+        x3 = (da + cb) ** 2 % P
+        z3 = x1 * (da - cb) ** 2 % P
+        x2 = aa * bb % P
+        z2 = e * (aa + A24 * e) % P
+    if swap:
+        x2, x3, z2, z3 = x3, x2, z3, z2
+    return x2 * pow(z2, P - 2, P) % P
+
+
+def x448(k_bytes, u_bytes):
+    return x448_ladder(x448_clamp(k_bytes), int.from_bytes(u_bytes, "little")).to_bytes(56, "little")
+
+
+def curve448_v(u):
+    """v with v^2 = u^3 + 156326 u^2 + u, or None when u is on the twist."""
+    rhs = (u * u % P * u + 156326 * u * u + u) % P
+    v = pow(rhs, (P + 1) // 4, P)
+    return v if v * v % P == rhs else None
+
+
+def edwards_from_curve448(u, v):
+    """RFC 7748 §4.2, the map curve448 -> edwards448.  Together with x448_u_from_edwards it composes to
+    multiplication by 4 (they are a 4-isogeny and its dual): u(E->M(M->E(Q))) = u([4]Q)."""
+    x = 4 * v * (u * u - 1) % P * pow((pow(u, 4, P) - 2 * u * u + 4 * v * v + 1) % P, -1, P) % P
+    y = -(pow(u, 5, P) - 2 * pow(u, 3, P) - 4 * u * v * v + u) % P * pow(
+        (pow(u, 5, P) - 2 * u * u * v * v - 2 * pow(u, 3, P) - 2 * v * v + u) % P, -1, P) % P
+    return (x, y)
+
+
+def x448_via_edwards(k_bytes, u_bytes, mul=scalarmul):
+    """X448(k, u) computed with Edwards VARIABLE-BASE multiplication: lift Q = (u, v) to P' = M->E(Q), multiply by
+    k/4 (the clamped scalar is a multiple of 4), map back: E->M([k/4]P') = [k/4][4]Q = [k]Q.  None on the twist."""
+    u = int.from_bytes(u_bytes, "little") % P
+    v = curve448_v(u)
+    if v is None or u in (0, 1, P - 1):
+        return None
+    k = x448_clamp(k_bytes)
+    out = mul(k // 4, edwards_from_curve448(u, v))
+    if out[0] == 0:
+        return (0).to_bytes(56, "little")
+    return x448_u_from_edwards(out).to_bytes(56, "little")

@@ -50,21 +50,142 @@ def test_golden_sign_and_keypair(capy, vectors):
             m.verify(kp.pub_key)
 
 
-def test_rfc8032_public_key_via_gpu(capy):
-    """RFC 8032 §7.4 test 1: A = [s]B with s from SHAKE256(sk) clamped; encoding = y with the sign of x."""
-    import hashlib
-
+def _rfc():
     with open(os.path.join(HERE, "golden", "rfc_ed448.json")) as f:
-        t = json.load(f)["rfc8032_7_4"][0]
-    h = bytearray(hashlib.shake_256(bytes.fromhex(t["secret"])).digest(114)[:57])
-    h[0] &= 0xFC
-    h[55] |= 0x80
-    h[56] = 0
-    s = int.from_bytes(h, "little")
-    xy = capy.ops.ed448_basemul_batch([s.to_bytes(56, "big")])[0]
-    enc = bytearray(xy[56:] + b"\0")
-    enc[56] |= (xy[0] & 1) << 7
-    assert bytes(enc).hex() == t["public"]
+        return json.load(f)
+
+
+def _gpu_group(capy):
+    """Group operations of the python RFC helpers (oracle/ed448_ref.py: rfc8032_verify, x448_via_edwards) routed
+    through the C ABI: fixed-base for multiples of G, variable-base otherwise, capy_ed448_add_batch for sums."""
+    from oracle import ed448_ref as E
+
+    def mul(k, pt):
+        if pt == E.G:
+            return E.pt_from_bytes(capy.ops.ed448_basemul_batch([E.sc_to_bytes(k)])[0])
+        return E.pt_from_bytes(capy.ops.ed448_scalarmul_batch([E.sc_to_bytes(k)], [E.pt_to_bytes(pt)])[0])
+
+    def var_mul(k, pt):
+        return E.pt_from_bytes(capy.ops.ed448_scalarmul_batch([E.sc_to_bytes(k)], [E.pt_to_bytes(pt)])[0])
+
+    def add(a, b):
+        return E.pt_from_bytes(capy.ops.ed448_add_batch([E.pt_to_bytes(a)], [E.pt_to_bytes(b)])[0])
+
+    return mul, var_mul, add
+
+
+def test_rfc8032_key_pairs_and_signatures_on_gpu(capy):
+    """RFC 8032 section 7.4, all nine key pairs and seven signatures, through the C ABI:
+    A = [s]B by the fixed-base kernel and by the variable-base kernel on G; the verification equation
+    [S]B = R + [k]A with [k]A on the variable-base kernel (A is not the generator) and the sum on
+    capy_ed448_add_batch; and the same equation as R = [S]B + [L-k]A on capy_ed448_double_scalarmul_batch (the shape of
+    Signable::verify, /root/reference/src/ecc/signable.rs:77)."""
+    from oracle import ed448_ref as E
+
+    H = bytes.fromhex
+    v = _rfc()["rfc8032_7_4"]
+    ss = [E.sc_to_bytes(E.rfc8032_secret_scalar(H(t["secret"]))[0]) for t in v]
+    pubs = capy.ops.ed448_basemul_batch(ss)
+    assert [E.rfc8032_encode(E.pt_from_bytes(p)).hex() for p in pubs] == [t["public"] for t in v]
+    assert capy.ops.ed448_scalarmul_batch(ss, [E.pt_to_bytes(E.G)] * len(v)) == pubs
+    mul, _, add = _gpu_group(capy)
+    sv = [t for t in v if "signature" in t]
+    assert len(sv) == 7
+    a_be, b_be, pts, rs = [], [], [], []
+    for t in sv:
+        pk, msg, sig, ctx = H(t["public"]), H(t["message"]), H(t["signature"]), H(t["context"])
+        assert E.rfc8032_verify(pk, msg, sig, ctx, mul=mul, addp=add), t["name"]
+        bad = bytearray(sig)
+        bad[100] ^= 0x10  # a different S: [S]B moves, the equation must fail
+        assert not E.rfc8032_verify(pk, msg, bytes(bad), ctx, mul=mul, addp=add)
+        k = E.rfc8032_challenge(sig[:57], pk, msg, ctx)
+        a_be.append(E.sc_to_bytes(int.from_bytes(sig[57:], "little")))
+        b_be.append(E.sc_to_bytes((E.R - k) % E.R))
+        pts.append(E.pt_to_bytes(E.rfc8032_decode(pk)))
+        rs.append(E.pt_to_bytes(E.rfc8032_decode(sig[:57])))
+    assert capy.ops.ed448_double_scalarmul_batch(a_be, b_be, pts) == rs
+
+
+def test_rfc7748_x448_through_the_variable_base_kernel(capy):
+    """RFC 7748 values reproduced with capy_ed448_scalarmul_batch through the 4-isogeny of RFC 7748 section 4.2
+    (oracle/ed448_ref.py: x448_via_edwards): both public keys and the Diffie-Hellman shared secret of section 6.2
+    (a variable-base multiplication of a non-generator point), the on-curve vector of section 5.2, and the 1000-fold
+    iteration of section 5.2: 1000 chained variable-base multiplications, every input point the previous output."""
+    from oracle import ed448_ref as E
+
+    H = bytes.fromhex
+    v = _rfc()
+    _, var_mul, _ = _gpu_group(capy)
+    d = v["rfc7748_6_2"]
+    five = (5).to_bytes(56, "little")
+    assert E.x448_via_edwards(H(d["alice_private"]), five, mul=var_mul).hex() == d["alice_public"]
+    assert E.x448_via_edwards(H(d["bob_private"]), five, mul=var_mul).hex() == d["bob_public"]
+    assert E.x448_via_edwards(H(d["alice_private"]), H(d["bob_public"]), mul=var_mul).hex() == d["shared_secret"]
+    assert E.x448_via_edwards(H(d["bob_private"]), H(d["alice_public"]), mul=var_mul).hex() == d["shared_secret"]
+    t = v["rfc7748_5_2"][0]
+    assert E.x448_via_edwards(H(t["scalar"]), H(t["u"]), mul=var_mul).hex() == t["out"]
+    it = v["rfc7748_5_2_iterated"]
+    k = u = H(it["start"])
+    for i in range(1000):
+        k, u = E.x448_via_edwards(k, u, mul=var_mul), k
+        if i == 0:
+            assert k.hex() == it["after_1"]
+    assert k.hex() == it["after_1000"]
+
+
+def test_variable_base_kernel_vs_montgomery_ladder(capy):
+    """768 random (scalar, point) pairs in one batch, points anywhere on the curve (4-torsion components included):
+    the variable-base kernel against the Montgomery ladder of RFC 7748 section 5, an algorithm that shares nothing with
+    the Edwards formulas of the kernel or of the oracle."""
+    from oracle import ed448_ref as E
+
+    rng = random.Random(0x7748)
+    ks, us, pts = [], [], []
+    while len(ks) < 768:
+        u = rng.getrandbits(448) % E.P
+        vv = E.curve448_v(u)
+        if vv is None or u in (0, 1, E.P - 1):
+            continue
+        ks.append(rng.randbytes(56))
+        us.append(u)
+        pts.append(E.pt_to_bytes(E.edwards_from_curve448(u, vv)))
+    got = capy.ops.ed448_scalarmul_batch([E.sc_to_bytes(E.x448_clamp(k) // 4) for k in ks], pts)
+    for k, u, g in zip(ks, us, got):
+        assert E.x448_u_from_edwards(E.pt_from_bytes(g)) == E.x448_ladder(E.x448_clamp(k), u)
+
+
+def test_config4_full_size_distinct_points(capy, O):
+    """BASELINE config 4 at full size with 2^18 DISTINCT points: P_i = [t_i]G from the fixed-base
+    kernel, uniform 448-bit k_i, and for EVERY item [k_i]P_i (variable-base kernel, per-lane window table in HBM)
+    must equal [k_i * t_i mod r]G (fixed-base kernel; the products are python big-ints).  Call sites:
+    /root/reference/src/ecc/encryptable.rs:37,78, src/ecc/signable.rs:77."""
+    import ctypes as C
+
+    from capycrypt_amd import _lib
+    from oracle import ed448_ref as E
+
+    lib = _lib.lib()
+    n = 1 << 18
+    rng = random.Random(0xCA9C0004)
+    tb = rng.randbytes(56 * n)
+    kb = rng.randbytes(56 * n)
+    ts = [int.from_bytes(tb[56 * i:56 * i + 56], "big") >> 2 for i in range(n)]  # 446-bit t_i
+    tb = b"".join(t.to_bytes(56, "big") for t in ts)
+    pts = (C.c_uint8 * (112 * n))()
+    _lib.check(lib.capy_ed448_basemul_batch(n, _lib.buf(tb), pts))
+    assert len(set(bytes(pts)[112 * i:112 * i + 112] for i in range(0, n, 257))) == len(range(0, n, 257))
+    out = (C.c_uint8 * (112 * n))()
+    _lib.check(lib.capy_ed448_scalarmul_batch(n, _lib.buf(kb), pts, out))
+    prod = b"".join(((int.from_bytes(kb[56 * i:56 * i + 56], "big") * ts[i]) % E.R).to_bytes(56, "big") for i in range(n))
+    exp = (C.c_uint8 * (112 * n))()
+    _lib.check(lib.capy_ed448_basemul_batch(n, _lib.buf(prod), exp))
+    got, want = bytes(out), bytes(exp)
+    if got != want:
+        bad = [i for i in range(n) if got[112 * i:112 * i + 112] != want[112 * i:112 * i + 112]]
+        raise AssertionError("%d of %d items differ, first %s" % (len(bad), n, bad[:8]))
+    raw = bytes(pts)
+    for i in (0, 1, 63, 64, 4095, 4096, n // 3, n - 2, n - 1):  # and a sample against the CPU oracle
+        assert got[112 * i:112 * i + 112] == O.ed448_scalarmul(kb[56 * i:56 * i + 56], raw[112 * i:112 * i + 112]), i
 
 
 def test_seeded_parity_vs_oracle(capy, O):

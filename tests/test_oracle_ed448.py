@@ -15,22 +15,112 @@ def test_generator_and_order():
     assert O.ed448_generator() == E.pt_to_bytes(E.G) and O.ed448_on_curve(O.ed448_generator())
 
 
-def test_rfc8032_public_keys():
+def _rfc():
     with open(os.path.join(HERE, "golden", "rfc_ed448.json")) as f:
-        v = json.load(f)
+        return json.load(f)
+
+
+H = bytes.fromhex
+
+
+def test_rfc_fixture_is_self_consistent():
+    """The published vectors were transcribed without network access: every one is machine-checked here so that a
+    transcription error cannot survive (see the fixture's _provenance).  Python big-int model for Ed448, the
+    Montgomery ladder (independent code) for X448."""
+    v = _rfc()
+    assert len(v["rfc8032_7_4"]) == 9
     for t in v["rfc8032_7_4"]:
-        assert E.rfc8032_pubkey(bytes.fromhex(t["secret"])).hex() == t["public"]
+        assert E.rfc8032_pubkey(H(t["secret"])).hex() == t["public"], t["name"]
+        if "signature" in t:
+            sig, msg, ctx = H(t["signature"]), H(t["message"]), H(t["context"])
+            assert E.rfc8032_verify(H(t["public"]), msg, sig, ctx), t["name"]
+            assert E.rfc8032_sign(H(t["secret"]), msg, ctx) == sig, t["name"]
+            bad = bytearray(sig)
+            bad[60] ^= 1
+            assert not E.rfc8032_verify(H(t["public"]), msg, bytes(bad), ctx)
+    for t in v["rfc7748_5_2"]:
+        assert E.x448(H(t["scalar"]), H(t["u"])).hex() == t["out"]
+    it = v["rfc7748_5_2_iterated"]
+    k = u = H(it["start"])
+    for i in range(1000):
+        k, u = E.x448(k, u), k
+        if i == 0:
+            assert k.hex() == it["after_1"]
+    assert k.hex() == it["after_1000"]
+    d = v["rfc7748_6_2"]
+    five = (5).to_bytes(56, "little")
+    assert E.x448(H(d["alice_private"]), five).hex() == d["alice_public"]
+    assert E.x448(H(d["bob_private"]), five).hex() == d["bob_public"]
+    assert E.x448(H(d["alice_private"]), H(d["bob_public"])).hex() == d["shared_secret"]
+    assert E.x448(H(d["bob_private"]), H(d["alice_public"])).hex() == d["shared_secret"]
 
 
-def test_rfc7748_x448():
-    with open(os.path.join(HERE, "golden", "rfc_ed448.json")) as f:
-        v = json.load(f)
-    for t in v["rfc7748_6_2"]:
-        a = bytearray(bytes.fromhex(t["private"]))
-        a[0] &= 252
-        a[55] |= 128
-        u = E.x448_u_from_edwards(E.scalarmul(int.from_bytes(a, "little"), E.G))
-        assert u.to_bytes(56, "little").hex() == t["public"]
+# --- the C port (the oracle the GPU is compared with) driven through the published vectors ---
+def _c_mul(k, pt):
+    return E.pt_from_bytes(O.ed448_scalarmul(E.sc_to_bytes(k), E.pt_to_bytes(pt)))
+
+
+def _c_mul_fixed_or_var(k, pt):
+    if pt == E.G:
+        return E.pt_from_bytes(O.ed448_basemul(E.sc_to_bytes(k)))
+    return _c_mul(k, pt)
+
+
+def _c_add(a, b):
+    return E.pt_from_bytes(O.ed448_add(E.pt_to_bytes(a), E.pt_to_bytes(b)))
+
+
+def test_c_oracle_rfc8032_keys_and_signatures():
+    """Fixed-base multiplication (public keys, [S]B), variable-base multiplication of a non-generator point ([k]A)
+    and point addition of the C oracle against RFC 8032 section 7.4."""
+    for t in _rfc()["rfc8032_7_4"]:
+        s, _ = E.rfc8032_secret_scalar(H(t["secret"]))
+        assert E.rfc8032_encode(E.pt_from_bytes(O.ed448_basemul(E.sc_to_bytes(s)))).hex() == t["public"]
+        assert E.rfc8032_encode(_c_mul(s, E.G)).hex() == t["public"]  # the variable-base routine on G
+        if "signature" in t:
+            assert E.rfc8032_verify(H(t["public"]), H(t["message"]), H(t["signature"]), H(t["context"]),
+                                    mul=_c_mul_fixed_or_var, addp=_c_add), t["name"]
+
+
+def test_c_oracle_x448_through_variable_base():
+    """RFC 7748 values reproduced with the C oracle's Edwards VARIABLE-base multiplication through the 4-isogeny of
+    RFC 7748 section 4.2: Diffie-Hellman shared secret (section 6.2), the on-curve vector of section 5.2 and the
+    1000-fold iteration -- 1000 chained multiplications of non-generator points by full-width scalars."""
+    v = _rfc()
+    d = v["rfc7748_6_2"]
+    five = (5).to_bytes(56, "little")
+    assert E.x448_via_edwards(H(d["alice_private"]), five, mul=_c_mul).hex() == d["alice_public"]
+    assert E.x448_via_edwards(H(d["alice_private"]), H(d["bob_public"]), mul=_c_mul).hex() == d["shared_secret"]
+    assert E.x448_via_edwards(H(d["bob_private"]), H(d["alice_public"]), mul=_c_mul).hex() == d["shared_secret"]
+    lifted = 0
+    for t in v["rfc7748_5_2"]:
+        got = E.x448_via_edwards(H(t["scalar"]), H(t["u"]), mul=_c_mul)
+        if got is not None:  # the second vector's u is on the twist: no Edwards point above it
+            assert got.hex() == t["out"]
+            lifted += 1
+    assert lifted == 1
+    it = v["rfc7748_5_2_iterated"]
+    k = u = H(it["start"])
+    for i in range(1000):
+        k, u = E.x448_via_edwards(k, u, mul=_c_mul), k
+        if i == 0:
+            assert k.hex() == it["after_1"]
+    assert k.hex() == it["after_1000"]
+
+
+def test_c_oracle_variable_base_vs_montgomery_ladder():
+    """Random (scalar, point) pairs: Edwards variable-base multiplication vs the Montgomery ladder, two algorithms
+    that share no code; points with and without a 4-torsion component."""
+    rng = random.Random(11)
+    n = 0
+    while n < 24:
+        u = rng.getrandbits(448) % E.P
+        if E.curve448_v(u) is None or u in (0, 1, E.P - 1):
+            continue
+        k = rng.randbytes(56)
+        ub = u.to_bytes(56, "little")
+        assert E.x448_via_edwards(k, ub, mul=_c_mul) == E.x448(k, ub)
+        n += 1
 
 
 def test_c_port_matches_python_model():
