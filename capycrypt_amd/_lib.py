@@ -27,17 +27,20 @@ SIGNATURES = {
     "capy_version": (C.c_char_p, []),
     "capy_device_count": (C.c_int, []),
     "capy_set_device": (C.c_int, [C.c_int]),
+    "capy_set_devices": (C.c_int, [vp, C.c_int]),
+    "capy_get_devices": (C.c_int, [vp, C.c_int]),
     "capy_device_synchronize": (C.c_int, []),
+    "capy_release_workspace": (C.c_int, []),
     "capy_sha3_batch": (C.c_int, [C.c_int, sz, vp, vp, vp]),
     "capy_sha3_batch_dev": (C.c_int, [C.c_int, sz, vp, vp, u64, u64, vp, vp]),
     "capy_cshake_batch": (C.c_int, [C.c_int, sz, vp, vp, sz, vp, sz, vp, sz, vp]),
     "capy_cshake_batch_dev": (C.c_int, [C.c_int, sz, vp, vp, u64, u64, sz, vp, sz, vp, sz, vp, u64, vp]),
-    "capy_kmac_xof_batch": (C.c_int, [C.c_int, sz, vp, sz, vp, vp, sz, vp, sz, vp]),
-    "capy_kmac_xof_batch_dev": (C.c_int, [C.c_int, sz, vp, sz, u64, vp, vp, u64, u64, sz, vp, sz, vp, u64, vp]),
-    "capy_sha3_encrypt_batch": (C.c_int, [C.c_int, sz, vp, sz, vp, vp, vp, vp]),
-    "capy_sha3_decrypt_batch": (C.c_int, [C.c_int, sz, vp, sz, vp, vp, vp, vp, vp]),
-    "capy_sha3_encrypt_batch_dev": (C.c_int, [C.c_int, sz, vp, sz, vp, vp, vp, u64, u64, vp, vp]),
-    "capy_sha3_decrypt_batch_dev": (C.c_int, [C.c_int, sz, vp, sz, vp, vp, vp, u64, u64, vp, vp, vp]),
+    "capy_kmac_xof_batch": (C.c_int, [C.c_int, sz, vp, sz, vp, vp, vp, sz, vp, sz, vp]),
+    "capy_kmac_xof_batch_dev": (C.c_int, [C.c_int, sz, vp, sz, u64, vp, vp, vp, u64, u64, sz, vp, sz, vp, u64, vp]),
+    "capy_sha3_encrypt_batch": (C.c_int, [C.c_int, sz, vp, sz, vp, vp, vp, vp, vp]),
+    "capy_sha3_decrypt_batch": (C.c_int, [C.c_int, sz, vp, sz, vp, vp, vp, vp, vp, vp]),
+    "capy_sha3_encrypt_batch_dev": (C.c_int, [C.c_int, sz, vp, sz, vp, u64, vp, vp, vp, u64, u64, vp, vp]),
+    "capy_sha3_decrypt_batch_dev": (C.c_int, [C.c_int, sz, vp, sz, vp, u64, vp, vp, vp, u64, u64, vp, vp, vp]),
     "capy_kem_sponge_encrypt_batch": (C.c_int, [C.c_int, sz, vp, sz, vp, vp, vp, vp]),
     "capy_kem_sponge_decrypt_batch": (C.c_int, [C.c_int, sz, vp, sz, vp, vp, vp, vp, vp]),
     "capy_ed448_scalarmul_batch": (C.c_int, [sz, vp, vp, vp]),
@@ -46,16 +49,18 @@ SIGNATURES = {
     "capy_ed448_basemul_batch_dev": (C.c_int, [sz, vp, vp, vp]),
     "capy_ed448_add_batch": (C.c_int, [sz, vp, vp, vp]),
     "capy_ed448_double_scalarmul_batch": (C.c_int, [sz, vp, vp, vp, vp]),
-    "capy_keypair_batch": (C.c_int, [C.c_int, sz, vp, sz, vp]),
-    "capy_schnorr_sign_batch": (C.c_int, [C.c_int, sz, vp, sz, vp, vp, vp, vp]),
+    "capy_ed448_validate_batch": (C.c_int, [sz, vp, vp]),
+    "capy_ed448_validate_batch_dev": (C.c_int, [sz, vp, vp, vp]),
+    "capy_keypair_batch": (C.c_int, [C.c_int, sz, vp, sz, vp, vp]),
+    "capy_schnorr_sign_batch": (C.c_int, [C.c_int, sz, vp, sz, vp, vp, vp, vp, vp]),
     "capy_schnorr_verify_batch": (C.c_int, [C.c_int, sz, vp, vp, vp, vp, vp, vp]),
     "capy_key_encrypt_batch": (C.c_int, [C.c_int, sz, vp, vp, vp, vp, vp, vp]),
-    "capy_key_decrypt_batch": (C.c_int, [C.c_int, sz, vp, sz, vp, vp, vp, vp, vp]),
-    "capy_keypair_batch_dev": (C.c_int, [C.c_int, sz, vp, sz, vp, vp]),
-    "capy_schnorr_sign_batch_dev": (C.c_int, [C.c_int, sz, vp, sz, vp, vp, u64, u64, vp, vp, vp]),
+    "capy_key_decrypt_batch": (C.c_int, [C.c_int, sz, vp, sz, vp, vp, vp, vp, vp, vp]),
+    "capy_keypair_batch_dev": (C.c_int, [C.c_int, sz, vp, sz, vp, vp, vp]),
+    "capy_schnorr_sign_batch_dev": (C.c_int, [C.c_int, sz, vp, sz, vp, vp, vp, u64, u64, vp, vp, vp]),
     "capy_schnorr_verify_batch_dev": (C.c_int, [C.c_int, sz, vp, vp, vp, u64, u64, vp, vp, vp, vp]),
     "capy_key_encrypt_batch_dev": (C.c_int, [C.c_int, sz, vp, vp, vp, vp, u64, u64, vp, vp, vp]),
-    "capy_key_decrypt_batch_dev": (C.c_int, [C.c_int, sz, vp, sz, vp, vp, vp, u64, u64, vp, vp, vp]),
+    "capy_key_decrypt_batch_dev": (C.c_int, [C.c_int, sz, vp, sz, vp, vp, vp, vp, u64, u64, vp, vp, vp]),
     "capy_set_sponge_lanes": (C.c_int, [C.c_int]),
     "capy_sha3_launch_plan": (C.c_int, [C.c_int, sz, u64, u64, vp, vp]),
     "capy_fill_random_dev": (C.c_int, [vp, u64, u64, vp]),

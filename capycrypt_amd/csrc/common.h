@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <functional>
 #include <string>
 #include <vector>
 #include "../../include/capyhip.h"
@@ -43,11 +44,14 @@ struct DevBuf {
 };
 
 // Grow-only device scratch, one set of named slots per (thread, device, stream).  All users of a slot
-// enqueue on that stream, so reuse across calls is ordered by the stream itself; growing a slot
-// frees the old block with hipFree, which synchronises the device first.  (hipMallocAsync /
-// hipFreeAsync proved unreliable on the default stream of this ROCm build: results raced.)
-enum WsSlot { WS_PRE = 0, WS_ZPW, WS_KEKA, WS_TAG2, WS_A, WS_B, WS_C, WS_D, WS_E, WS_F, WS_TABLE, WS_STATE, WS_ORDER, WS_NSLOTS };
+// enqueue on that stream, so reuse across calls is ordered by the stream itself; a slot that has to grow
+// gets a new block and the old one is retired until capy_release_workspace() / thread exit, so no call
+// ever frees (= synchronises) on the way.  (hipMallocAsync / hipFreeAsync proved unreliable on the default
+// stream of this ROCm build: results raced.)
+enum WsSlot { WS_PRE = 0, WS_ZPW, WS_ZOFF, WS_KEKA, WS_TAG2, WS_A, WS_B, WS_C, WS_D, WS_E, WS_F, WS_TABLE, WS_STATE, WS_ORDER, WS_NSLOTS };
 void *workspace(hipStream_t stream, WsSlot slot, size_t bytes);  // nullptr on allocation failure
+void workspace_release();                                           // free this thread's scratch (synchronises)
+void workspace_scrub(hipStream_t stream, WsSlot slot, size_t bytes);  // zero a slot's first bytes, stream-ordered
 
 // Messages of a host batch on the device.  If every message already starts on an 8-byte boundary the
 // packed buffer is copied as is; otherwise it is re-laid out so that every message starts on a
@@ -66,6 +70,27 @@ struct PackedBatch {
     // copy message bytes back into the caller's packed layout
     int download(size_t n, uint8_t *host_msgs, const uint64_t *host_offsets) const;
 };
+
+// ---- multi-device execution of the host-buffer entry points (capy_set_devices, include/capyhip.h).
+// Items are independent, so a batch is cut into contiguous shards, one per configured device, balanced by message
+// bytes where the call carries messages (byte_offsets: n+1 offsets) and by count otherwise; one worker thread per
+// shard selects its device and runs the single-device body on its slice of the caller's arrays.  No collective, no
+// peer traffic; output order and bytes are those of the single-device call for every device list.
+// Returns false when no device list is configured (the calling thread's current device is used).
+bool configured_devices(std::vector<int> &ids);
+int run_sharded(const std::vector<int> &ids, size_t n, const uint64_t *byte_offsets,
+                const std::function<int(size_t first, size_t count)> &body);
+// CAPY_SHARD(n, offsets, call): run `call` (an expression in `first` / `count`) on every shard when a device list is
+// configured, and return from the enclosing function with its status
+#define CAPY_SHARD(n, byte_offsets, call)                                                                       \
+    do {                                                                                                         \
+        std::vector<int> _ids;                                                                                   \
+        if (capy::configured_devices(_ids))                                                                      \
+            return capy::run_sharded(_ids, (n), (byte_offsets), [&](size_t first, size_t count) { return (call); }); \
+    } while (0)
+
+// longest per-item key / password (the per-item head builder of the kernels encodes 8*|K| in at most three bytes)
+constexpr size_t CAPY_MAX_KEY_LEN = (size_t)1 << 20;
 
 inline bool valid_d(int d) { return d == 224 || d == 256 || d == 384 || d == 512; }
 

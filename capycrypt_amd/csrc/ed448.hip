@@ -130,6 +130,13 @@ __global__ __launch_bounds__(64) void add_kernel(uint64_t n, const uint8_t *p_xy
     pt_to_affine_bytes(out_xy + i * 112, pt_add(pt_from_affine_bytes(p_xy + i * 112), pt_from_affine_bytes(q_xy + i * 112)));
 }
 
+__global__ __launch_bounds__(64) void validate_kernel(uint64_t n, const uint8_t *xy, int32_t *status)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    status[i] = pt_validate_bytes(xy + i * 112) ? CAPY_ITEM_OK : CAPY_ITEM_FAIL;
+}
+
 // affine (x, y) -> fixed-base table entry (x, y, d*x*y) in limbs
 __global__ void gtab_pack_kernel(uint32_t n, const uint8_t *xy, uint32_t *gtab)
 {
@@ -291,36 +298,37 @@ static int sc_mul4_launch(size_t n, const uint8_t *in, uint8_t *out, hipStream_t
 }
 
 // s_i = 4 * KMAC(pw_i, "", 448, "SK", d) mod r   (keypair.rs:42-43, signable.rs:41-43, ecc/encryptable.rs:76-77)
-static int derive_s_dev(int d, size_t n, const uint8_t *pws, size_t pw_len, uint8_t *s_be, hipStream_t st)
+static int derive_s_dev(int d, size_t n, const KeyView &pw, uint8_t *s_be, hipStream_t st)
 {
     MsgView none;
-    int rc = kmac_launch(d, n, pws, pw_len, pw_len, none, true, (const uint8_t *)"SK", 2, 0, s_be, 56, 56, nullptr, st);
+    int rc = kmac_launch(d, n, pw, none, true, (const uint8_t *)"SK", 2, 0, s_be, 56, 56, nullptr, st);
     if (rc) return rc;
     return sc_mul4_launch(n, s_be, s_be, st);
 }
 
 // ------------------------------------------------------------------ protocol glue on device buffers
 // Signable::sign, src/ecc/signable.rs:40-57
-static int sign_dev(int d, size_t n, const uint8_t *pws, size_t pw_len, const MsgView &m, uint8_t *h, uint8_t *z,
-                    hipStream_t st)
+static int sign_dev(int d, size_t n, const KeyView &pw, const MsgView &m, uint8_t *h, uint8_t *z, hipStream_t st)
 {
     CAPY_WS(s_be, uint8_t *, st, WS_A, n * 56);
     CAPY_WS(k_be, uint8_t *, st, WS_B, n * 56);
     CAPY_WS(U, uint8_t *, st, WS_C, n * 112);
-    int rc = derive_s_dev(d, n, pws, pw_len, s_be, st);
+    int rc = derive_s_dev(d, n, pw, s_be, st);
     if (rc) return rc;
     // k = 4 * KMAC(s_bytes, msg, 448, "N")  (`*` taken as arithmetic mod r)
-    rc = kmac_launch(d, n, s_be, 56, 56, m, true, (const uint8_t *)"N", 1, 0, k_be, 56, 56, nullptr, st);
+    rc = kmac_launch(d, n, fixed_keys(s_be, 56, 56), m, true, (const uint8_t *)"N", 1, 0, k_be, 56, 56, nullptr, st);
     if (rc) return rc;
     rc = sc_mul4_launch(n, k_be, k_be, st);
     if (rc) return rc;
     rc = fb_launch(n, k_be, U, st);  // U = k*G, affine
     if (rc) return rc;
     // h = KMAC(U.x bytes, msg, 448, "T")
-    rc = kmac_launch(d, n, U, 56, 112, m, true, (const uint8_t *)"T", 1, 0, h, 56, 56, nullptr, st);
+    rc = kmac_launch(d, n, fixed_keys(U, 56, 112), m, true, (const uint8_t *)"T", 1, 0, h, 56, 56, nullptr, st);
     if (rc) return rc;
     hipLaunchKernelGGL(sc_sign_z_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, (uint64_t)n, k_be, h, s_be, z);
     CAPY_HIP(hipGetLastError());
+    workspace_scrub(st, WS_A, n * 56);  // s
+    workspace_scrub(st, WS_B, n * 56);  // k
     return CAPY_OK;
 }
 
@@ -332,7 +340,7 @@ static int verify_dev(int d, size_t n, const uint8_t *pubs, const MsgView &m, co
     CAPY_WS(h2, uint8_t *, st, WS_A, n * 56);
     int rc = dsm_launch(n, z, h, pubs, U, st);  // U = z*G + h*V
     if (rc) return rc;
-    rc = kmac_launch(d, n, U, 56, 112, m, true, (const uint8_t *)"T", 1, 0, h2, 56, 56, nullptr, st);
+    rc = kmac_launch(d, n, fixed_keys(U, 56, 112), m, true, (const uint8_t *)"T", 1, 0, h2, 56, 56, nullptr, st);
     if (rc) return rc;
     tag_compare_launch(h, 56, h2, 56, 56, status, n, st);
     CAPY_HIP(hipGetLastError());
@@ -343,7 +351,7 @@ static int verify_dev(int d, size_t n, const uint8_t *pubs, const MsgView &m, co
 static int pk_keys_dev(int d, size_t n, const uint8_t *W, uint8_t *keka, hipStream_t st)
 {
     MsgView none;
-    return kmac_launch(d, n, W, 56, 112, none, true, (const uint8_t *)"PK", 2, 0, keka, 112, 112, nullptr, st);
+    return kmac_launch(d, n, fixed_keys(W, 56, 112), none, true, (const uint8_t *)"PK", 2, 0, keka, 112, 112, nullptr, st);
 }
 // KeyEncryptable::key_encrypt, src/ecc/encryptable.rs:34-50
 static int key_encrypt_dev(int d, size_t n, const uint8_t *pubs, const uint8_t *k_rand, const MsgView &m, uint8_t *z_xy,
@@ -361,24 +369,32 @@ static int key_encrypt_dev(int d, size_t n, const uint8_t *pubs, const uint8_t *
     rc = pk_keys_dev(d, n, W, keka, st);
     if (rc) return rc;
     // t = kmac_xof(ka, m, 448, "PKA") over the plaintext (:43), then m ^= kmac_xof(ke, "", |m|, "PKE") (:45-46)
-    return symmetric_crypt_dev(true, d, n, keka, 56, 112, m, tags, 56, "PKE", "PKA", nullptr, st);
+    rc = symmetric_crypt_dev(true, d, n, keka, 56, 112, m, tags, 56, "PKE", "PKA", nullptr, st);
+    workspace_scrub(st, WS_B, n * 56);   // the ephemeral scalar k
+    workspace_scrub(st, WS_C, n * 112);  // the shared point W
+    workspace_scrub(st, WS_D, n * 112);  // ke || ka
+    return rc;
 }
 
 // KeyEncryptable::key_decrypt, src/ecc/encryptable.rs:72-94
-static int key_decrypt_dev(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint8_t *z_xy, const MsgView &m,
+static int key_decrypt_dev(int d, size_t n, const KeyView &pw, const uint8_t *z_xy, const MsgView &m,
                            const uint8_t *tags, int32_t *status, hipStream_t st)
 {
     CAPY_WS(s_be, uint8_t *, st, WS_A, n * 56);
     CAPY_WS(W, uint8_t *, st, WS_C, n * 112);
     CAPY_WS(keka, uint8_t *, st, WS_D, n * 112);
-    int rc = derive_s_dev(d, n, pws, pw_len, s_be, st);
+    int rc = derive_s_dev(d, n, pw, s_be, st);
     if (rc) return rc;
     rc = vb_launch(n, s_be, 56, z_xy, 112, W, st);  // W = s*Z
     if (rc) return rc;
     rc = pk_keys_dev(d, n, W, keka, st);
     if (rc) return rc;
     // candidate plaintext, tag check, restore the ciphertext where the tag failed (:82-93)
-    return symmetric_crypt_dev(false, d, n, keka, 56, 112, m, const_cast<uint8_t *>(tags), 56, "PKE", "PKA", status, st);
+    rc = symmetric_crypt_dev(false, d, n, keka, 56, 112, m, const_cast<uint8_t *>(tags), 56, "PKE", "PKA", status, st);
+    workspace_scrub(st, WS_A, n * 56);   // s
+    workspace_scrub(st, WS_C, n * 112);  // W
+    workspace_scrub(st, WS_D, n * 112);  // ke || ka
+    return rc;
 }
 
 static int up(DevBuf &b, const void *src, size_t bytes)
@@ -416,6 +432,7 @@ int capy_ed448_scalarmul_batch(size_t n, const uint8_t *scalars_be, const uint8_
 {
     if (!n) return CAPY_OK;
     if (!scalars_be || !points_xy || !out_xy) return fail(CAPY_ERR_ARG, "null argument");
+    CAPY_SHARD(n, nullptr, capy_ed448_scalarmul_batch(count, scalars_be + first * 56, points_xy + first * 112, out_xy + first * 112));
     DevBuf s, p, o;
     TRY(up(s, scalars_be, n * 56));
     TRY(up(p, points_xy, n * 112));
@@ -433,6 +450,7 @@ int capy_ed448_basemul_batch(size_t n, const uint8_t *scalars_be, uint8_t *out_x
 {
     if (!n) return CAPY_OK;
     if (!scalars_be || !out_xy) return fail(CAPY_ERR_ARG, "null argument");
+    CAPY_SHARD(n, nullptr, capy_ed448_basemul_batch(count, scalars_be + first * 56, out_xy + first * 112));
     DevBuf s, o;
     TRY(up(s, scalars_be, n * 56));
     CAPY_HIP(o.alloc(n * 112));
@@ -444,6 +462,7 @@ int capy_ed448_add_batch(size_t n, const uint8_t *p_xy, const uint8_t *q_xy, uin
 {
     if (!n) return CAPY_OK;
     if (!p_xy || !q_xy || !out_xy) return fail(CAPY_ERR_ARG, "null argument");
+    CAPY_SHARD(n, nullptr, capy_ed448_add_batch(count, p_xy + first * 112, q_xy + first * 112, out_xy + first * 112));
     DevBuf p, q, o;
     TRY(up(p, p_xy, n * 112));
     TRY(up(q, q_xy, n * 112));
@@ -454,11 +473,34 @@ int capy_ed448_add_batch(size_t n, const uint8_t *p_xy, const uint8_t *q_xy, uin
     return down(out_xy, o, n * 112);
 }
 
+int capy_ed448_validate_batch_dev(size_t n, const uint8_t *points_xy, int32_t *status, void *stream)
+{
+    if (!n) return CAPY_OK;
+    if (!points_xy || !status) return fail(CAPY_ERR_ARG, "null argument");
+    hipLaunchKernelGGL(validate_kernel, grid64(n), dim3(64), 0, (hipStream_t)stream, (uint64_t)n, points_xy, status);
+    CAPY_HIP(hipGetLastError());
+    return CAPY_OK;
+}
+
+int capy_ed448_validate_batch(size_t n, const uint8_t *points_xy, int32_t *status)
+{
+    if (!n) return CAPY_OK;
+    if (!points_xy || !status) return fail(CAPY_ERR_ARG, "null argument");
+    CAPY_SHARD(n, nullptr, capy_ed448_validate_batch(count, points_xy + first * 112, status + first));
+    DevBuf p, st;
+    TRY(up(p, points_xy, n * 112));
+    CAPY_HIP(st.alloc(n * 4));
+    TRY(capy_ed448_validate_batch_dev(n, p.as<uint8_t>(), st.as<int32_t>(), nullptr));
+    return down(status, st, n * 4);
+}
+
 int capy_ed448_double_scalarmul_batch(size_t n, const uint8_t *a_be, const uint8_t *b_be, const uint8_t *points_xy,
                                       uint8_t *out_xy)
 {
     if (!n) return CAPY_OK;
     if (!a_be || !b_be || !points_xy || !out_xy) return fail(CAPY_ERR_ARG, "null argument");
+    CAPY_SHARD(n, nullptr, capy_ed448_double_scalarmul_batch(count, a_be + first * 56, b_be + first * 56, points_xy + first * 112,
+                                                             out_xy + first * 112));
     DevBuf a, b, p, o;
     TRY(up(a, a_be, n * 56));
     TRY(up(b, b_be, n * 56));
@@ -469,23 +511,34 @@ int capy_ed448_double_scalarmul_batch(size_t n, const uint8_t *a_be, const uint8
 }
 
 // ---------------------------------------------------------------- src/ecc protocols (device buffers, stream ordered)
-int capy_keypair_batch_dev(int d, size_t n, const uint8_t *pws, size_t pw_len, uint8_t *pub_xy, void *stream)
+static KeyView dev_keys(const uint8_t *pws, size_t pw_len, const uint64_t *pw_offsets)
+{
+    KeyView kv = fixed_keys(pws, pw_len, pw_len);
+    kv.key_offsets = pw_offsets;
+    return kv;
+}
+
+int capy_keypair_batch_dev(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint64_t *pw_offsets, uint8_t *pub_xy,
+                           void *stream)
 {
     if (!valid_d(d)) return fail(CAPY_ERR_UNSUPPORTED_SECPARAM, "unsupported security parameter");
     if (!n) return CAPY_OK;
     hipStream_t st = (hipStream_t)stream;
     CAPY_WS(s_be, uint8_t *, st, WS_A, n * 56);
-    TRY(derive_s_dev(d, n, pws, pw_len, s_be, st));
-    return fb_launch(n, s_be, pub_xy, st);
+    TRY(derive_s_dev(d, n, dev_keys(pws, pw_len, pw_offsets), s_be, st));
+    TRY(fb_launch(n, s_be, pub_xy, st));
+    workspace_scrub(st, WS_A, n * 56);  // the secret scalar s
+    return CAPY_OK;
 }
 
-int capy_schnorr_sign_batch_dev(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint8_t *msgs,
-                                const uint64_t *offsets, uint64_t uniform_len, uint64_t msg_stride, uint8_t *h,
-                                uint8_t *z_be, void *stream)
+int capy_schnorr_sign_batch_dev(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint64_t *pw_offsets,
+                                const uint8_t *msgs, const uint64_t *offsets, uint64_t uniform_len, uint64_t msg_stride,
+                                uint8_t *h, uint8_t *z_be, void *stream)
 {
     if (!valid_d(d)) return fail(CAPY_ERR_UNSUPPORTED_SECPARAM, "unsupported security parameter");
     if (!n) return CAPY_OK;
-    return sign_dev(d, n, pws, pw_len, view_dev(msgs, offsets, uniform_len, msg_stride), h, z_be, (hipStream_t)stream);
+    return sign_dev(d, n, dev_keys(pws, pw_len, pw_offsets), view_dev(msgs, offsets, uniform_len, msg_stride), h, z_be,
+                    (hipStream_t)stream);
 }
 
 int capy_schnorr_verify_batch_dev(int d, size_t n, const uint8_t *pub_xy, const uint8_t *msgs, const uint64_t *offsets,
@@ -508,44 +561,51 @@ int capy_key_encrypt_batch_dev(int d, size_t n, const uint8_t *pub_xy, const uin
                            (hipStream_t)stream);
 }
 
-int capy_key_decrypt_batch_dev(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint8_t *z_xy, uint8_t *msgs,
-                               const uint64_t *offsets, uint64_t uniform_len, uint64_t msg_stride, const uint8_t *tags,
-                               int32_t *status, void *stream)
+int capy_key_decrypt_batch_dev(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint64_t *pw_offsets,
+                               const uint8_t *z_xy, uint8_t *msgs, const uint64_t *offsets, uint64_t uniform_len,
+                               uint64_t msg_stride, const uint8_t *tags, int32_t *status, void *stream)
 {
     if (!valid_d(d)) return fail(CAPY_ERR_UNSUPPORTED_SECPARAM, "unsupported security parameter");
     if (!n) return CAPY_OK;
-    return key_decrypt_dev(d, n, pws, pw_len, z_xy, view_dev(msgs, offsets, uniform_len, msg_stride), tags, status,
-                           (hipStream_t)stream);
+    return key_decrypt_dev(d, n, dev_keys(pws, pw_len, pw_offsets), z_xy, view_dev(msgs, offsets, uniform_len, msg_stride),
+                           tags, status, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------- src/ecc protocols (host buffers)
-int capy_keypair_batch(int d, size_t n, const uint8_t *pws, size_t pw_len, uint8_t *pub_xy)
+int capy_keypair_batch(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint64_t *pw_offsets, uint8_t *pub_xy)
 {
     if (!valid_d(d)) return fail(CAPY_ERR_UNSUPPORTED_SECPARAM, "unsupported security parameter");
     if (!n) return CAPY_OK;
     if (!pub_xy) return fail(CAPY_ERR_ARG, "null argument");
-    DevBuf pw, s, o;
-    TRY(up(pw, pws, n * pw_len));
+    CAPY_SHARD(n, pw_offsets, capy_keypair_batch(d, count, pw_offsets ? pws : pws + first * pw_len, pw_len,
+                                                 pw_offsets ? pw_offsets + first : nullptr, pub_xy + first * 112));
+    PackedKeys pw;
+    TRY(pw.upload(n, pws, pw_len, pw_offsets));
+    DevBuf s, o;
     CAPY_HIP(s.alloc(n * 56));
     CAPY_HIP(o.alloc(n * 112));
-    TRY(derive_s_dev(d, n, pw.as<uint8_t>(), pw_len, s.as<uint8_t>(), nullptr));
+    TRY(derive_s_dev(d, n, pw.view, s.as<uint8_t>(), nullptr));
     TRY(fb_launch(n, s.as<uint8_t>(), o.as<uint8_t>(), nullptr));
     return down(pub_xy, o, n * 112);
 }
 
-int capy_schnorr_sign_batch(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint8_t *msgs,
-                            const uint64_t *offsets, uint8_t *h, uint8_t *z_be)
+int capy_schnorr_sign_batch(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint64_t *pw_offsets,
+                            const uint8_t *msgs, const uint64_t *offsets, uint8_t *h, uint8_t *z_be)
 {
     if (!valid_d(d)) return fail(CAPY_ERR_UNSUPPORTED_SECPARAM, "unsupported security parameter");
     if (!n) return CAPY_OK;
     if (!offsets || !h || !z_be) return fail(CAPY_ERR_ARG, "null argument");
+    CAPY_SHARD(n, offsets, capy_schnorr_sign_batch(d, count, pw_offsets ? pws : pws + first * pw_len, pw_len,
+                                                   pw_offsets ? pw_offsets + first : nullptr, msgs, offsets + first,
+                                                   h + first * 56, z_be + first * 56));
     PackedBatch b;
     TRY(b.upload(n, msgs, offsets));
-    DevBuf pw, dh, dz;
-    TRY(up(pw, pws, n * pw_len));
+    PackedKeys pw;
+    TRY(pw.upload(n, pws, pw_len, pw_offsets));
+    DevBuf dh, dz;
     CAPY_HIP(dh.alloc(n * 56));
     CAPY_HIP(dz.alloc(n * 56));
-    TRY(sign_dev(d, n, pw.as<uint8_t>(), pw_len, view_of(b), dh.as<uint8_t>(), dz.as<uint8_t>(), nullptr));
+    TRY(sign_dev(d, n, pw.view, view_of(b), dh.as<uint8_t>(), dz.as<uint8_t>(), nullptr));
     TRY(down(h, dh, n * 56));
     return down(z_be, dz, n * 56);
 }
@@ -556,6 +616,8 @@ int capy_schnorr_verify_batch(int d, size_t n, const uint8_t *pub_xy, const uint
     if (!valid_d(d)) return fail(CAPY_ERR_UNSUPPORTED_SECPARAM, "unsupported security parameter");
     if (!n) return CAPY_OK;
     if (!offsets || !h || !z_be || !status || !pub_xy) return fail(CAPY_ERR_ARG, "null argument");
+    CAPY_SHARD(n, offsets, capy_schnorr_verify_batch(d, count, pub_xy + first * 112, msgs, offsets + first, h + first * 56,
+                                                     z_be + first * 56, status + first));
     PackedBatch b;
     TRY(b.upload(n, msgs, offsets));
     DevBuf pk, dh, dz, st;
@@ -573,6 +635,8 @@ int capy_key_encrypt_batch(int d, size_t n, const uint8_t *pub_xy, const uint8_t
     if (!valid_d(d)) return fail(CAPY_ERR_UNSUPPORTED_SECPARAM, "unsupported security parameter");
     if (!n) return CAPY_OK;
     if (!offsets || !pub_xy || !k_rand || !z_xy || !tags) return fail(CAPY_ERR_ARG, "null argument");
+    CAPY_SHARD(n, offsets, capy_key_encrypt_batch(d, count, pub_xy + first * 112, k_rand + first * 56, msgs, offsets + first,
+                                                  z_xy + first * 112, tags + first * 56));
     PackedBatch b;
     TRY(b.upload(n, msgs, offsets));
     DevBuf pk, kr, dz, dt;
@@ -587,21 +651,24 @@ int capy_key_encrypt_batch(int d, size_t n, const uint8_t *pub_xy, const uint8_t
     return down(tags, dt, n * 56);
 }
 
-int capy_key_decrypt_batch(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint8_t *z_xy, uint8_t *msgs,
-                           const uint64_t *offsets, const uint8_t *tags, int32_t *status)
+int capy_key_decrypt_batch(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint64_t *pw_offsets,
+                           const uint8_t *z_xy, uint8_t *msgs, const uint64_t *offsets, const uint8_t *tags, int32_t *status)
 {
     if (!valid_d(d)) return fail(CAPY_ERR_UNSUPPORTED_SECPARAM, "unsupported security parameter");
     if (!n) return CAPY_OK;
     if (!offsets || !z_xy || !tags || !status) return fail(CAPY_ERR_ARG, "null argument");
+    CAPY_SHARD(n, offsets, capy_key_decrypt_batch(d, count, pw_offsets ? pws : pws + first * pw_len, pw_len,
+                                                  pw_offsets ? pw_offsets + first : nullptr, z_xy + first * 112, msgs,
+                                                  offsets + first, tags + first * 56, status + first));
     PackedBatch b;
     TRY(b.upload(n, msgs, offsets));
-    DevBuf pw, dz, dt, st;
-    TRY(up(pw, pws, n * pw_len));
+    PackedKeys pw;
+    TRY(pw.upload(n, pws, pw_len, pw_offsets));
+    DevBuf dz, dt, st;
     TRY(up(dz, z_xy, n * 112));
     TRY(up(dt, tags, n * 56));
     CAPY_HIP(st.alloc(n * 4));
-    TRY(key_decrypt_dev(d, n, pw.as<uint8_t>(), pw_len, dz.as<uint8_t>(), view_of(b), dt.as<uint8_t>(), st.as<int32_t>(),
-                        nullptr));
+    TRY(key_decrypt_dev(d, n, pw.view, dz.as<uint8_t>(), view_of(b), dt.as<uint8_t>(), st.as<int32_t>(), nullptr));
     CAPY_HIP(hipStreamSynchronize(nullptr));
     TRY(b.download(n, msgs, offsets));
     return down(status, st, n * 4);

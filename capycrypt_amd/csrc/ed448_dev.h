@@ -634,6 +634,23 @@ CAPY_HD inline bool fe_is_zero(Fe a)
 // The inversion is 446 squarings -- 7 % of a variable-base and 44 % of a fixed-base scalar multiplication.
 // A zero Z (possible only for inputs that are not curve points) is replaced by 1 in the shared product, so it cannot
 // spoil its partner; that item still gets (0, 0), exactly what pt_to_affine_bytes writes for it.
+// Input validation for points that come from outside (public keys, Z of a ciphertext): both coordinates canonical
+// (< p, i.e. re-encoding reproduces the input bytes) and x^2 + y^2 = 1 + d x^2 y^2.  The multiplication kernels do
+// not check this themselves (the group law is only meaningful on the curve); callers that accept untrusted points
+// run capy_ed448_validate_batch first.
+CAPY_HD inline bool pt_validate_bytes(const uint8_t *xy)
+{
+    const Fe x = fe_from_bytes(xy), y = fe_from_bytes(xy + 56);
+    uint8_t re[112];
+    fe_to_bytes(re, x);
+    fe_to_bytes(re + 56, y);
+    uint32_t diff = 0;
+    for (int i = 0; i < 112; i++) diff |= (uint32_t)(re[i] ^ xy[i]);
+    const Fe xx = fe_sqr(x), yy = fe_sqr(y);
+    const Fe lhs = fe_add(xx, yy), rhs = fe_add(fe_one(), fe_mul_d(fe_mul(xx, yy)));
+    return diff == 0 && fe_is_zero(fe_sub(lhs, rhs));
+}
+
 CAPY_HD inline void pt_pair_to_affine_bytes(uint8_t *xy0, uint8_t *xy1, const Pt &p0, const Pt &p1)
 {
     const bool z0_bad = fe_is_zero(p0.Z), z1_bad = fe_is_zero(p1.Z);

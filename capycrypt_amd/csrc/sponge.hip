@@ -4,6 +4,8 @@
 #include <string.h>
 #include <algorithm>
 #include <atomic>
+#include <mutex>
+#include <thread>
 #include "common.h"
 #include "sponge_launch.h"
 #include "sponge_fused.h"
@@ -21,6 +23,69 @@ int fail(int code, const std::string &msg)
     return code;
 }
 
+// ------------------------------------------------------------------ multi-device sharding (see common.h)
+static std::mutex g_dev_mu;
+static std::vector<int> g_dev_ids;  // empty: not configured
+// a worker of run_sharded never shards again (its body is the single-device form of the same entry point)
+static thread_local bool g_in_shard = false;
+
+bool configured_devices(std::vector<int> &ids)
+{
+    if (g_in_shard) return false;
+    std::lock_guard<std::mutex> lk(g_dev_mu);
+    ids = g_dev_ids;
+    return !ids.empty();
+}
+
+// contiguous shard bounds: by bytes (lengths from n+1 offsets, an item goes to the shard its midpoint falls in --
+// the rule of capycrypt_amd/sharding.py: shard_by_bytes) or by count
+static std::vector<size_t> shard_bounds(size_t n, size_t world, const uint64_t *off)
+{
+    std::vector<size_t> b(world + 1, n);
+    b[0] = 0;
+    const uint64_t total = off ? off[n] - off[0] : 0;
+    if (!off || total == 0) {
+        const size_t base = n / world, extra = n % world;
+        for (size_t r = 1; r < world; r++) b[r] = r * base + std::min(r, extra);
+        return b;
+    }
+    size_t i = 0;
+    for (size_t r = 1; r < world; r++) {
+        const long double target = (long double)total * r / world;
+        while (i < n && (long double)(off[i] - off[0]) + (long double)(off[i + 1] - off[i]) / 2 <= target) i++;
+        b[r] = i;
+    }
+    return b;
+}
+
+int run_sharded(const std::vector<int> &ids, size_t n, const uint64_t *byte_offsets,
+                const std::function<int(size_t, size_t)> &body)
+{
+    const size_t world = ids.size();
+    const std::vector<size_t> b = shard_bounds(n, world, byte_offsets);
+    std::vector<int> rcs(world, CAPY_OK);
+    std::vector<std::string> errs(world);
+    auto work = [&](size_t r) {
+        g_in_shard = true;
+        if (hipSetDevice(ids[r]) != hipSuccess) {
+            rcs[r] = CAPY_ERR_HIP;
+            errs[r] = "hipSetDevice(" + std::to_string(ids[r]) + ") failed";
+            (void)hipGetLastError();
+        } else {
+            rcs[r] = body(b[r], b[r + 1] - b[r]);
+            if (rcs[r]) errs[r] = g_err;
+        }
+        g_in_shard = false;
+    };
+    std::vector<std::thread> th;
+    for (size_t r = 0; r < world; r++)
+        if (b[r + 1] > b[r]) th.emplace_back(work, r);
+    for (auto &t : th) t.join();
+    for (size_t r = 0; r < world; r++)
+        if (rcs[r]) return fail(rcs[r], "device " + std::to_string(ids[r]) + ": " + errs[r]);
+    return CAPY_OK;
+}
+
 // ------------------------------------------------------------------ workspace
 namespace {
 struct WsEntry {
@@ -29,16 +94,24 @@ struct WsEntry {
     void *ptr[WS_NSLOTS];
     size_t cap[WS_NSLOTS];
 };
-// freed when the host thread ends (at process exit this runs before the HIP runtime's own teardown; a late hipFree
-// only returns an error)
+// One list per host thread.  A slot that has to grow gets a new, larger block; the old block is RETIRED, not freed --
+// kernels already enqueued may still use it, and hipFree would synchronise the device, which the *_dev entry points
+// promise not to do.  Retired blocks (less than the final size in total, the growth is geometric) and the live ones
+// are returned by capy_release_workspace() or when the thread ends (at process exit that runs before the HIP
+// runtime's own teardown; a late hipFree only returns an error).
 struct WsList {
     std::vector<WsEntry> v;
-    ~WsList()
+    std::vector<void *> retired;
+    void release()
     {
         for (auto &w : v)
             for (void *q : w.ptr)
                 if (q) (void)hipFree(q);
+        for (void *q : retired) (void)hipFree(q);
+        v.clear();
+        retired.clear();
     }
+    ~WsList() { release(); }
 };
 thread_local WsList g_ws_list;
 }  // namespace
@@ -57,14 +130,30 @@ void *workspace(hipStream_t stream, WsSlot slot, size_t bytes)
     }
     if (bytes == 0) bytes = 8;
     if (e->cap[slot] < bytes) {
-        if (e->ptr[slot]) (void)hipFree(e->ptr[slot]);  // synchronises outstanding work first
-        size_t cap = bytes + bytes / 4 + 256;
-        e->ptr[slot] = nullptr;
-        e->cap[slot] = 0;
-        if (hipMalloc(&e->ptr[slot], cap) != hipSuccess) return nullptr;
+        const size_t cap = bytes + bytes / 2 + 256;
+        void *fresh = nullptr;
+        if (hipMalloc(&fresh, cap) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        if (e->ptr[slot]) g_ws_list.retired.push_back(e->ptr[slot]);
+        e->ptr[slot] = fresh;
         e->cap[slot] = cap;
     }
     return e->ptr[slot];
+}
+
+void workspace_release() { g_ws_list.release(); }
+
+// Secret intermediates (z||pw, ke||ka, the Schnorr secret s and nonce k, the ECDH point W) sit in pooled scratch that
+// later, unrelated calls reuse: zero them on the same stream once the call's last reader has been enqueued.
+void workspace_scrub(hipStream_t stream, WsSlot slot, size_t bytes)
+{
+    int dev = 0;
+    if (!bytes || hipGetDevice(&dev) != hipSuccess) return;
+    for (auto &w : g_ws_list.v)
+        if (w.device == dev && w.stream == stream && w.ptr[slot])
+            (void)hipMemsetAsync(w.ptr[slot], 0, std::min(bytes, w.cap[slot]), stream);
 }
 
 #define CAPY_WS(var, type, stream, slot, bytes)                                      \
@@ -252,6 +341,7 @@ static bool mixed_plan(int rw, const SpongeParams &p, bool forced, MixedPlan &m)
 {
     const uint32_t rb = (uint32_t)rw * 8;
     if (p.out_mode != 0 || !p.absorb_body || p.offsets || p.mask || p.pre_len || p.head_len % rb || p.stride_bytes != rb) return false;
+    if (p.key_offsets) return false;  // per-item key lengths: the head block count differs per sponge
     if ((((uintptr_t)p.msgs | p.msg_stride) & 7) || p.msg_stride * 64 >= 0xfff00000ULL || p.msg_stride < p.uniform_len) return false;
     const uint64_t S = device_simds(), n = p.n;
     m.nf = p.uniform_len / rb;
@@ -365,7 +455,8 @@ static int launch_sponge(int rw, const SpongeParams &p, hipStream_t s)
         auto subrange = [&](uint64_t first, uint64_t count) {
             SpongeParams r = p;
             r.msgs = p.msgs ? p.msgs + first * p.msg_stride : nullptr;
-            r.keys = p.keys ? p.keys + first * p.key_stride : nullptr;
+            r.keys = (p.keys && !p.key_offsets) ? p.keys + first * p.key_stride : p.keys;
+            r.key_offsets = p.key_offsets ? p.key_offsets + first : nullptr;
             r.out = p.out ? p.out + first * p.out_stride : nullptr;
             r.n = count;
             return r;
@@ -406,35 +497,64 @@ static void body_args(SpongeParams &p, const MsgView &m)
     p.order = m.order;
 }
 
-// Stage the (D224-only) raw prefix bytes with the stream-ordered allocator, launch, release.
+// The (D224-only) raw prefix bytes reach the device as the ARGUMENT of a tiny kernel that writes them into the
+// stream's prefix slot: stream-ordered behind every earlier reader of the slot, no host copy and no synchronisation,
+// so the *_dev entry points stay asynchronous at D224 as well.  bytepad(encode_string("KMAC") || encode_string(S), 172)
+// is two blocks (344 bytes) for every customisation string up to 162 bytes; a longer prefix takes the synchronous copy.
+struct PreBytes {
+    uint64_t w[44];
+};
+__global__ void pre_write_kernel(const PreBytes b, uint64_t *dst, uint32_t nwords)
+{
+    const uint32_t i = threadIdx.x;
+    if (i < nwords) dst[i] = b.w[i];
+}
+
 static int launch_with_pre(int rw, SpongeParams &p, const std::vector<uint8_t> &pre_host, hipStream_t s)
 {
     if (!pre_host.empty()) {
-        // the slot may still be read by an earlier launch on this stream: drain it before overwriting
-        CAPY_HIP(hipStreamSynchronize(s));
-        CAPY_WS(pre_dev, uint8_t *, s, WS_PRE, pre_host.size());
-        CAPY_HIP(hipMemcpy(pre_dev, pre_host.data(), pre_host.size(), hipMemcpyHostToDevice));
-        p.pre = pre_dev;
+        PreBytes pb;
+        const size_t cap = std::max(pre_host.size(), sizeof pb.w);
+        if (pre_host.size() <= sizeof pb.w) {
+            // the slot is sized for the largest inline prefix up front: steady-state calls never reallocate it
+            CAPY_WS(pre_dev, uint8_t *, s, WS_PRE, cap);
+            memset(pb.w, 0, sizeof pb.w);
+            memcpy(pb.w, pre_host.data(), pre_host.size());
+            hipLaunchKernelGGL(pre_write_kernel, dim3(1), dim3(64), 0, s, pb, reinterpret_cast<uint64_t *>(pre_dev),
+                               (uint32_t)((pre_host.size() + 7) / 8));
+            CAPY_HIP(hipGetLastError());
+            p.pre = pre_dev;
+        } else {
+            CAPY_HIP(hipStreamSynchronize(s));  // an earlier launch on this stream may still read the slot
+            CAPY_WS(pre_dev, uint8_t *, s, WS_PRE, cap);
+            CAPY_HIP(hipMemcpy(pre_dev, pre_host.data(), pre_host.size(), hipMemcpyHostToDevice));
+            p.pre = pre_dev;
+        }
     }
     return launch_sponge(rw, p, s);
 }
 
 // A KMACXOF launch in all its forms (kmac_xof, shake_functions.rs:79-89): digest-style output
 // (out_mode 0) or in-place keystream XOR over the message buffer (out_mode 1, X = ""), optional mask.
-int kmac_launch(int d, size_t n, const uint8_t *keys, size_t key_len, uint64_t key_stride, const MsgView &m,
+int kmac_launch(int d, size_t n, const KeyView &kv, const MsgView &m,
                        bool absorb_body, const uint8_t *custom, size_t custom_len, int out_mode, uint8_t *outs,
                        uint64_t out_stride, size_t out_len, const int32_t *mask, hipStream_t s)
 {
     if (!valid_d(d)) return fail(CAPY_ERR_UNSUPPORTED_SECPARAM, "unsupported security parameter");
-    if (key_len > (1u << 20)) return fail(CAPY_ERR_ARG, "key too long");
+    if (kv.key_len > CAPY_MAX_KEY_LEN) return fail(CAPY_ERR_ARG, "key too long");
     Framing f = cshake_framing(d);
     SpongeParams p;
     memset(&p, 0, sizeof p);
     std::vector<uint8_t> pre_host;
     cshake_prefix(d, (const uint8_t *)"KMAC", 4, custom, custom_len, f, p, pre_host);
-    kmac_head(d, key_len, p);
-    p.keys = keys;
-    p.key_stride = key_stride;
+    if (kv.key_offsets) {  // per-item key lengths: the kernels build each item's head (item_head, sponge_params.h)
+        p.key_offsets = kv.key_offsets;
+        p.bytepad_w = (uint32_t)((1600 - d) / 8);
+    } else {
+        kmac_head(d, kv.key_len, p);
+    }
+    p.keys = kv.keys;
+    p.key_stride = kv.key_stride;
     body_args(p, m);
     p.absorb_body = absorb_body ? 1 : 0;
     p.suffix = 0x040100ULL;  // right_encode(0) = 00 01 (shake_functions.rs:86), then cSHAKE suffix 0x04 (:57)
@@ -521,6 +641,23 @@ __global__ void concat_rows_kernel(uint8_t *dst, const uint8_t *a, uint32_t a_le
         uint64_t r = i / row, c = i - r * row;
         dst[i] = c < a_len ? a[r * a_len + c] : b[r * b_len + (c - a_len)];
     }
+}
+
+// the same with one password length per item: row i = z_i (512 bytes) || pw_i, rows packed back to back;
+// row_off[i] = 512 i + (pw_off[i] - pw_off[0]).  One wave per item.
+__global__ __launch_bounds__(256) void concat_var_kernel(uint8_t *dst, uint64_t *row_off, const uint8_t *zs, const uint8_t *pws,
+                                                         const uint64_t *pw_off, uint64_t n)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 4 + threadIdx.x / 64;
+    const uint32_t lane = threadIdx.x & 63;
+    if (i > n) return;
+    const uint64_t base = pw_off[0];
+    const uint64_t o = pw_off[i] - base, row = 512 * i + o;
+    if (lane == 0) row_off[i] = row;
+    if (i == n) return;
+    const uint64_t len = pw_off[i + 1] - pw_off[i];
+    for (uint32_t c = lane; c < 512; c += 64) dst[row + c] = zs[512 * i + c];
+    for (uint64_t c = lane; c < len; c += 64) dst[row + 512 + c] = pws[base + o + c];
 }
 
 void tag_compare_launch(const uint8_t *a, uint64_t a_stride, const uint8_t *b, uint64_t b_stride, uint32_t tag_len,
@@ -666,11 +803,11 @@ int symmetric_crypt_dev(bool encrypt, int d, size_t n, const uint8_t *keka, size
     if (!valid_d(d)) return fail(CAPY_ERR_UNSUPPORTED_SECPARAM, "unsupported security parameter");
     if (n == 0) return CAPY_OK;
     auto keystream = [&](const int32_t *mask) {
-        return kmac_launch(d, n, keka, key_len, keka_stride, m, false, (const uint8_t *)ke_custom, strlen(ke_custom), 1,
-                           nullptr, 0, 0, mask, s);
+        return kmac_launch(d, n, fixed_keys(keka, key_len, keka_stride), m, false, (const uint8_t *)ke_custom,
+                           strlen(ke_custom), 1, nullptr, 0, 0, mask, s);
     };
     auto tag = [&](uint8_t *out) {
-        return kmac_launch(d, n, keka + key_len, key_len, keka_stride, m, true, (const uint8_t *)ka_custom,
+        return kmac_launch(d, n, fixed_keys(keka + key_len, key_len, keka_stride), m, true, (const uint8_t *)ka_custom,
                            strlen(ka_custom), 0, out, tag_len, tag_len, nullptr, s);
     };
     uint8_t *tag2 = nullptr;
@@ -735,26 +872,43 @@ int symmetric_crypt_dev(bool encrypt, int d, size_t n, const uint8_t *keka, size
 
 // sha3_encrypt / sha3_decrypt on device buffers (src/sha3/encryptable.rs:29-83)
 // (and the sponge half of KEMEncryptable, src/kem/encryptable.rs:47-59,84-104: same flow, tags "KEMKE"/"KEMKA")
-static int sha3_crypt_dev(bool encrypt, int d, size_t n, const uint8_t *pws, size_t pw_len, const uint8_t *zs,
+// pw: n passwords, fixed length or per item (KeyView); pws_bytes = total password bytes (sizes the scratch of the
+// per-item form without reading device memory)
+static int sha3_crypt_dev(bool encrypt, int d, size_t n, const KeyView &pw, uint64_t pws_bytes, const uint8_t *zs,
                           const MsgView &m, uint8_t *tags, int32_t *status, hipStream_t s, const char *ke_custom = "SKE",
                           const char *ka_custom = "SKA")
 {
     if (!valid_d(d)) return fail(CAPY_ERR_UNSUPPORTED_SECPARAM, "unsupported security parameter");
     if (n == 0) return CAPY_OK;
     // z || pw per item (:33-34), then ke||ka = kmac_xof(z||pw, "", 1024, "S") (:36-37)
-    const size_t zk = 512 + pw_len;
-    CAPY_WS(zpw, uint8_t *, s, WS_ZPW, n * zk);
     CAPY_WS(keka, uint8_t *, s, WS_KEKA, n * 128);
-    {
+    MsgView none;
+    int rc;
+    if (pw.key_offsets) {
+        CAPY_WS(zpw, uint8_t *, s, WS_ZPW, n * 512 + pws_bytes);
+        CAPY_WS(zoff, uint64_t *, s, WS_ZOFF, (n + 1) * 8);
+        hipLaunchKernelGGL(concat_var_kernel, dim3((unsigned)((n + 1 + 3) / 4)), dim3(256), 0, s, zpw, zoff, zs, pw.keys,
+                           pw.key_offsets, (uint64_t)n);
+        CAPY_HIP(hipGetLastError());
+        KeyView kv;
+        kv.keys = zpw;
+        kv.key_offsets = zoff;
+        rc = kmac_launch(d, n, kv, none, true, (const uint8_t *)"S", 1, 0, keka, 128, 128, nullptr, s);
+    } else {
+        const size_t zk = 512 + pw.key_len;
+        CAPY_WS(zpw, uint8_t *, s, WS_ZPW, n * zk);
         uint64_t tot = (uint64_t)n * zk;
         unsigned blocks = (unsigned)std::min<uint64_t>((tot + 255) / 256, 8192);
-        hipLaunchKernelGGL(concat_rows_kernel, dim3(blocks), dim3(256), 0, s, zpw, zs, 512u, pws, (uint32_t)pw_len,
+        hipLaunchKernelGGL(concat_rows_kernel, dim3(blocks), dim3(256), 0, s, zpw, zs, 512u, pw.keys, (uint32_t)pw.key_len,
                            (uint64_t)n);
+        CAPY_HIP(hipGetLastError());
+        rc = kmac_launch(d, n, fixed_keys(zpw, zk, zk), none, true, (const uint8_t *)"S", 1, 0, keka, 128, 128, nullptr, s);
     }
-    MsgView none;
-    int rc = kmac_launch(d, n, zpw, zk, zk, none, true, (const uint8_t *)"S", 1, 0, keka, 128, 128, nullptr, s);
     if (rc) return rc;
-    return symmetric_crypt_dev(encrypt, d, n, keka, 64, 128, m, tags, 64, ke_custom, ka_custom, status, s);
+    rc = symmetric_crypt_dev(encrypt, d, n, keka, 64, 128, m, tags, 64, ke_custom, ka_custom, status, s);
+    workspace_scrub(s, WS_ZPW, n * 512 + (pw.key_offsets ? pws_bytes : n * pw.key_len));
+    workspace_scrub(s, WS_KEKA, n * 128);
+    return rc;
 }
 
 // ------------------------------------------------------------------ bulk host <-> device copies
@@ -854,6 +1008,35 @@ int PackedBatch::download(size_t n, uint8_t *host_msgs, const uint64_t *host_off
     return CAPY_OK;
 }
 
+int PackedKeys::upload(size_t n, const uint8_t *keys, size_t key_len, const uint64_t *offsets)
+{
+    if (!offsets) {
+        if (key_len > CAPY_MAX_KEY_LEN) return fail(CAPY_ERR_ARG, "key too long");
+        total = (uint64_t)n * key_len;
+        if (total && !keys) return fail(CAPY_ERR_ARG, "null key buffer");
+        CAPY_HIP(data.alloc(total));
+        if (total) CAPY_HIP(hipMemcpy(data.p, keys, total, hipMemcpyHostToDevice));
+        view = fixed_keys(data.as<uint8_t>(), key_len, key_len);
+        return CAPY_OK;
+    }
+    std::vector<uint64_t> rel(n + 1);
+    for (size_t i = 0; i <= n; i++) {
+        if (i && offsets[i] < offsets[i - 1]) return fail(CAPY_ERR_ARG, "key offsets must be non-decreasing");
+        if (i && offsets[i] - offsets[i - 1] > CAPY_MAX_KEY_LEN) return fail(CAPY_ERR_ARG, "key too long");
+        rel[i] = offsets[i] - offsets[0];
+    }
+    total = rel[n];
+    if (total && !keys) return fail(CAPY_ERR_ARG, "null key buffer");
+    CAPY_HIP(data.alloc(total));
+    if (total) CAPY_HIP(hipMemcpy(data.p, keys + offsets[0], total, hipMemcpyHostToDevice));
+    CAPY_HIP(offs.alloc((n + 1) * 8));
+    CAPY_HIP(hipMemcpy(offs.p, rel.data(), (n + 1) * 8, hipMemcpyHostToDevice));
+    view = KeyView();
+    view.keys = data.as<uint8_t>();
+    view.key_offsets = offs.as<uint64_t>();
+    return CAPY_OK;
+}
+
 MsgView view_of(const PackedBatch &b)
 {
     MsgView m;
@@ -903,8 +1086,39 @@ int capy_set_device(int device)
     return CAPY_OK;
 }
 
+int capy_set_devices(const int *ids, int n)
+{
+    if (n < 0 || (n > 0 && !ids)) return fail(CAPY_ERR_ARG, "bad device list");
+    int have = 0;
+    if (hipGetDeviceCount(&have) != hipSuccess) have = 0;
+    for (int i = 0; i < n; i++)
+        if (ids[i] < 0 || ids[i] >= have) return fail(CAPY_ERR_ARG, "device id out of range");
+    std::lock_guard<std::mutex> lk(g_dev_mu);
+    g_dev_ids.assign(ids, ids + n);
+    return CAPY_OK;
+}
+
+int capy_get_devices(int *ids, int capacity)
+{
+    std::lock_guard<std::mutex> lk(g_dev_mu);
+    const int n = (int)g_dev_ids.size();
+    for (int i = 0; i < n && i < capacity; i++) ids[i] = g_dev_ids[i];
+    return n;
+}
+
 int capy_device_synchronize(void)
 {
+    std::vector<int> ids;
+    if (configured_devices(ids)) {
+        int cur = 0;
+        CAPY_HIP(hipGetDevice(&cur));
+        for (int id : ids) {
+            CAPY_HIP(hipSetDevice(id));
+            CAPY_HIP(hipDeviceSynchronize());
+        }
+        CAPY_HIP(hipSetDevice(cur));
+        return CAPY_OK;
+    }
     CAPY_HIP(hipDeviceSynchronize());
     return CAPY_OK;
 }
@@ -922,6 +1136,7 @@ int capy_sha3_batch(int d, size_t n, const uint8_t *msgs, const uint64_t *offset
     if (!valid_d(d)) return fail(CAPY_ERR_UNSUPPORTED_SECPARAM, "unsupported security parameter");
     if (n == 0) return CAPY_OK;
     if (!offsets || !digests) return fail(CAPY_ERR_ARG, "null argument");
+    CAPY_SHARD(n, offsets, capy_sha3_batch(d, count, msgs, offsets + first, digests + first * (size_t)(d / 8)));
     PackedBatch b;
     int rc = b.upload(n, msgs, offsets);
     if (rc) return rc;
@@ -941,6 +1156,8 @@ int capy_cshake_batch(int d, size_t n, const uint8_t *xs, const uint64_t *offset
     if (!valid_d(d)) return fail(CAPY_ERR_UNSUPPORTED_SECPARAM, "unsupported security parameter");
     if (n == 0) return CAPY_OK;
     if (!offsets || !outs) return fail(CAPY_ERR_ARG, "null argument");
+    CAPY_SHARD(n, offsets, capy_cshake_batch(d, count, xs, offsets + first, l_bits, fn_name, fn_len, custom, custom_len,
+                                             outs + first * (l_bits / 8)));
     PackedBatch b;
     int rc = b.upload(n, xs, offsets);
     if (rc) return rc;
@@ -964,20 +1181,27 @@ int capy_cshake_batch_dev(int d, size_t n, const uint8_t *xs, const uint64_t *of
 }
 
 int capy_kmac_xof_batch_dev(int d, size_t n, const uint8_t *keys, size_t key_len, uint64_t key_stride,
-                            const uint8_t *xs, const uint64_t *offsets, uint64_t uniform_len, uint64_t msg_stride,
-                            size_t l_bits, const uint8_t *custom, size_t custom_len, uint8_t *outs,
+                            const uint64_t *key_offsets, const uint8_t *xs, const uint64_t *offsets, uint64_t uniform_len,
+                            uint64_t msg_stride, size_t l_bits, const uint8_t *custom, size_t custom_len, uint8_t *outs,
                             uint64_t out_stride, void *stream)
 {
-    return kmac_launch(d, n, keys, key_len, key_stride, view_dev(xs, offsets, uniform_len, msg_stride), true, custom,
-                       custom_len, 0, outs, out_stride, l_bits / 8, nullptr, (hipStream_t)stream);
+    KeyView kv = fixed_keys(keys, key_len, key_stride);
+    kv.key_offsets = key_offsets;
+    return kmac_launch(d, n, kv, view_dev(xs, offsets, uniform_len, msg_stride), true, custom, custom_len, 0, outs,
+                       out_stride, l_bits / 8, nullptr, (hipStream_t)stream);
 }
 
-int capy_kmac_xof_batch(int d, size_t n, const uint8_t *keys, size_t key_len, const uint8_t *xs,
-                        const uint64_t *offsets, size_t l_bits, const uint8_t *custom, size_t custom_len, uint8_t *outs)
+int capy_kmac_xof_batch(int d, size_t n, const uint8_t *keys, size_t key_len, const uint64_t *key_offsets,
+                        const uint8_t *xs, const uint64_t *offsets, size_t l_bits, const uint8_t *custom, size_t custom_len,
+                        uint8_t *outs)
 {
     if (!valid_d(d)) return fail(CAPY_ERR_UNSUPPORTED_SECPARAM, "unsupported security parameter");
     if (n == 0) return CAPY_OK;
     if (!outs) return fail(CAPY_ERR_ARG, "null argument");
+    CAPY_SHARD(n, offsets,
+               capy_kmac_xof_batch(d, count, key_offsets ? keys : keys + first * key_len, key_len,
+                                   key_offsets ? key_offsets + first : nullptr, xs, offsets ? offsets + first : nullptr,
+                                   l_bits, custom, custom_len, outs + first * (l_bits / 8)));
     std::vector<uint64_t> zero_off;
     if (!offsets) {  // every x_i empty
         zero_off.assign(n + 1, 0);
@@ -986,54 +1210,68 @@ int capy_kmac_xof_batch(int d, size_t n, const uint8_t *keys, size_t key_len, co
     PackedBatch b;
     int rc = b.upload(n, xs, offsets);
     if (rc) return rc;
-    DevBuf k, out;
-    CAPY_HIP(k.alloc(n * key_len));
-    if (key_len) CAPY_HIP(hipMemcpy(k.p, keys, n * key_len, hipMemcpyHostToDevice));
+    PackedKeys k;
+    rc = k.upload(n, keys, key_len, key_offsets);
+    if (rc) return rc;
+    DevBuf out;
     const size_t ol = l_bits / 8, os = (ol + 7) & ~(size_t)7;
     CAPY_HIP(out.alloc(n * os));
-    rc = kmac_launch(d, n, k.as<uint8_t>(), key_len, key_len, view_of(b), true, custom, custom_len, 0,
-                     out.as<uint8_t>(), os, ol, nullptr, nullptr);
+    rc = kmac_launch(d, n, k.view, view_of(b), true, custom, custom_len, 0, out.as<uint8_t>(), os, ol, nullptr, nullptr);
     if (rc) return rc;
     if (ol) CAPY_HIP(hipMemcpy2D(outs, ol, out.p, os, ol, n, hipMemcpyDeviceToHost));
     return CAPY_OK;
 }
 
 // ---------------------------------------------------------------- sha3_encrypt / sha3_decrypt
-int capy_sha3_encrypt_batch_dev(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint8_t *zs, uint8_t *msgs,
-                                const uint64_t *offsets, uint64_t uniform_len, uint64_t msg_stride, uint8_t *tags,
+static KeyView dev_keys(const uint8_t *pws, size_t pw_len, const uint64_t *pw_offsets)
+{
+    KeyView kv = fixed_keys(pws, pw_len, pw_len);
+    kv.key_offsets = pw_offsets;
+    return kv;
+}
+
+int capy_sha3_encrypt_batch_dev(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint64_t *pw_offsets,
+                                uint64_t pws_bytes, const uint8_t *zs, uint8_t *msgs, const uint64_t *offsets,
+                                uint64_t uniform_len, uint64_t msg_stride, uint8_t *tags, void *stream)
+{
+    return sha3_crypt_dev(true, d, n, dev_keys(pws, pw_len, pw_offsets), pws_bytes, zs,
+                          view_dev(msgs, offsets, uniform_len, msg_stride), tags, nullptr, (hipStream_t)stream);
+}
+
+int capy_sha3_decrypt_batch_dev(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint64_t *pw_offsets,
+                                uint64_t pws_bytes, const uint8_t *zs, uint8_t *msgs, const uint64_t *offsets,
+                                uint64_t uniform_len, uint64_t msg_stride, const uint8_t *tags, int32_t *status,
                                 void *stream)
 {
-    return sha3_crypt_dev(true, d, n, pws, pw_len, zs, view_dev(msgs, offsets, uniform_len, msg_stride), tags, nullptr,
+    return sha3_crypt_dev(false, d, n, dev_keys(pws, pw_len, pw_offsets), pws_bytes, zs,
+                          view_dev(msgs, offsets, uniform_len, msg_stride), const_cast<uint8_t *>(tags), status,
                           (hipStream_t)stream);
 }
 
-int capy_sha3_decrypt_batch_dev(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint8_t *zs, uint8_t *msgs,
-                                const uint64_t *offsets, uint64_t uniform_len, uint64_t msg_stride,
-                                const uint8_t *tags, int32_t *status, void *stream)
-{
-    return sha3_crypt_dev(false, d, n, pws, pw_len, zs, view_dev(msgs, offsets, uniform_len, msg_stride),
-                          const_cast<uint8_t *>(tags), status, (hipStream_t)stream);
-}
-
-static int sha3_crypt_host(bool encrypt, int d, size_t n, const uint8_t *pws, size_t pw_len, const uint8_t *zs,
-                           uint8_t *msgs, const uint64_t *offsets, uint8_t *tags, int32_t *status,
+static int sha3_crypt_host(bool encrypt, int d, size_t n, const uint8_t *pws, size_t pw_len, const uint64_t *pw_offsets,
+                           const uint8_t *zs, uint8_t *msgs, const uint64_t *offsets, uint8_t *tags, int32_t *status,
                            const char *ke_custom = "SKE", const char *ka_custom = "SKA")
 {
     if (!valid_d(d)) return fail(CAPY_ERR_UNSUPPORTED_SECPARAM, "unsupported security parameter");
     if (n == 0) return CAPY_OK;
     if (!offsets || !zs || !tags) return fail(CAPY_ERR_ARG, "null argument");
+    CAPY_SHARD(n, offsets,
+               sha3_crypt_host(encrypt, d, count, pw_offsets ? pws : pws + first * pw_len, pw_len,
+                               pw_offsets ? pw_offsets + first : nullptr, zs + first * 512, msgs, offsets + first,
+                               tags + first * 64, status ? status + first : nullptr, ke_custom, ka_custom));
     PackedBatch b;
     int rc = b.upload(n, msgs, offsets);
     if (rc) return rc;
-    DevBuf dpw, dz, dtag, dst;
-    CAPY_HIP(dpw.alloc(n * pw_len));
+    PackedKeys dpw;
+    rc = dpw.upload(n, pws, pw_len, pw_offsets);
+    if (rc) return rc;
+    DevBuf dz, dtag, dst;
     CAPY_HIP(dz.alloc(n * 512));
     CAPY_HIP(dtag.alloc(n * 64));
     CAPY_HIP(dst.alloc(n * 4));
-    if (pw_len) CAPY_HIP(hipMemcpy(dpw.p, pws, n * pw_len, hipMemcpyHostToDevice));
     CAPY_HIP(hipMemcpy(dz.p, zs, n * 512, hipMemcpyHostToDevice));
     if (!encrypt) CAPY_HIP(hipMemcpy(dtag.p, tags, n * 64, hipMemcpyHostToDevice));
-    rc = sha3_crypt_dev(encrypt, d, n, dpw.as<uint8_t>(), pw_len, dz.as<uint8_t>(), view_of(b), dtag.as<uint8_t>(),
+    rc = sha3_crypt_dev(encrypt, d, n, dpw.view, dpw.total, dz.as<uint8_t>(), view_of(b), dtag.as<uint8_t>(),
                         dst.as<int32_t>(), nullptr, ke_custom, ka_custom);
     if (rc) return rc;
     CAPY_HIP(hipStreamSynchronize(nullptr));
@@ -1046,35 +1284,41 @@ static int sha3_crypt_host(bool encrypt, int d, size_t n, const uint8_t *pws, si
     return CAPY_OK;
 }
 
-int capy_sha3_encrypt_batch(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint8_t *zs, uint8_t *msgs,
-                            const uint64_t *offsets, uint8_t *tags)
+int capy_sha3_encrypt_batch(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint64_t *pw_offsets,
+                            const uint8_t *zs, uint8_t *msgs, const uint64_t *offsets, uint8_t *tags)
 {
-    return sha3_crypt_host(true, d, n, pws, pw_len, zs, msgs, offsets, tags, nullptr);
+    return sha3_crypt_host(true, d, n, pws, pw_len, pw_offsets, zs, msgs, offsets, tags, nullptr);
 }
 
-int capy_sha3_decrypt_batch(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint8_t *zs, uint8_t *msgs,
-                            const uint64_t *offsets, const uint8_t *tags, int32_t *status)
+int capy_sha3_decrypt_batch(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint64_t *pw_offsets,
+                            const uint8_t *zs, uint8_t *msgs, const uint64_t *offsets, const uint8_t *tags, int32_t *status)
 {
     if (!status) return fail(CAPY_ERR_ARG, "null status");
-    return sha3_crypt_host(false, d, n, pws, pw_len, zs, msgs, offsets, const_cast<uint8_t *>(tags), status);
+    return sha3_crypt_host(false, d, n, pws, pw_len, pw_offsets, zs, msgs, offsets, const_cast<uint8_t *>(tags), status);
 }
 
 // ---------------------------------------------------------------- KEMEncryptable, sponge half
 int capy_kem_sponge_encrypt_batch(int d, size_t n, const uint8_t *secrets, size_t secret_len, const uint8_t *zs,
                                   uint8_t *msgs, const uint64_t *offsets, uint8_t *tags)
 {
-    return sha3_crypt_host(true, d, n, secrets, secret_len, zs, msgs, offsets, tags, nullptr, "KEMKE", "KEMKA");
+    return sha3_crypt_host(true, d, n, secrets, secret_len, nullptr, zs, msgs, offsets, tags, nullptr, "KEMKE", "KEMKA");
 }
 
 int capy_kem_sponge_decrypt_batch(int d, size_t n, const uint8_t *secrets, size_t secret_len, const uint8_t *zs,
                                   uint8_t *msgs, const uint64_t *offsets, const uint8_t *tags, int32_t *status)
 {
     if (!status) return fail(CAPY_ERR_ARG, "null status");
-    return sha3_crypt_host(false, d, n, secrets, secret_len, zs, msgs, offsets, const_cast<uint8_t *>(tags), status,
-                           "KEMKE", "KEMKA");
+    return sha3_crypt_host(false, d, n, secrets, secret_len, nullptr, zs, msgs, offsets, const_cast<uint8_t *>(tags),
+                           status, "KEMKE", "KEMKA");
 }
 
 // ---------------------------------------------------------------- measurement helpers
+int capy_release_workspace(void)
+{
+    workspace_release();
+    return CAPY_OK;
+}
+
 int capy_set_sponge_lanes(int lanes)
 {
     g_debug_flags.store(((unsigned)lanes >> 8) & 0xff);  // undocumented A/B switches in the high bits

@@ -64,6 +64,7 @@ __global__ __launch_bounds__(64) void sponge_fused_crypt_kernel(const FusedParam
     SpongeParams p;
     p.pre = nullptr;
     p.pre_len = 0;
+    p.key_offsets = nullptr;
     p.key_len = fp.key_len;
     p.hdr_len = fp.hdr_len;
     p.hdr0 = fp.hdr0;
@@ -89,6 +90,12 @@ __global__ __launch_bounds__(64) void sponge_fused_crypt_kernel(const FusedParam
         }
         c.key = fp.keka + item * fp.keka_stride + (role == 0 ? fp.ka_offset : 0);
     }
+    // ke / ka are derived keys of one fixed length: the head is the same for every item
+    c.key_len = fp.key_len;
+    c.hdr_len = fp.hdr_len;
+    c.hdr0 = fp.hdr0;
+    c.hdr1 = fp.hdr1;
+    c.head_len = fp.head_len;
     c.len = role == 0 ? tgt_len : 0;
     c.suffix = p.suffix;
     const uint64_t total = (uint64_t)fp.head_len + c.len + 3;

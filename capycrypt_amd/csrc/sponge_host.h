@@ -14,12 +14,38 @@ struct MsgView {
     bool aligned8 = false;  // every message start is known to be 8-byte aligned
 };
 
+// where the per-item keys / passwords live on the device: n fixed-length keys (key_len bytes, key_stride apart) or,
+// with key_offsets (n+1 device offsets into keys), one length per item
+struct KeyView {
+    const uint8_t *keys = nullptr;
+    size_t key_len = 0;
+    uint64_t key_stride = 0;
+    const uint64_t *key_offsets = nullptr;
+};
+inline KeyView fixed_keys(const uint8_t *keys, size_t key_len, uint64_t key_stride)
+{
+    KeyView k;
+    k.keys = keys;
+    k.key_len = key_len;
+    k.key_stride = key_stride;
+    return k;
+}
+
+// Keys / passwords of a host batch on the device.  offsets == nullptr: n keys of key_len bytes; else n+1 host offsets
+// (non-decreasing), re-based to the first key on upload.
+struct PackedKeys {
+    DevBuf data, offs;
+    KeyView view;
+    uint64_t total = 0;  // key bytes of the batch
+    int upload(size_t n, const uint8_t *keys, size_t key_len, const uint64_t *offsets);
+};
+
 MsgView view_of(const PackedBatch &b);
 MsgView view_dev(const uint8_t *msgs, const uint64_t *offsets, uint64_t uniform_len, uint64_t msg_stride);
 
 // kmac_xof over device buffers (see sponge.hip). out_mode 0: out_len bytes per item at outs + i*out_stride;
 // out_mode 1: keystream XOR into the message buffer (absorb_body must be false). mask: optional per-item enable.
-int kmac_launch(int d, size_t n, const uint8_t *keys, size_t key_len, uint64_t key_stride, const MsgView &m,
+int kmac_launch(int d, size_t n, const KeyView &kv, const MsgView &m,
                 bool absorb_body, const uint8_t *custom, size_t custom_len, int out_mode, uint8_t *outs,
                 uint64_t out_stride, size_t out_len, const int32_t *mask, hipStream_t s);
 

@@ -92,19 +92,21 @@ __global__ __launch_bounds__(64, WAVES) void sponge_kernel(const SpongeParams p)
             tgt_len = p.uniform_len;
             c.msg = p.msgs + item * p.msg_stride;
         }
-        c.key = p.keys + item * p.key_stride;
     }
+    item_head(p, item, active, c);
     c.len = p.absorb_body ? tgt_len : 0;
     c.suffix = p.suffix;
     if (p.sha3_suffix_rule && (c.len % 136) == 135) c.suffix = (p.suffix & ~0xffULL) | 0x86;
-    const uint64_t total = (uint64_t)p.pre_len + p.head_len + c.len + p.suffix_len;
+    const uint64_t total = (uint64_t)p.pre_len + c.head_len + c.len + p.suffix_len;
     const uint32_t rem = (uint32_t)(total % p.stride_bytes);
     c.pad80 = p.fips_pad || rem != 0;
     c.padded = rem ? total + (p.stride_bytes - rem) : total;
     const uint32_t nb = active ? (uint32_t)(c.padded / p.stride_bytes) : 0;
 
-    const bool grid_aligned = ((p.pre_len + p.head_len) % RB == 0) && (p.stride_bytes == RB);  // wave-uniform
-    const uint32_t hb = grid_aligned ? (p.pre_len + p.head_len) / RB : 0;
+    const bool grid_aligned = ((p.pre_len + (p.key_offsets ? 0u : p.head_len)) % RB == 0) && (p.stride_bytes == RB);  // wave-uniform
+    // head blocks: wave-uniform unless the keys have per-item lengths (then a multiple of w = RB per lane)
+    const uint32_t hb = grid_aligned ? (p.pre_len + c.head_len) / RB : 0;
+    const uint32_t hb_max = p.key_offsets ? wave_max_u32(hb) : hb;
     const bool msg_aligned = active && grid_aligned && (((uintptr_t)c.msg & 7) == 0);
     const uint32_t nfull = (msg_aligned && p.absorb_body) ? (uint32_t)(c.len / RB) : 0;
 
@@ -132,8 +134,8 @@ __global__ __launch_bounds__(64, WAVES) void sponge_kernel(const SpongeParams p)
     }
 
     // ---------------- phase H: per-item head blocks (uniform trip count)
-    for (uint32_t b = 0; b < (resume ? 0u : hb); b++) {
-        if (active) {
+    for (uint32_t b = 0; b < (resume ? 0u : hb_max); b++) {
+        if (active && b < hb) {
 #pragma unroll
             for (int w = 0; w < RW; w++) xor_word(a, w, stream_word(p, c, (uint64_t)b * RB + 8 * w));
             keccak_cold<FULLCHIP>(a);

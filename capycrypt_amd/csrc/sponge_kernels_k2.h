@@ -157,19 +157,21 @@ __global__ __launch_bounds__(64) void sponge_kernel_k2(const SpongeParams p)
             tgt_len = p.uniform_len;
             c.msg = p.msgs + item * p.msg_stride;
         }
-        c.key = p.keys + item * p.key_stride;
     }
+    item_head(p, item, active, c);
     c.len = p.absorb_body ? tgt_len : 0;
     c.suffix = p.suffix;
     if (p.sha3_suffix_rule && (c.len % 136) == 135) c.suffix = (p.suffix & ~0xffULL) | 0x86;
-    const uint64_t total = (uint64_t)p.pre_len + p.head_len + c.len + p.suffix_len;
+    const uint64_t total = (uint64_t)p.pre_len + c.head_len + c.len + p.suffix_len;
     const uint32_t rem = (uint32_t)(total % p.stride_bytes);
     c.pad80 = p.fips_pad || rem != 0;
     c.padded = rem ? total + (p.stride_bytes - rem) : total;
     const uint32_t nb = active ? (uint32_t)(c.padded / p.stride_bytes) : 0;
 
-    const bool grid_aligned = ((p.pre_len + p.head_len) % RB == 0) && (p.stride_bytes == RB);
-    const uint32_t hb = grid_aligned ? (p.pre_len + p.head_len) / RB : 0;
+    const bool grid_aligned = ((p.pre_len + (p.key_offsets ? 0u : p.head_len)) % RB == 0) && (p.stride_bytes == RB);
+    // head blocks: wave-uniform unless the keys have per-item lengths (then a multiple of w = RB per lane)
+    const uint32_t hb = grid_aligned ? (p.pre_len + c.head_len) / RB : 0;
+    const uint32_t hb_max = p.key_offsets ? wave_max_u32(hb) : hb;
     const bool msg_aligned = active && grid_aligned && (((uintptr_t)c.msg & 7) == 0);
     const uint32_t nfull = (msg_aligned && p.absorb_body) ? (uint32_t)(c.len / RB) : 0;
 
@@ -187,8 +189,8 @@ __global__ __launch_bounds__(64) void sponge_kernel_k2(const SpongeParams p)
     };
 
     // ---------------- phase H
-    for (uint32_t b = 0; b < hb; b++)
-        if (active) absorb_slow((uint64_t)b * RB);  // a pair is active or inactive as a whole
+    for (uint32_t b = 0; b < hb_max; b++)
+        if (active && b < hb) absorb_slow((uint64_t)b * RB);  // a pair is active or inactive as a whole
 
     // ---------------- phase B: whole-wave coalesced loads, one block ahead, source pointers hoisted
     if (h == 0) {

@@ -14,6 +14,12 @@ struct SpongeParams {
     // per-item head = hdr bytes || key bytes || zeros up to head_len   (head_len = 0: no head)
     const uint8_t *keys;
     uint64_t key_stride;
+    // optional n+1 byte offsets into keys: key i = keys[key_offsets[i] .. key_offsets[i+1]), every item with its own
+    // length (the reference takes any &[u8] per message: src/ecc/signable.rs:40-43, src/sha3/hashable.rs:33-35).  The
+    // header bytes and the head length then follow from the item's key length (item_head below) and key_stride,
+    // key_len, hdr_len, hdr0/1, head_len are ignored; bytepad_w is the SP 800-185 bytepad width w.
+    const uint64_t *key_offsets;
+    uint32_t bytepad_w;
     uint32_t key_len;
     uint32_t hdr_len;
     uint64_t hdr0, hdr1;  // up to 16 header bytes, little-endian packed
@@ -60,7 +66,47 @@ struct ItemCtx {
     uint64_t padded;  // head + body + suffix + pad
     uint64_t suffix;
     bool pad80;
+    // the item's head: bytepad(encode_string(K_i), w) = hdr (hdr_len bytes of hdr0) || K_i || zeros up to head_len
+    uint32_t key_len, hdr_len, head_len;
+    uint64_t hdr0, hdr1;
 };
+
+// Fill the head fields (and the key pointer) of item `item`.  Uniform keys: copies of the launch parameters (scalar
+// registers).  Per-item keys (p.key_offsets): hdr = left_encode(w) || left_encode(8 |K_i|), built here exactly as the
+// reference's byte_pad(encode_string(k), w) does (src/sha3/aux_functions.rs:11-49, src/sha3/shake_functions.rs:84):
+// head_len = z + (w - z % w) with z = hdr_len + |K_i| (a full extra block of zeros when z is a multiple of w).
+__device__ __forceinline__ void item_head(const SpongeParams &p, uint64_t item, bool active, ItemCtx &c)
+{
+    if (p.key_offsets == nullptr) {  // wave-uniform
+        c.key = active ? p.keys + item * p.key_stride : nullptr;
+        c.key_len = p.key_len;
+        c.hdr_len = p.hdr_len;
+        c.hdr0 = p.hdr0;
+        c.hdr1 = p.hdr1;
+        c.head_len = p.head_len;
+        return;
+    }
+    uint64_t o0 = 0;
+    uint32_t klen = 0;
+    if (active) {
+        o0 = p.key_offsets[item];
+        klen = (uint32_t)(p.key_offsets[item + 1] - o0);
+    }
+    c.key = p.keys + o0;
+    c.key_len = klen;
+    const uint32_t w = p.bytepad_w, bits = klen * 8;  // w < 256, |K_i| <= 2^20 (checked on the host): bits < 2^24
+    const uint32_t nb = bits < 0x100 ? 1 : (bits < 0x10000 ? 2 : 3);
+    uint64_t h = 1 | ((uint64_t)w << 8) | ((uint64_t)nb << 16);
+    // big-endian bytes of `bits` at positions 3 .. 3+nb-1
+    const uint32_t be = nb == 1 ? bits : (nb == 2 ? ((bits >> 8) | ((bits & 0xff) << 8))
+                                                  : ((bits >> 16) | (bits & 0xff00) | ((bits & 0xff) << 16)));
+    h |= (uint64_t)be << 24;
+    c.hdr0 = h;
+    c.hdr1 = 0;
+    c.hdr_len = 3 + nb;
+    const uint32_t z = c.hdr_len + klen;
+    c.head_len = z + (w - z % w);
+}
 
 __device__ __forceinline__ uint32_t stream_byte(const SpongeParams &p, const ItemCtx &c, uint64_t pos)
 {
@@ -71,15 +117,15 @@ __device__ __forceinline__ uint32_t stream_byte(const SpongeParams &p, const Ite
         return v;
     }
     pos -= p.pre_len;
-    if (pos < p.head_len) {
-        if (pos < p.hdr_len) {
-            v = (uint32_t)((pos < 8 ? p.hdr0 >> (8 * pos) : p.hdr1 >> (8 * (pos - 8))) & 0xff);
+    if (pos < c.head_len) {
+        if (pos < c.hdr_len) {
+            v = (uint32_t)((pos < 8 ? c.hdr0 >> (8 * pos) : c.hdr1 >> (8 * (pos - 8))) & 0xff);
         } else {
-            uint64_t k = pos - p.hdr_len;
-            if (k < p.key_len) v = c.key[k];
+            uint64_t k = pos - c.hdr_len;
+            if (k < c.key_len) v = c.key[k];
         }
     } else {
-        uint64_t q = pos - p.head_len;
+        uint64_t q = pos - c.head_len;
         if (q < c.len) {
             v = c.msg[q];
         } else {
@@ -93,7 +139,7 @@ __device__ __forceinline__ uint32_t stream_byte(const SpongeParams &p, const Ite
 
 __device__ __forceinline__ uint64_t stream_word(const SpongeParams &p, const ItemCtx &c, uint64_t pos)
 {
-    const uint64_t body0 = (uint64_t)p.pre_len + p.head_len;
+    const uint64_t body0 = (uint64_t)p.pre_len + c.head_len;
     if (pos >= body0) {
         const uint64_t body_end = body0 + c.len;
         const uint8_t *a = c.msg + (pos - body0);
@@ -120,10 +166,10 @@ __device__ __forceinline__ uint64_t stream_word(const SpongeParams &p, const Ite
         }
     }
     // whole word inside the per-item key (any alignment) or inside the head's zero fill
-    if (pos >= (uint64_t)p.pre_len + p.hdr_len && pos + 8 <= body0) {
-        const uint64_t k = pos - p.pre_len - p.hdr_len;
-        if (k >= p.key_len) return 0;
-        if (k + 8 <= p.key_len) {
+    if (pos >= (uint64_t)p.pre_len + c.hdr_len && pos + 8 <= body0) {
+        const uint64_t k = pos - p.pre_len - c.hdr_len;
+        if (k >= c.key_len) return 0;
+        if (k + 8 <= c.key_len) {
             const uint8_t *a = c.key + k;
             if (((uintptr_t)a & 7) == 0) return *reinterpret_cast<const uint64_t *>(a);
             uint64_t w = 0;

@@ -11,14 +11,17 @@
 //   KeyEncryptable   key_encrypt / key_decrypt                  src/ecc/encryptable.rs:10-95
 //   kmac_xof (pub fn)                                           src/sha3/shake_functions.rs:79-89
 //
-// Every method is the batch-of-1 form of a batched GPU call; Result<(), OperationError> becomes an
-// OperationError exception.  Nonces default to std::random_device, or are injected for reproducibility.
+// Every method is the batch-of-1 form of a batched GPU call; the `*_many` free functions take a slice of Message (and
+// per-message passwords / keys of any lengths) and issue ONE batched call -- the form a GPU is worth using through.
+// Result<(), OperationError> becomes an OperationError exception.  Nonces come from the operating system's CSPRNG
+// (getrandom(2); the reference draws them from thread_rng, also a CSPRNG) or are injected for reproducibility.
 #pragma once
+#include <cerrno>
 #include <cstdint>
 #include <ctime>
 #include <optional>
-#include <random>
 #include <stdexcept>
+#include <sys/random.h>
 #include <string>
 #include <vector>
 #include "../../include/capyhip.h"
@@ -64,10 +67,18 @@ inline uint8_t *ptr(Bytes &b)
 }  // namespace detail
 
 inline Bytes get_random_bytes(size_t size)
-{  // src/sha3/aux_functions.rs:80-84
-    static thread_local std::mt19937_64 gen{std::random_device{}()};
+{  // src/sha3/aux_functions.rs:80-84: thread_rng there, the kernel CSPRNG here.  Key and nonce material (the 512-byte
+   // sha3_encrypt nonce, the ECDHIES ephemeral scalar) must never come from a seeded general-purpose generator.
     Bytes out(size);
-    for (auto &b : out) b = (uint8_t)gen();
+    size_t got = 0;
+    while (got < size) {
+        const ssize_t r = getrandom(out.data() + got, size - got, 0);
+        if (r < 0) {
+            if (errno == EINTR) continue;
+            throw std::runtime_error("getrandom failed");
+        }
+        got += (size_t)r;
+    }
     return out;
 }
 
@@ -76,7 +87,7 @@ inline Bytes kmac_xof(const Bytes &k, const Bytes &x, size_t l, const std::strin
 {
     Bytes out(l / 8);
     const uint64_t off[2] = {0, x.size()};
-    detail::check(capy_kmac_xof_batch((int)d, 1, detail::ptr(k), k.size(), detail::ptr(x), off, l,
+    detail::check(capy_kmac_xof_batch((int)d, 1, detail::ptr(k), k.size(), nullptr, detail::ptr(x), off, l,
                                       (const uint8_t *)s.data(), s.size(), detail::ptr(out)));
     return out;
 }
@@ -100,7 +111,7 @@ struct KeyPair {  // src/ecc/keypair.rs:11-22
         KeyPair kp;
         kp.owner = owner;
         kp.pub_key.resize(112);
-        detail::check(capy_keypair_batch((int)d, 1, detail::ptr(pw), pw.size(), kp.pub_key.data()));
+        detail::check(capy_keypair_batch((int)d, 1, detail::ptr(pw), pw.size(), nullptr, kp.pub_key.data()));
         kp.priv_key = pw;
         char buf[32];
         std::time_t t = std::time(nullptr);
@@ -147,7 +158,7 @@ struct Message {  // src/lib.rs:63-94; every operation is in place, as in the re
         Bytes z = z_inject ? *z_inject : get_random_bytes(512);
         const uint64_t off[2] = {0, msg.size()};
         digest.assign(64, 0);
-        detail::check(capy_sha3_encrypt_batch((int)dd, 1, detail::ptr(pw), pw.size(), z.data(), detail::ptr(msg), off,
+        detail::check(capy_sha3_encrypt_batch((int)dd, 1, detail::ptr(pw), pw.size(), nullptr, z.data(), detail::ptr(msg), off,
                                               digest.data()));
         sym_nonce = z;
     }
@@ -155,13 +166,14 @@ struct Message {  // src/lib.rs:63-94; every operation is in place, as in the re
     {  // src/sha3/encryptable.rs:58-83
         if (!d) throw OperationError("SecurityParameterNotSet");
         if (!sym_nonce) throw OperationError("SymNonceNotSet");
+        if (sym_nonce->size() != 512) throw std::invalid_argument("sym_nonce must be the 512 bytes sha3_encrypt produced");
+        if (digest.size() != 64) throw OperationError("SHA3DecryptionFailure");  // tag compare fails, msg untouched (:77)
         const uint64_t off[2] = {0, msg.size()};
         int32_t status = 0;
         Bytes tag = digest;
-        tag.resize(64);
-        detail::check(capy_sha3_decrypt_batch((int)*d, 1, detail::ptr(pw), pw.size(), sym_nonce->data(),
+        detail::check(capy_sha3_decrypt_batch((int)*d, 1, detail::ptr(pw), pw.size(), nullptr, sym_nonce->data(),
                                               detail::ptr(msg), off, tag.data(), &status));
-        if (status != CAPY_ITEM_OK || digest.size() != 64) throw OperationError("SHA3DecryptionFailure");
+        if (status != CAPY_ITEM_OK) throw OperationError("SHA3DecryptionFailure");
     }
 
     // ---- Signable
@@ -169,7 +181,7 @@ struct Message {  // src/lib.rs:63-94; every operation is in place, as in the re
     {  // src/ecc/signable.rs:40-57
         const uint64_t off[2] = {0, msg.size()};
         Signature s{Bytes(56), Bytes(56)};
-        detail::check(capy_schnorr_sign_batch((int)dd, 1, detail::ptr(key.priv_key), key.priv_key.size(),
+        detail::check(capy_schnorr_sign_batch((int)dd, 1, detail::ptr(key.priv_key), key.priv_key.size(), nullptr,
                                               detail::ptr(msg), off, s.h.data(), s.z.data()));
         sig = s;
         d = dd;
@@ -178,6 +190,8 @@ struct Message {  // src/lib.rs:63-94; every operation is in place, as in the re
     {  // src/ecc/signable.rs:72-86
         if (!sig) throw OperationError("SignatureNotSet");
         if (!d) throw OperationError("SecurityParameterNotSet");
+        if (sig->h.size() != 56 || sig->z.size() != 56 || pub_key.size() != 112)
+            throw OperationError("SignatureVerificationFailure");
         const uint64_t off[2] = {0, msg.size()};
         int32_t status = 0;
         detail::check(capy_schnorr_verify_batch((int)*d, 1, pub_key.data(), detail::ptr(msg), off, sig->h.data(),
@@ -201,14 +215,235 @@ struct Message {  // src/lib.rs:63-94; every operation is in place, as in the re
     {  // src/ecc/encryptable.rs:72-94
         if (!asym_nonce) throw OperationError("SymNonceNotSet");  // sic, :73
         if (!d) throw OperationError("SecurityParameterNotSet");
+        if (digest.size() != 56 || asym_nonce->size() != 112) throw OperationError("KeyDecryptionError");
         const uint64_t off[2] = {0, msg.size()};
         int32_t status = 0;
         Bytes tag = digest;
-        tag.resize(56);
-        detail::check(capy_key_decrypt_batch((int)*d, 1, detail::ptr(pw), pw.size(), asym_nonce->data(),
+        detail::check(capy_key_decrypt_batch((int)*d, 1, detail::ptr(pw), pw.size(), nullptr, asym_nonce->data(),
                                              detail::ptr(msg), off, tag.data(), &status));
-        if (status != CAPY_ITEM_OK || digest.size() != 56) throw OperationError("KeyDecryptionError");
+        if (status != CAPY_ITEM_OK) throw OperationError("KeyDecryptionError");
     }
 };
+
+// ------------------------------------------------------------------ batched forms: one GPU call for a slice of Message
+// (the reference API is one message at a time; a batch of one through this shim pays a whole kernel launch for one
+// sponge -- INTEGRATION.md section 6 -- so bulk callers use these).  Passwords / keys: one per message, any lengths.
+namespace detail {
+struct Packed {
+    Bytes data;
+    std::vector<uint64_t> offs;
+};
+template <class It, class Get>
+inline Packed pack(It first, It last, Get get)
+{
+    Packed p;
+    p.offs.push_back(0);
+    for (It it = first; it != last; ++it) {
+        const Bytes &b = get(*it);
+        p.data.insert(p.data.end(), b.begin(), b.end());
+        p.offs.push_back(p.data.size());
+    }
+    return p;
+}
+inline Packed pack_msgs(const std::vector<Message *> &ms)
+{
+    return pack(ms.begin(), ms.end(), [](const Message *m) -> const Bytes & { return m->msg; });
+}
+inline Packed pack_bytes(const std::vector<Bytes> &v)
+{
+    return pack(v.begin(), v.end(), [](const Bytes &b) -> const Bytes & { return b; });
+}
+inline void unpack_msgs(const Packed &p, const std::vector<Message *> &ms)
+{
+    for (size_t i = 0; i < ms.size(); i++) ms[i]->msg.assign(p.data.begin() + p.offs[i], p.data.begin() + p.offs[i + 1]);
+}
+inline void same_count(size_t a, size_t b)
+{
+    if (a != b) throw std::invalid_argument("batch arguments differ in count");
+}
+inline std::string now_string()
+{
+    char buf[32];
+    std::time_t t = std::time(nullptr);
+    std::strftime(buf, sizeof buf, "%Y-%m-%d %H:%M:%S", std::localtime(&t));
+    return buf;
+}
+}  // namespace detail
+
+inline void compute_sha3_hash_many(const std::vector<Message *> &ms, SecParam dd)
+{
+    detail::Packed p = detail::pack_msgs(ms);
+    const size_t dl = (size_t)dd / 8;
+    Bytes dig(ms.size() * dl + 1);
+    detail::check(capy_sha3_batch((int)dd, ms.size(), detail::ptr(p.data), p.offs.data(), dig.data()));
+    for (size_t i = 0; i < ms.size(); i++) {
+        Bytes &m = ms[i]->msg;  // the caller-visible suffix + pad mutation, as compute_sha3_hash
+        ms[i]->digest.assign(dig.begin() + i * dl, dig.begin() + (i + 1) * dl);
+        m.push_back((136 - m.size() % 136) == 1 ? 0x86 : 0x06);
+        const size_t r = (1600 - 2 * (size_t)dd) / 8;
+        if (m.size() % r) {
+            m.insert(m.end(), r - m.size() % r, 0);
+            m.back() = 0x80;
+        }
+    }
+}
+
+inline void sha3_encrypt_many(const std::vector<Message *> &ms, const std::vector<Bytes> &pws, SecParam dd,
+                              const std::vector<Bytes> *zs_inject = nullptr)
+{
+    detail::same_count(ms.size(), pws.size());
+    detail::Packed p = detail::pack_msgs(ms), k = detail::pack_bytes(pws);
+    Bytes zs;
+    for (size_t i = 0; i < ms.size(); i++) {
+        const Bytes z = zs_inject ? (*zs_inject)[i] : get_random_bytes(512);
+        if (z.size() != 512) throw std::invalid_argument("nonces must be 512 bytes");
+        zs.insert(zs.end(), z.begin(), z.end());
+    }
+    Bytes tags(ms.size() * 64 + 1);
+    detail::check(capy_sha3_encrypt_batch((int)dd, ms.size(), detail::ptr(k.data), 0, k.offs.data(), detail::ptr(zs),
+                                          detail::ptr(p.data), p.offs.data(), tags.data()));
+    detail::unpack_msgs(p, ms);
+    for (size_t i = 0; i < ms.size(); i++) {
+        ms[i]->digest.assign(tags.begin() + 64 * i, tags.begin() + 64 * (i + 1));
+        ms[i]->sym_nonce = Bytes(zs.begin() + 512 * i, zs.begin() + 512 * (i + 1));
+        ms[i]->d = dd;
+    }
+}
+
+// returns one flag per message: true = decrypted, false = SHA3DecryptionFailure (message left as the ciphertext)
+inline std::vector<bool> sha3_decrypt_many(const std::vector<Message *> &ms, const std::vector<Bytes> &pws)
+{
+    detail::same_count(ms.size(), pws.size());
+    if (ms.empty()) return {};
+    detail::Packed p = detail::pack_msgs(ms), k = detail::pack_bytes(pws);
+    Bytes zs, tags;
+    for (const Message *m : ms) {
+        if (!m->d || *m->d != *ms[0]->d) throw OperationError("SecurityParameterNotSet");
+        if (!m->sym_nonce) throw OperationError("SymNonceNotSet");
+        if (m->sym_nonce->size() != 512) throw std::invalid_argument("sym_nonce must be 512 bytes");
+        zs.insert(zs.end(), m->sym_nonce->begin(), m->sym_nonce->end());
+        Bytes t = m->digest;
+        t.resize(64);  // a digest of another length cannot match: flagged below
+        tags.insert(tags.end(), t.begin(), t.end());
+    }
+    std::vector<int32_t> st(ms.size(), CAPY_ITEM_FAIL);
+    detail::check(capy_sha3_decrypt_batch((int)*ms[0]->d, ms.size(), detail::ptr(k.data), 0, k.offs.data(), zs.data(),
+                                          detail::ptr(p.data), p.offs.data(), tags.data(), st.data()));
+    std::vector<bool> ok(ms.size());
+    for (size_t i = 0; i < ms.size(); i++) {
+        ok[i] = st[i] == CAPY_ITEM_OK && ms[i]->digest.size() == 64;
+        if (ok[i]) ms[i]->msg.assign(p.data.begin() + p.offs[i], p.data.begin() + p.offs[i + 1]);
+    }
+    return ok;
+}
+
+inline std::vector<KeyPair> keypair_new_many(const std::vector<Bytes> &pws, const std::string &owner, SecParam dd)
+{
+    detail::Packed k = detail::pack_bytes(pws);
+    Bytes pubs(pws.size() * 112 + 1);
+    detail::check(capy_keypair_batch((int)dd, pws.size(), detail::ptr(k.data), 0, k.offs.data(), pubs.data()));
+    std::vector<KeyPair> out(pws.size());
+    const std::string now = detail::now_string();
+    for (size_t i = 0; i < pws.size(); i++) {
+        out[i].owner = owner;
+        out[i].pub_key.assign(pubs.begin() + 112 * i, pubs.begin() + 112 * (i + 1));
+        out[i].priv_key = pws[i];
+        out[i].date_created = now;
+    }
+    return out;
+}
+
+inline void sign_many(const std::vector<Message *> &ms, const std::vector<const KeyPair *> &keys, SecParam dd)
+{
+    detail::same_count(ms.size(), keys.size());
+    detail::Packed p = detail::pack_msgs(ms);
+    detail::Packed k = detail::pack(keys.begin(), keys.end(), [](const KeyPair *kp) -> const Bytes & { return kp->priv_key; });
+    Bytes h(ms.size() * 56 + 1), z(ms.size() * 56 + 1);
+    detail::check(capy_schnorr_sign_batch((int)dd, ms.size(), detail::ptr(k.data), 0, k.offs.data(), detail::ptr(p.data),
+                                          p.offs.data(), h.data(), z.data()));
+    for (size_t i = 0; i < ms.size(); i++) {
+        ms[i]->sig = Signature{Bytes(h.begin() + 56 * i, h.begin() + 56 * (i + 1)), Bytes(z.begin() + 56 * i, z.begin() + 56 * (i + 1))};
+        ms[i]->d = dd;
+    }
+}
+
+// one flag per message: true = signature verifies
+inline std::vector<bool> verify_many(const std::vector<Message *> &ms, const std::vector<Point> &pub_keys)
+{
+    detail::same_count(ms.size(), pub_keys.size());
+    if (ms.empty()) return {};
+    detail::Packed p = detail::pack_msgs(ms);
+    Bytes pk, h, z;
+    std::vector<bool> wellformed(ms.size());
+    for (size_t i = 0; i < ms.size(); i++) {
+        if (!ms[i]->sig) throw OperationError("SignatureNotSet");
+        if (!ms[i]->d || *ms[i]->d != *ms[0]->d) throw OperationError("SecurityParameterNotSet");
+        wellformed[i] = ms[i]->sig->h.size() == 56 && ms[i]->sig->z.size() == 56 && pub_keys[i].size() == 112;
+        Bytes a = pub_keys[i], b = ms[i]->sig->h, c = ms[i]->sig->z;
+        a.resize(112);
+        b.resize(56);
+        c.resize(56);
+        pk.insert(pk.end(), a.begin(), a.end());
+        h.insert(h.end(), b.begin(), b.end());
+        z.insert(z.end(), c.begin(), c.end());
+    }
+    std::vector<int32_t> st(ms.size(), CAPY_ITEM_FAIL);
+    detail::check(capy_schnorr_verify_batch((int)*ms[0]->d, ms.size(), pk.data(), detail::ptr(p.data), p.offs.data(), h.data(),
+                                            z.data(), st.data()));
+    std::vector<bool> ok(ms.size());
+    for (size_t i = 0; i < ms.size(); i++) ok[i] = wellformed[i] && st[i] == CAPY_ITEM_OK;
+    return ok;
+}
+
+inline void key_encrypt_many(const std::vector<Message *> &ms, const std::vector<Point> &pub_keys, SecParam dd,
+                             const std::vector<Bytes> *k_inject = nullptr)
+{
+    detail::same_count(ms.size(), pub_keys.size());
+    detail::Packed p = detail::pack_msgs(ms);
+    Bytes pk, ks;
+    for (size_t i = 0; i < ms.size(); i++) {
+        if (pub_keys[i].size() != 112) throw std::invalid_argument("public keys must be 112 bytes");
+        pk.insert(pk.end(), pub_keys[i].begin(), pub_keys[i].end());
+        const Bytes k = k_inject ? (*k_inject)[i] : get_random_bytes(56);
+        if (k.size() != 56) throw std::invalid_argument("nonces must be 56 bytes");
+        ks.insert(ks.end(), k.begin(), k.end());
+    }
+    Bytes zs(ms.size() * 112 + 1), tags(ms.size() * 56 + 1);
+    detail::check(capy_key_encrypt_batch((int)dd, ms.size(), detail::ptr(pk), detail::ptr(ks), detail::ptr(p.data),
+                                         p.offs.data(), zs.data(), tags.data()));
+    detail::unpack_msgs(p, ms);
+    for (size_t i = 0; i < ms.size(); i++) {
+        ms[i]->asym_nonce = Point(zs.begin() + 112 * i, zs.begin() + 112 * (i + 1));
+        ms[i]->digest.assign(tags.begin() + 56 * i, tags.begin() + 56 * (i + 1));
+        ms[i]->d = dd;
+    }
+}
+
+// one flag per message: true = decrypted, false = KeyDecryptionError (message left as the ciphertext)
+inline std::vector<bool> key_decrypt_many(const std::vector<Message *> &ms, const std::vector<Bytes> &pws)
+{
+    detail::same_count(ms.size(), pws.size());
+    if (ms.empty()) return {};
+    detail::Packed p = detail::pack_msgs(ms), k = detail::pack_bytes(pws);
+    Bytes zs, tags;
+    for (const Message *m : ms) {
+        if (!m->asym_nonce) throw OperationError("SymNonceNotSet");  // sic, src/ecc/encryptable.rs:73
+        if (!m->d || *m->d != *ms[0]->d) throw OperationError("SecurityParameterNotSet");
+        Bytes a = *m->asym_nonce, t = m->digest;
+        a.resize(112);
+        t.resize(56);
+        zs.insert(zs.end(), a.begin(), a.end());
+        tags.insert(tags.end(), t.begin(), t.end());
+    }
+    std::vector<int32_t> st(ms.size(), CAPY_ITEM_FAIL);
+    detail::check(capy_key_decrypt_batch((int)*ms[0]->d, ms.size(), detail::ptr(k.data), 0, k.offs.data(), zs.data(),
+                                         detail::ptr(p.data), p.offs.data(), tags.data(), st.data()));
+    std::vector<bool> ok(ms.size());
+    for (size_t i = 0; i < ms.size(); i++) {
+        ok[i] = st[i] == CAPY_ITEM_OK && ms[i]->digest.size() == 56 && ms[i]->asym_nonce->size() == 112;
+        if (ok[i]) ms[i]->msg.assign(p.data.begin() + p.offs[i], p.data.begin() + p.offs[i + 1]);
+    }
+    return ok;
+}
 
 }  // namespace capycrypt

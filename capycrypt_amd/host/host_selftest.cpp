@@ -87,6 +87,61 @@ int main()
     }
     k.key_decrypt(kp.priv_key);
     EXPECT(k.msg == korig);
+    // batched forms: ragged passwords and message lengths in one call each, equal to the one-at-a-time forms
+    {
+        std::vector<Bytes> pws = {Bytes{'a'}, get_random_bytes(7), get_random_bytes(64), get_random_bytes(200), Bytes{}};
+        std::vector<Bytes> zs, ks;
+        std::vector<Message> a, b;
+        for (size_t i = 0; i < pws.size(); i++) {
+            Bytes body = get_random_bytes(1 + 977 * i);
+            a.emplace_back(body);
+            b.emplace_back(body);
+            zs.push_back(get_random_bytes(512));
+            ks.push_back(get_random_bytes(56));
+        }
+        std::vector<Message *> pa, pb;
+        for (auto &m : a) pa.push_back(&m);
+        for (auto &m : b) pb.push_back(&m);
+        sha3_encrypt_many(pa, pws, SecParam::D256, &zs);
+        for (size_t i = 0; i < b.size(); i++) b[i].sha3_encrypt(pws[i], SecParam::D256, &zs[i]);
+        for (size_t i = 0; i < b.size(); i++) EXPECT(a[i].msg == b[i].msg && a[i].digest == b[i].digest);
+        std::vector<Bytes> wrong = pws;
+        wrong[2][0] ^= 1;
+        std::vector<bool> ok = sha3_decrypt_many(pa, wrong);
+        EXPECT(ok[0] && ok[1] && !ok[2] && ok[3] && ok[4] && a[2].msg == b[2].msg);
+        std::vector<KeyPair> kps = keypair_new_many(pws, "test key", SecParam::D512);
+        std::vector<const KeyPair *> kpp;
+        std::vector<Point> pubs;
+        for (auto &k : kps) {
+            kpp.push_back(&k);
+            pubs.push_back(k.pub_key);
+        }
+        for (size_t i = 0; i < pws.size(); i++) EXPECT(kps[i].pub_key == KeyPair::new_(pws[i], "x", SecParam::D512).pub_key);
+        sign_many(pa, kpp, SecParam::D512);
+        for (size_t i = 0; i < b.size(); i++) {
+            b[i].msg = a[i].msg;
+            b[i].sign(kps[i], SecParam::D512);
+            EXPECT(a[i].sig->h == b[i].sig->h && a[i].sig->z == b[i].sig->z);
+        }
+        a[3].msg[0] ^= 1;
+        std::vector<bool> vok = verify_many(pa, pubs);
+        EXPECT(vok[0] && vok[1] && vok[2] && !vok[3] && vok[4]);
+        a[3].msg[0] ^= 1;
+        std::vector<Bytes> plain;
+        for (auto &m : a) plain.push_back(m.msg);
+        key_encrypt_many(pa, pubs, SecParam::D512, &ks);
+        std::vector<bool> kok = key_decrypt_many(pa, wrong);
+        EXPECT(kok[0] && kok[1] && !kok[2] && kok[3] && kok[4]);
+        for (size_t i = 0; i < a.size(); i++) EXPECT((a[i].msg == plain[i]) == (i != 2));
+    }
+    // the nonce source is the operating system's CSPRNG (getrandom): draws differ and are not degenerate
+    {
+        Bytes r1 = get_random_bytes(4096), r2 = get_random_bytes(4096);
+        EXPECT(r1 != r2);
+        int zeros = 0;
+        for (uint8_t c : r1) zeros += c == 0;
+        EXPECT(zeros < 64);
+    }
     // error variants
     try {
         sec_param_try_from(300);

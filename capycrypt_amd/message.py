@@ -94,6 +94,68 @@ class KeyPair:
         pub = ops.keypair_batch([bytes(pw)], d)[0]
         return KeyPair(owner, pub, bytes(pw), time.strftime("%Y-%m-%d %H:%M:%S"))
 
+    @staticmethod
+    def new_many(pws, owner, d):
+        """One batched GPU call for a list of passwords (any lengths)."""
+        d = SecParam.try_from(d)
+        now = time.strftime("%Y-%m-%d %H:%M:%S")
+        return [KeyPair(owner, pub, bytes(pw), now) for pw, pub in zip(pws, ops.keypair_batch(list(pws), d))]
+
+    # ---------------- on-disk format (src/ecc/keypair.rs:11-22, 56-77: #[derive(Serialize, Deserialize)] + serde_json,
+    # to_string_pretty).  Field order owner, pub_key, priv_key, date_created; priv_key (Vec<u8>) as an array of
+    # numbers.  `pub_key` is an ExtendedPoint of the absent curve crate, whose serde layout cannot be checked here: a
+    # value read from a reference-written file is kept verbatim and written back unchanged (the affine bytes are then
+    # recomputed from priv_key with derive_pub_key(d) -- the file does not record d); a key made here is written as
+    # the affine x||y byte array and flagged by `capyhip_curve_layout`, exactly as Message.to_json does.
+    def to_json(self):
+        import json
+
+        doc = {"owner": self.owner, "pub_key": None, "priv_key": list(self.priv_key), "date_created": self.date_created}
+        foreign = getattr(self, "_foreign", {})
+        if "pub_key" in foreign:
+            doc["pub_key"] = foreign["pub_key"]
+        else:
+            doc["pub_key"] = list(self.pub_key)
+            doc["capyhip_curve_layout"] = "bytes"
+        return json.dumps(doc, indent=2)  # serde_json::to_string_pretty: two-space indent
+
+    @staticmethod
+    def from_json(text):
+        import json
+
+        doc = json.loads(text)
+        for k in ("owner", "pub_key", "priv_key", "date_created"):
+            if k not in doc:
+                raise ValueError("KeyPair JSON: missing field %r" % k)
+        if not isinstance(doc["owner"], str) or not isinstance(doc["date_created"], str):
+            raise ValueError("KeyPair JSON: owner and date_created must be strings")
+        kp = KeyPair(doc["owner"], b"", bytes(doc["priv_key"]), doc["date_created"])
+        if doc.get("capyhip_curve_layout") == "bytes":
+            pub = bytes(doc["pub_key"])
+            if len(pub) != 112:
+                raise ValueError("KeyPair JSON: pub_key must be 112 bytes in the capyhip layout")
+            kp.pub_key = pub
+        else:
+            kp._foreign = {"pub_key": doc["pub_key"]}  # the curve crate's layout: kept verbatim
+        return kp
+
+    def derive_pub_key(self, d):
+        """Recompute the affine public key from priv_key (the password): V = [4 KMAC(pw, "", 448, "SK", d)] G,
+        src/ecc/keypair.rs:42-44.  Needed after loading a reference-written file, whose pub_key layout is opaque."""
+        self.pub_key = ops.keypair_batch([self.priv_key], SecParam.try_from(d))[0]
+        return self.pub_key
+
+    def write_to_file(self, filename):
+        """src/ecc/keypair.rs:56-59"""
+        with open(filename, "w") as f:
+            f.write(self.to_json())
+
+    @staticmethod
+    def read_from_file(filename):
+        """src/ecc/keypair.rs:70-77"""
+        with open(filename) as f:
+            return KeyPair.from_json(f.read())
+
 
 class Message:
     """src/lib.rs:63-94; all operations are in place on the Message, as in the reference."""
@@ -141,6 +203,11 @@ class Message:
             raise OperationError("SecurityParameterNotSet")
         if self.sym_nonce is None:
             raise OperationError("SymNonceNotSet")
+        if len(self.sym_nonce) != 512:
+            # the reference accepts a nonce of any length here; the C ABI carries the 512 bytes sha3_encrypt produces
+            raise ValueError("sym_nonce must be the 512 bytes sha3_encrypt produced, got %d" % len(self.sym_nonce))
+        if len(self.digest) != 64:  # `self.digest == new_tag` is false for any other length (:77), msg left as it was
+            raise OperationError("SHA3DecryptionFailure")
         out, ok = ops.sha3_decrypt_batch([bytes(pw)], [self.sym_nonce], [bytes(self.msg)], [self.digest], self.d)
         self.msg[:] = out[0]
         if not ok[0]:
@@ -160,6 +227,8 @@ class Message:
             raise OperationError("SignatureNotSet")
         if self.d is None:
             raise OperationError("SecurityParameterNotSet")
+        if len(self.sig.h) != 56 or len(self.sig.z) != 56 or len(pub_key) != 112:
+            raise OperationError("SignatureVerificationFailure")  # fields read from an untrusted file
         ok = ops.schnorr_verify_batch([pub_key], [bytes(self.msg)], [(self.sig.h, self.sig.z)], self.d)[0]
         if not ok:
             raise OperationError("SignatureVerificationFailure")
@@ -181,6 +250,8 @@ class Message:
             raise OperationError("SymNonceNotSet")  # sic: the reference reuses this variant (:73)
         if self.d is None:
             raise OperationError("SecurityParameterNotSet")
+        if len(self.digest) != 56 or len(self.asym_nonce) != 112:  # `t_p == self.digest` fails (:88), msg left as it was
+            raise OperationError("KeyDecryptionError")
         out, ok = ops.key_decrypt_batch([bytes(pw)], [self.asym_nonce], [bytes(self.msg)], [self.digest], self.d)
         self.msg[:] = out[0]
         if not ok[0]:

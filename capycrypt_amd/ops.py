@@ -1,5 +1,10 @@
 """Batched operators over the C ABI (include/capyhip.h).  Everything here runs on the GPU through
 libcapyhip.so; inputs and outputs are host bytes.  A batch of 1 equals the reference's scalar call.
+
+Every argument is checked here before a pointer reaches the library: item counts must agree and fixed-size
+fields (512-byte nonces, 64/56-byte tags, 56-byte scalars, 112-byte points) must have exactly that size
+(ValueError otherwise) -- the C ABI takes plain pointers and would read past a short buffer.  Keys and
+passwords may differ in length per item, as in the reference (any &[u8] per message).
 """
 import ctypes as C
 
@@ -10,12 +15,37 @@ def _d(d):
     return int(getattr(d, "value", d))
 
 
-def _same_len(items, what, expect=None):
-    """All byte strings of one batch argument share a length (the C ABI takes one length per call)."""
-    n = expect if expect is not None else (len(items[0]) if items else 0)
-    if any(len(x) != n for x in items):
-        raise ValueError("%s of one batch must all be %s bytes long" % (what, n if expect is not None else "equally many"))
-    return n
+def _count(n, items, what):
+    if len(items) != n:
+        raise ValueError("%s: %d given for a batch of %d" % (what, len(items), n))
+
+
+def _fixed(n, items, size, what):
+    """n byte strings of exactly `size` bytes, joined."""
+    _count(n, items, what)
+    items = [bytes(x) for x in items]
+    for x in items:
+        if len(x) != size:
+            raise ValueError("%s must be %d bytes long, got %d" % (what, size, len(x)))
+    return L.buf(b"".join(items))
+
+
+def _keys(n, keys, what):
+    """n keys / passwords of any lengths -> (buffer, fixed length, offsets or None) as the C ABI takes them:
+    equal lengths go as one key_len (the kernels' uniform path), ragged lengths as n+1 offsets."""
+    _count(n, keys, what)
+    keys = [bytes(k) for k in keys]
+    if any(len(k) > (1 << 20) for k in keys):
+        raise ValueError("%s longer than 1 MiB are not supported" % what)
+    klen = len(keys[0]) if n else 0
+    if all(len(k) == klen for k in keys):
+        return L.buf(b"".join(keys)), klen, None
+    data, offs = L.pack(keys)
+    return data, 0, offs
+
+
+def _rows(raw, n, size):
+    return [raw[size * i:size * i + size] for i in range(n)]
 
 
 def sha3_batch(msgs, d):
@@ -25,9 +55,7 @@ def sha3_batch(msgs, d):
     data, offs = L.pack(msgs)
     out = (C.c_uint8 * max(1, n * (d // 8 if d > 0 else 1)))()
     L.check(L.lib().capy_sha3_batch(d, n, data, offs, out))
-    dl = d // 8
-    raw = bytes(out)
-    return [raw[i * dl:(i + 1) * dl] for i in range(n)]
+    return _rows(bytes(out), n, d // 8)
 
 
 def cshake_batch(xs, l_bits, n_str, s_str, d):
@@ -39,180 +67,178 @@ def cshake_batch(xs, l_bits, n_str, s_str, d):
     out = (C.c_uint8 * max(1, n * ol))()
     nb, sb = bytes(n_str), bytes(s_str)
     L.check(L.lib().capy_cshake_batch(d, n, data, offs, l_bits, L.buf(nb), len(nb), L.buf(sb), len(sb), out))
-    raw = bytes(out)
-    return [raw[i * ol:(i + 1) * ol] for i in range(n)]
+    return _rows(bytes(out), n, ol)
 
 
 def kmac_xof_batch(keys, xs, l_bits, s_str, d):
-    """kmac_xof(), /root/reference/src/sha3/shake_functions.rs:79-89; all keys must have one length."""
+    """kmac_xof(), /root/reference/src/sha3/shake_functions.rs:79-89; one key per message, any lengths."""
     d = _d(d)
-    n = len(keys)
-    if len(xs) != n:
-        raise ValueError("keys and messages differ in count")
-    klen = len(keys[0]) if n else 0
-    _same_len(keys, "keys")
+    n = len(xs)
+    kbuf, klen, koffs = _keys(n, keys, "keys")
     data, offs = L.pack(xs)
     ol = l_bits // 8
     out = (C.c_uint8 * max(1, n * ol))()
     sb = bytes(s_str)
-    L.check(L.lib().capy_kmac_xof_batch(d, n, L.buf(b"".join(bytes(k) for k in keys)), klen, data, offs, l_bits,
-                                        L.buf(sb), len(sb), out))
-    raw = bytes(out)
-    return [raw[i * ol:(i + 1) * ol] for i in range(n)]
+    L.check(L.lib().capy_kmac_xof_batch(d, n, kbuf, klen, koffs, data, offs, l_bits, L.buf(sb), len(sb), out))
+    return _rows(bytes(out), n, ol)
+
+
+def _sym_encrypt(fn, keys, zs, msgs, d, what, per_item=True):
+    d = _d(d)
+    n = len(msgs)
+    kbuf, klen, koffs = _keys(n, keys, what)
+    zbuf = _fixed(n, zs, 512, "nonces")
+    data, offs = L.pack(msgs)
+    tags = (C.c_uint8 * max(1, 64 * n))()
+    if not per_item:  # the KEM entry points take one secret length per call
+        L.check(fn(d, n, kbuf, klen, zbuf, data, offs, tags))
+    else:
+        L.check(fn(d, n, kbuf, klen, koffs, zbuf, data, offs, tags))
+    raw = bytes(data)
+    return [raw[offs[i]:offs[i + 1]] for i in range(n)], _rows(bytes(tags), n, 64)
+
+
+def _sym_decrypt(fn, keys, zs, cts, tags, d, what, per_item=True):
+    d = _d(d)
+    n = len(cts)
+    kbuf, klen, koffs = _keys(n, keys, what)
+    zbuf = _fixed(n, zs, 512, "nonces")
+    tbuf = _fixed(n, tags, 64, "tags")
+    data, offs = L.pack(cts)
+    status = (C.c_int32 * max(1, n))()
+    if not per_item:
+        L.check(fn(d, n, kbuf, klen, zbuf, data, offs, tbuf, status))
+    else:
+        L.check(fn(d, n, kbuf, klen, koffs, zbuf, data, offs, tbuf, status))
+    raw = bytes(data)
+    return [raw[offs[i]:offs[i + 1]] for i in range(n)], [status[i] == 0 for i in range(n)]
 
 
 def sha3_encrypt_batch(pws, zs, msgs, d):
     """sha3_encrypt(), /root/reference/src/sha3/encryptable.rs:29-45 -> (ciphertexts, tags)."""
-    d = _d(d)
-    n = len(msgs)
-    plen = len(pws[0]) if n else 0
-    _same_len(pws, "passwords")
-    _same_len(zs, "nonces", 512)
-    data, offs = L.pack(msgs)
-    tags = (C.c_uint8 * max(1, 64 * n))()
-    L.check(L.lib().capy_sha3_encrypt_batch(d, n, L.buf(b"".join(map(bytes, pws))), plen,
-                                            L.buf(b"".join(map(bytes, zs))), data, offs, tags))
-    raw, t = bytes(data), bytes(tags)
-    return [raw[offs[i]:offs[i + 1]] for i in range(n)], [t[64 * i:64 * i + 64] for i in range(n)]
+    return _sym_encrypt(L.lib().capy_sha3_encrypt_batch, pws, zs, msgs, d, "passwords")
 
 
 def sha3_decrypt_batch(pws, zs, cts, tags, d):
     """sha3_decrypt(), /root/reference/src/sha3/encryptable.rs:58-83 -> (messages, ok flags)."""
-    d = _d(d)
-    n = len(cts)
-    plen = len(pws[0]) if n else 0
-    _same_len(pws, "passwords")
-    data, offs = L.pack(cts)
-    status = (C.c_int32 * max(1, n))()
-    L.check(L.lib().capy_sha3_decrypt_batch(d, n, L.buf(b"".join(map(bytes, pws))), plen,
-                                            L.buf(b"".join(map(bytes, zs))), data, offs,
-                                            L.buf(b"".join(map(bytes, tags))), status))
-    raw = bytes(data)
-    return [raw[offs[i]:offs[i + 1]] for i in range(n)], [status[i] == 0 for i in range(n)]
+    return _sym_decrypt(L.lib().capy_sha3_decrypt_batch, pws, zs, cts, tags, d, "passwords")
+
+
+def _kem_secrets(n, secrets):
+    _count(n, secrets, "secrets")
+    slen = len(secrets[0]) if n else 0
+    if any(len(s) != slen for s in secrets):
+        raise ValueError("secrets of one batch must all have one length (the ML-KEM shared secret)")
+    return secrets
 
 
 def kem_sponge_encrypt_batch(secrets, zs, msgs, d):
     """Sponge half of kem_encrypt(), /root/reference/src/kem/encryptable.rs:47-59 -> (ciphertexts, tags)."""
-    d = _d(d)
-    n = len(msgs)
-    slen = len(secrets[0]) if n else 0
-    _same_len(secrets, "secrets")
-    _same_len(zs, "nonces", 512)
-    data, offs = L.pack(msgs)
-    tags = (C.c_uint8 * max(1, 64 * n))()
-    L.check(L.lib().capy_kem_sponge_encrypt_batch(d, n, L.buf(b"".join(map(bytes, secrets))), slen,
-                                                  L.buf(b"".join(map(bytes, zs))), data, offs, tags))
-    raw, t = bytes(data), bytes(tags)
-    return [raw[offs[i]:offs[i + 1]] for i in range(n)], [t[64 * i:64 * i + 64] for i in range(n)]
+    return _sym_encrypt(L.lib().capy_kem_sponge_encrypt_batch, _kem_secrets(len(msgs), secrets), zs, msgs, d, "secrets",
+                        per_item=False)
 
 
 def kem_sponge_decrypt_batch(secrets, zs, cts, tags, d):
     """Sponge half of kem_decrypt(), /root/reference/src/kem/encryptable.rs:84-104 -> (messages, ok flags)."""
-    d = _d(d)
-    n = len(cts)
-    slen = len(secrets[0]) if n else 0
-    data, offs = L.pack(cts)
-    status = (C.c_int32 * max(1, n))()
-    L.check(L.lib().capy_kem_sponge_decrypt_batch(d, n, L.buf(b"".join(map(bytes, secrets))), slen,
-                                                  L.buf(b"".join(map(bytes, zs))), data, offs,
-                                                  L.buf(b"".join(map(bytes, tags))), status))
-    raw = bytes(data)
-    return [raw[offs[i]:offs[i + 1]] for i in range(n)], [status[i] == 0 for i in range(n)]
+    return _sym_decrypt(L.lib().capy_kem_sponge_decrypt_batch, _kem_secrets(len(cts), secrets), zs, cts, tags, d,
+                        "secrets", per_item=False)
 
 
 # ------------------------------------------------------------------ Ed448
 def ed448_scalarmul_batch(scalars_be, points_xy):
     n = len(scalars_be)
     out = (C.c_uint8 * max(1, 112 * n))()
-    L.check(L.lib().capy_ed448_scalarmul_batch(n, L.buf(b"".join(map(bytes, scalars_be))),
-                                               L.buf(b"".join(map(bytes, points_xy))), out))
-    raw = bytes(out)
-    return [raw[112 * i:112 * i + 112] for i in range(n)]
+    L.check(L.lib().capy_ed448_scalarmul_batch(n, _fixed(n, scalars_be, 56, "scalars"),
+                                               _fixed(n, points_xy, 112, "points"), out))
+    return _rows(bytes(out), n, 112)
 
 
 def ed448_basemul_batch(scalars_be):
     n = len(scalars_be)
     out = (C.c_uint8 * max(1, 112 * n))()
-    L.check(L.lib().capy_ed448_basemul_batch(n, L.buf(b"".join(map(bytes, scalars_be))), out))
-    raw = bytes(out)
-    return [raw[112 * i:112 * i + 112] for i in range(n)]
+    L.check(L.lib().capy_ed448_basemul_batch(n, _fixed(n, scalars_be, 56, "scalars"), out))
+    return _rows(bytes(out), n, 112)
 
 
 def ed448_add_batch(ps, qs):
     n = len(ps)
     out = (C.c_uint8 * max(1, 112 * n))()
-    L.check(L.lib().capy_ed448_add_batch(n, L.buf(b"".join(map(bytes, ps))), L.buf(b"".join(map(bytes, qs))), out))
-    raw = bytes(out)
-    return [raw[112 * i:112 * i + 112] for i in range(n)]
+    L.check(L.lib().capy_ed448_add_batch(n, _fixed(n, ps, 112, "points"), _fixed(n, qs, 112, "points"), out))
+    return _rows(bytes(out), n, 112)
 
 
 def ed448_double_scalarmul_batch(a_be, b_be, points_xy):
     n = len(a_be)
     out = (C.c_uint8 * max(1, 112 * n))()
-    L.check(L.lib().capy_ed448_double_scalarmul_batch(n, L.buf(b"".join(map(bytes, a_be))),
-                                                      L.buf(b"".join(map(bytes, b_be))),
-                                                      L.buf(b"".join(map(bytes, points_xy))), out))
-    raw = bytes(out)
-    return [raw[112 * i:112 * i + 112] for i in range(n)]
+    L.check(L.lib().capy_ed448_double_scalarmul_batch(n, _fixed(n, a_be, 56, "scalars"), _fixed(n, b_be, 56, "scalars"),
+                                                      _fixed(n, points_xy, 112, "points"), out))
+    return _rows(bytes(out), n, 112)
+
+
+def ed448_validate_batch(points_xy):
+    """True per point iff both coordinates are canonical (< p) and the point is on the curve."""
+    n = len(points_xy)
+    status = (C.c_int32 * max(1, n))()
+    L.check(L.lib().capy_ed448_validate_batch(n, _fixed(n, points_xy, 112, "points"), status))
+    return [status[i] == 0 for i in range(n)]
 
 
 def keypair_batch(pws, d):
+    """KeyPair::new, /root/reference/src/ecc/keypair.rs:41-51 -> public keys; one password per key, any lengths."""
     d = _d(d)
     n = len(pws)
-    plen = len(pws[0]) if n else 0
-    _same_len(pws, "passwords")
+    pbuf, plen, poffs = _keys(n, pws, "passwords")
     out = (C.c_uint8 * max(1, 112 * n))()
-    L.check(L.lib().capy_keypair_batch(d, n, L.buf(b"".join(map(bytes, pws))), plen, out))
-    raw = bytes(out)
-    return [raw[112 * i:112 * i + 112] for i in range(n)]
+    L.check(L.lib().capy_keypair_batch(d, n, pbuf, plen, poffs, out))
+    return _rows(bytes(out), n, 112)
 
 
 def schnorr_sign_batch(pws, msgs, d):
+    """Signable::sign, /root/reference/src/ecc/signable.rs:40-57 -> [(h, z)]."""
     d = _d(d)
     n = len(msgs)
-    plen = len(pws[0]) if n else 0
-    _same_len(pws, "passwords")
+    pbuf, plen, poffs = _keys(n, pws, "passwords")
     data, offs = L.pack(msgs)
     h = (C.c_uint8 * max(1, 56 * n))()
     z = (C.c_uint8 * max(1, 56 * n))()
-    L.check(L.lib().capy_schnorr_sign_batch(d, n, L.buf(b"".join(map(bytes, pws))), plen, data, offs, h, z))
-    hb, zb = bytes(h), bytes(z)
-    return [(hb[56 * i:56 * i + 56], zb[56 * i:56 * i + 56]) for i in range(n)]
+    L.check(L.lib().capy_schnorr_sign_batch(d, n, pbuf, plen, poffs, data, offs, h, z))
+    return list(zip(_rows(bytes(h), n, 56), _rows(bytes(z), n, 56)))
 
 
 def schnorr_verify_batch(pubs, msgs, sigs, d):
+    """Signable::verify, /root/reference/src/ecc/signable.rs:72-86 -> ok flags."""
     d = _d(d)
     n = len(msgs)
+    _count(n, sigs, "signatures")
     data, offs = L.pack(msgs)
     status = (C.c_int32 * max(1, n))()
-    L.check(L.lib().capy_schnorr_verify_batch(d, n, L.buf(b"".join(map(bytes, pubs))), data, offs,
-                                              L.buf(b"".join(bytes(s[0]) for s in sigs)),
-                                              L.buf(b"".join(bytes(s[1]) for s in sigs)), status))
+    L.check(L.lib().capy_schnorr_verify_batch(d, n, _fixed(n, pubs, 112, "public keys"), data, offs,
+                                              _fixed(n, [s[0] for s in sigs], 56, "signature hashes"),
+                                              _fixed(n, [s[1] for s in sigs], 56, "signature scalars"), status))
     return [status[i] == 0 for i in range(n)]
 
 
 def key_encrypt_batch(pubs, k_rands, msgs, d):
+    """KeyEncryptable::key_encrypt, /root/reference/src/ecc/encryptable.rs:34-50 -> (ciphertexts, Z points, tags)."""
     d = _d(d)
     n = len(msgs)
     data, offs = L.pack(msgs)
     zxy = (C.c_uint8 * max(1, 112 * n))()
     tags = (C.c_uint8 * max(1, 56 * n))()
-    L.check(L.lib().capy_key_encrypt_batch(d, n, L.buf(b"".join(map(bytes, pubs))),
-                                           L.buf(b"".join(map(bytes, k_rands))), data, offs, zxy, tags))
-    raw, zb, tb = bytes(data), bytes(zxy), bytes(tags)
-    return ([raw[offs[i]:offs[i + 1]] for i in range(n)], [zb[112 * i:112 * i + 112] for i in range(n)],
-            [tb[56 * i:56 * i + 56] for i in range(n)])
+    L.check(L.lib().capy_key_encrypt_batch(d, n, _fixed(n, pubs, 112, "public keys"), _fixed(n, k_rands, 56, "nonces"),
+                                           data, offs, zxy, tags))
+    raw = bytes(data)
+    return ([raw[offs[i]:offs[i + 1]] for i in range(n)], _rows(bytes(zxy), n, 112), _rows(bytes(tags), n, 56))
 
 
 def key_decrypt_batch(pws, zxys, cts, tags, d):
+    """KeyEncryptable::key_decrypt, /root/reference/src/ecc/encryptable.rs:72-94 -> (messages, ok flags)."""
     d = _d(d)
     n = len(cts)
-    plen = len(pws[0]) if n else 0
-    _same_len(pws, "passwords")
+    pbuf, plen, poffs = _keys(n, pws, "passwords")
     data, offs = L.pack(cts)
     status = (C.c_int32 * max(1, n))()
-    L.check(L.lib().capy_key_decrypt_batch(d, n, L.buf(b"".join(map(bytes, pws))), plen,
-                                           L.buf(b"".join(map(bytes, zxys))), data, offs,
-                                           L.buf(b"".join(map(bytes, tags))), status))
+    L.check(L.lib().capy_key_decrypt_batch(d, n, pbuf, plen, poffs, _fixed(n, zxys, 112, "nonce points"), data, offs,
+                                           _fixed(n, tags, 56, "tags"), status))
     raw = bytes(data)
     return [raw[offs[i]:offs[i + 1]] for i in range(n)], [status[i] == 0 for i in range(n)]

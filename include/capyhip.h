@@ -10,11 +10,21 @@
  *   d            security parameter 224 | 256 | 384 | 512        (SecParam, src/lib.rs:111-135)
  *   msgs/offsets n messages packed in one buffer; message i is msgs[offsets[i] .. offsets[i+1]).
  *                offsets has n+1 entries, non-decreasing.  Host batches are re-packed to aligned starts as needed.
+ *   keys / pws   n per-item keys or passwords.  key_offsets (pw_offsets) == NULL: n byte strings of key_len (pw_len)
+ *                bytes back to back; otherwise n+1 non-decreasing byte offsets into the buffer, key i =
+ *                keys[key_offsets[i] .. key_offsets[i+1]) -- one length per item, as the reference takes any &[u8]
+ *                per message (src/ecc/signable.rs:40-43, src/ecc/keypair.rs:41, src/sha3/hashable.rs:33-35) -- and
+ *                key_len is ignored.  A key is at most 1 MiB long.
  *   scalars      56-byte BIG-endian, unreduced                   (src/sha3/aux_functions.rs:102-110)
  *   points       affine (x, y), 2 x 56-byte little-endian canonical field elements (x first)
  *   return       0 = ok, <0 = CAPY_ERR_*; capy_last_error() gives the text (thread local)
  *   *_dev        same operation on buffers already resident in device memory, enqueued on `stream`
- *                (a hipStream_t passed as void*, NULL = default stream), no host synchronisation.
+ *                (a hipStream_t passed as void*, NULL = default stream), no host synchronisation and no device
+ *                copy from host memory: internal scratch is pooled per (host thread, device, stream), grows by
+ *                allocating (never by freeing) and is returned by capy_release_workspace(); secret intermediates
+ *                in it (z||pw, ke||ka, s, k, the ECDH point) are zeroed on the stream at the end of the call.
+ *                One exception: cSHAKE/KMAC at d = 224 with a customisation string longer than 162 bytes stages its
+ *                prefix with a synchronous copy.
  *                Message starts that are 8-byte aligned take the coalesced fast path (any alignment is correct).
  *                The kernels read whole aligned 8-byte words: up to 7 bytes past the end of an 8-byte aligned
  *                message are read (never written, never past the aligned word that holds its last byte).
@@ -44,7 +54,19 @@ const char *capy_last_error(void);
 const char *capy_version(void);
 int capy_device_count(void);
 int capy_set_device(int device); /* device used by the calling thread's subsequent calls */
-int capy_device_synchronize(void);
+/* Multi-GPU ("batches shard trivially across the 8 GPUs of one node", BASELINE north_star).
+ * After capy_set_devices(ids, n) every HOST-buffer entry point below cuts its batch into n contiguous shards --
+ * balanced by message bytes where the call carries messages, by count otherwise --, runs shard k on device ids[k]
+ * (one worker thread per device) and has it write its slice of the caller's output arrays.  Items are independent:
+ * no collective and no peer-to-peer traffic; results, output order and in-place effects are identical to the
+ * single-device call for every device list (an id may repeat).  n = 0 returns to the calling thread's current
+ * device.  Process-wide; the *_dev entry points are unaffected (their buffers live on one device).
+ * capy_get_devices writes at most `capacity` ids and returns the length of the configured list. */
+int capy_set_devices(const int *ids, int n);
+int capy_get_devices(int *ids, int capacity);
+int capy_device_synchronize(void); /* every configured device, else the current one */
+/* Free the calling thread's pooled device scratch on every device (synchronises); also done when the thread ends. */
+int capy_release_workspace(void);
 
 /* ------------------------------------------------------------------ sponge (src/sha3) */
 
@@ -66,34 +88,39 @@ int capy_cshake_batch_dev(int d, size_t n, const uint8_t *xs, const uint64_t *of
                           uint64_t msg_stride, size_t l_bits, const uint8_t *fn_name, size_t fn_len,
                           const uint8_t *custom, size_t custom_len, uint8_t *outs, uint64_t out_stride, void *stream);
 
-/* KMACXOF: out_i = kmac_xof(key_i, x_i, l_bits, S, d); keys are n fixed-length keys of key_len bytes.
+/* KMACXOF: out_i = kmac_xof(key_i, x_i, l_bits, S, d); keys as in Conventions (fixed key_len or key_offsets).
  * Replaces kmac_xof(), src/sha3/shake_functions.rs:79-89 (pub), and
  * SpongeHashable::compute_tagged_hash, src/sha3/hashable.rs:33-35 (l_bits = d). */
-int capy_kmac_xof_batch(int d, size_t n, const uint8_t *keys, size_t key_len, const uint8_t *xs,
-                        const uint64_t *offsets, size_t l_bits, const uint8_t *custom, size_t custom_len,
-                        uint8_t *outs);
-/* device form: keys at keys + i*key_stride; x_i via offsets or (uniform_len, msg_stride); x may be NULL
- * with uniform_len = 0; outs at outs + i*out_stride (out_stride multiple of 8). */
+int capy_kmac_xof_batch(int d, size_t n, const uint8_t *keys, size_t key_len, const uint64_t *key_offsets,
+                        const uint8_t *xs, const uint64_t *offsets, size_t l_bits, const uint8_t *custom,
+                        size_t custom_len, uint8_t *outs);
+/* device form: keys at keys + i*key_stride (key_len bytes each), or via key_offsets (n+1 DEVICE offsets, key_len and
+ * key_stride ignored); x_i via offsets or (uniform_len, msg_stride); x may be NULL with uniform_len = 0; outs at
+ * outs + i*out_stride (out_stride multiple of 8). */
 int capy_kmac_xof_batch_dev(int d, size_t n, const uint8_t *keys, size_t key_len, uint64_t key_stride,
-                            const uint8_t *xs, const uint64_t *offsets, uint64_t uniform_len,
-                            uint64_t msg_stride, size_t l_bits, const uint8_t *custom, size_t custom_len,
-                            uint8_t *outs, uint64_t out_stride, void *stream);
+                            const uint64_t *key_offsets, const uint8_t *xs, const uint64_t *offsets,
+                            uint64_t uniform_len, uint64_t msg_stride, size_t l_bits, const uint8_t *custom,
+                            size_t custom_len, uint8_t *outs, uint64_t out_stride, void *stream);
 
 /* SpongeEncryptable::sha3_encrypt, src/sha3/encryptable.rs:29-45.
- * pws: n passwords of pw_len bytes; zs: n caller-supplied 512-byte nonces (the reference draws them
- * from thread_rng, :31); msgs transformed in place to ciphertext; tags: n * 64 bytes. */
-int capy_sha3_encrypt_batch(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint8_t *zs,
-                            uint8_t *msgs, const uint64_t *offsets, uint8_t *tags);
+ * pws: n passwords (fixed pw_len or pw_offsets, see Conventions); zs: n caller-supplied 512-byte nonces (the reference
+ * draws them from thread_rng, :31); msgs transformed in place to ciphertext; tags: n * 64 bytes. */
+int capy_sha3_encrypt_batch(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint64_t *pw_offsets,
+                            const uint8_t *zs, uint8_t *msgs, const uint64_t *offsets, uint8_t *tags);
 /* SpongeEncryptable::sha3_decrypt, src/sha3/encryptable.rs:58-83.  status[i] = CAPY_ITEM_OK and msg i
  * holds the plaintext, or CAPY_ITEM_FAIL and msg i is restored to the ciphertext (:77-82). */
-int capy_sha3_decrypt_batch(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint8_t *zs,
-                            uint8_t *msgs, const uint64_t *offsets, const uint8_t *tags, int32_t *status);
-int capy_sha3_encrypt_batch_dev(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint8_t *zs,
-                                uint8_t *msgs, const uint64_t *offsets, uint64_t uniform_len,
-                                uint64_t msg_stride, uint8_t *tags, void *stream);
-int capy_sha3_decrypt_batch_dev(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint8_t *zs,
-                                uint8_t *msgs, const uint64_t *offsets, uint64_t uniform_len,
-                                uint64_t msg_stride, const uint8_t *tags, int32_t *status, void *stream);
+int capy_sha3_decrypt_batch(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint64_t *pw_offsets,
+                            const uint8_t *zs, uint8_t *msgs, const uint64_t *offsets, const uint8_t *tags,
+                            int32_t *status);
+/* device forms: pw_offsets (if not NULL) are n+1 DEVICE offsets; pws_bytes is then the total number of password bytes
+ * (pw_offsets[n] - pw_offsets[0]; it sizes the z||pw scratch without reading device memory), ignored otherwise. */
+int capy_sha3_encrypt_batch_dev(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint64_t *pw_offsets,
+                                uint64_t pws_bytes, const uint8_t *zs, uint8_t *msgs, const uint64_t *offsets,
+                                uint64_t uniform_len, uint64_t msg_stride, uint8_t *tags, void *stream);
+int capy_sha3_decrypt_batch_dev(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint64_t *pw_offsets,
+                                uint64_t pws_bytes, const uint8_t *zs, uint8_t *msgs, const uint64_t *offsets,
+                                uint64_t uniform_len, uint64_t msg_stride, const uint8_t *tags, int32_t *status,
+                                void *stream);
 
 /* The sponge half of KEMEncryptable::kem_encrypt / kem_decrypt, src/kem/encryptable.rs:47-59, 84-104
  * (SURVEY.md §8f rank 1): identical flow to sha3_encrypt with the ML-KEM shared secret in place of the
@@ -120,13 +147,20 @@ int capy_ed448_add_batch(size_t n, const uint8_t *p_xy, const uint8_t *q_xy, uin
 int capy_ed448_double_scalarmul_batch(size_t n, const uint8_t *a_be, const uint8_t *b_be,
                                       const uint8_t *points_xy, uint8_t *out_xy);
 
+/* status[i] = CAPY_ITEM_OK iff point i has canonical coordinates (both < p) and lies on the curve.  The multiplication
+ * and protocol entry points do NOT validate their point inputs (results for off-curve or non-canonical input are
+ * unspecified, as with the reference's ExtendedPoint built from raw coordinates); callers that take points from
+ * untrusted sources (a public key or asym_nonce read from a file, src/lib.rs:101-108) run this first. */
+int capy_ed448_validate_batch(size_t n, const uint8_t *points_xy, int32_t *status);
+int capy_ed448_validate_batch_dev(size_t n, const uint8_t *points_xy, int32_t *status, void *stream);
+
 /* ------------------------------------------------------------------ src/ecc protocols */
 
 /* KeyPair::new, src/ecc/keypair.rs:41-51: pub_i = [4 * KMAC(pw_i,"",448,"SK",d) mod r] G */
-int capy_keypair_batch(int d, size_t n, const uint8_t *pws, size_t pw_len, uint8_t *pub_xy);
+int capy_keypair_batch(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint64_t *pw_offsets, uint8_t *pub_xy);
 /* Signable::sign, src/ecc/signable.rs:40-57.  h: n*56 bytes, z_be: n*56 bytes (big-endian scalar). */
-int capy_schnorr_sign_batch(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint8_t *msgs,
-                            const uint64_t *offsets, uint8_t *h, uint8_t *z_be);
+int capy_schnorr_sign_batch(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint64_t *pw_offsets,
+                            const uint8_t *msgs, const uint64_t *offsets, uint8_t *h, uint8_t *z_be);
 /* Signable::verify, src/ecc/signable.rs:72-86.  status[i] = CAPY_ITEM_OK | CAPY_ITEM_FAIL */
 int capy_schnorr_verify_batch(int d, size_t n, const uint8_t *pub_xy, const uint8_t *msgs,
                               const uint64_t *offsets, const uint8_t *h, const uint8_t *z_be, int32_t *status);
@@ -135,24 +169,26 @@ int capy_schnorr_verify_batch(int d, size_t n, const uint8_t *pub_xy, const uint
 int capy_key_encrypt_batch(int d, size_t n, const uint8_t *pub_xy, const uint8_t *k_rand, uint8_t *msgs,
                            const uint64_t *offsets, uint8_t *z_xy, uint8_t *tags);
 /* KeyEncryptable::key_decrypt, src/ecc/encryptable.rs:72-94 (restore-on-failure, :88-93). */
-int capy_key_decrypt_batch(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint8_t *z_xy,
-                           uint8_t *msgs, const uint64_t *offsets, const uint8_t *tags, int32_t *status);
+int capy_key_decrypt_batch(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint64_t *pw_offsets,
+                           const uint8_t *z_xy, uint8_t *msgs, const uint64_t *offsets, const uint8_t *tags,
+                           int32_t *status);
 
 /* Device-buffer forms of the src/ecc protocols (same semantics; messages via offsets or uniform_len/msg_stride,
  * enqueued on `stream`, no host synchronisation). */
-int capy_keypair_batch_dev(int d, size_t n, const uint8_t *pws, size_t pw_len, uint8_t *pub_xy, void *stream);
-int capy_schnorr_sign_batch_dev(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint8_t *msgs,
-                                const uint64_t *offsets, uint64_t uniform_len, uint64_t msg_stride, uint8_t *h,
-                                uint8_t *z_be, void *stream);
+int capy_keypair_batch_dev(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint64_t *pw_offsets,
+                           uint8_t *pub_xy, void *stream);
+int capy_schnorr_sign_batch_dev(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint64_t *pw_offsets,
+                                const uint8_t *msgs, const uint64_t *offsets, uint64_t uniform_len, uint64_t msg_stride,
+                                uint8_t *h, uint8_t *z_be, void *stream);
 int capy_schnorr_verify_batch_dev(int d, size_t n, const uint8_t *pub_xy, const uint8_t *msgs, const uint64_t *offsets,
                                   uint64_t uniform_len, uint64_t msg_stride, const uint8_t *h, const uint8_t *z_be,
                                   int32_t *status, void *stream);
 int capy_key_encrypt_batch_dev(int d, size_t n, const uint8_t *pub_xy, const uint8_t *k_rand, uint8_t *msgs,
                                const uint64_t *offsets, uint64_t uniform_len, uint64_t msg_stride, uint8_t *z_xy,
                                uint8_t *tags, void *stream);
-int capy_key_decrypt_batch_dev(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint8_t *z_xy, uint8_t *msgs,
-                               const uint64_t *offsets, uint64_t uniform_len, uint64_t msg_stride, const uint8_t *tags,
-                               int32_t *status, void *stream);
+int capy_key_decrypt_batch_dev(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint64_t *pw_offsets,
+                               const uint8_t *z_xy, uint8_t *msgs, const uint64_t *offsets, uint64_t uniform_len,
+                               uint64_t msg_stride, const uint8_t *tags, int32_t *status, void *stream);
 
 /* ------------------------------------------------------------------ measurement helpers */
 

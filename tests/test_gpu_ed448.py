@@ -39,15 +39,78 @@ def test_golden_scalarmul(capy, vectors):
 
 
 def test_golden_sign_and_keypair(capy, vectors):
+    """The committed sign / keypair vectors: password and message lengths differ per vector, and each security
+    parameter's vectors go through the C ABI as ONE batch (per-item password lengths, include/capyhip.h Conventions),
+    then once more one at a time through the reference-shaped API."""
+    from capycrypt_amd.message import sign_many, verify_many
+
     for d in (224, 256, 384, 512):
         v = [t for t in vectors["sign"] if t["d"] == d]
-        for t in v:  # key / message lengths differ per vector: batches of one, as the reference API
+        pws = [bytes.fromhex(t["pw"]) for t in v]
+        assert len(set(len(p) for p in pws)) > 1  # really ragged
+        kps = capy.KeyPair.new_many(pws, "test key", d)
+        assert [k.pub_key.hex() for k in kps] == [t["pub"] for t in v]
+        ms = [capy.Message(bytes.fromhex(t["msg"])) for t in v]
+        sign_many(ms, kps, d)
+        assert [(m.sig.h.hex(), m.sig.z.hex()) for m in ms] == [(t["h"], t["z"]) for t in v]
+        assert all(verify_many(ms, [k.pub_key for k in kps]))
+        for t in v:
             kp = capy.KeyPair.new(bytes.fromhex(t["pw"]), "test key", d)
             assert kp.pub_key.hex() == t["pub"]
             m = capy.Message(bytes.fromhex(t["msg"]))
             m.sign(kp, d)
             assert (m.sig.h.hex(), m.sig.z.hex()) == (t["h"], t["z"])
             m.verify(kp.pub_key)
+
+
+def test_ragged_passwords_through_every_protocol(capy, O):
+    """One batch, every item with its own password length (0 .. 300 bytes, incl. the bytepad boundaries of D256/D512):
+    keypair, sign, verify, key_encrypt -> key_decrypt against the oracle item by item."""
+    rng = random.Random(0x9A55)
+    for d in (256, 512):
+        r2 = (1600 - d) // 8
+        plens = [0, 1, 2, 31, 32, 33, 64, r2 - 5, r2 - 4, r2 - 3, r2 - 2, r2, 2 * r2 - 4, 300] + [rng.randrange(0, 200) for _ in range(70)]
+        n = len(plens)
+        pws = [rng.randbytes(x) for x in plens]
+        msgs = [rng.randbytes(rng.randrange(0, 400)) for _ in range(n)]
+        pubs = capy.ops.keypair_batch(pws, d)
+        assert pubs == [O.keypair_pub(p, d) for p in pws]
+        sigs = capy.ops.schnorr_sign_batch(pws, msgs, d)
+        assert sigs == [O.sign(p, m, d) for p, m in zip(pws, msgs)]
+        assert all(capy.ops.schnorr_verify_batch(pubs, msgs, sigs, d))
+        ks = [rng.randbytes(56) for _ in range(n)]
+        cts, zs, tags = capy.ops.key_encrypt_batch(pubs, ks, msgs, d)
+        wrong = list(pws)
+        wrong[5] = wrong[5] + b"x"
+        out, ok = capy.ops.key_decrypt_batch(wrong, zs, cts, tags, d)
+        assert ok == [i != 5 for i in range(n)]
+        assert all(out[i] == (msgs[i] if i != 5 else cts[i]) for i in range(n))
+
+
+def test_point_validation(capy, O):
+    """capy_ed448_validate_batch: on-curve and canonical.  Valid: generator, identity, random multiples.  Invalid: a
+    coordinate >= p (non-canonical encoding of a valid point), an off-curve pair, y flipped in one bit."""
+    from oracle import ed448_ref as E
+
+    rng = random.Random(3)
+    good = [E.pt_to_bytes(E.G), E.pt_to_bytes((0, 1)), E.pt_to_bytes((0, E.P - 1))]
+    good += [O.ed448_basemul(rng.randbytes(56)) for _ in range(61)]
+    x, y = E.scalarmul(12345, E.G)
+    small = E.scalarmul(0, E.G)  # (0, 1): x + p is a non-canonical encoding that still fits 56 bytes
+    bad = [
+        (small[0] + E.P).to_bytes(56, "little") + E.fe_to_bytes(small[1]),  # x = p  (== 0 mod p)
+        E.fe_to_bytes(0) + (1 + E.P).to_bytes(56, "little"),                # y = p + 1
+        E.fe_to_bytes(x) + E.fe_to_bytes((y + 1) % E.P),                    # off the curve
+        E.fe_to_bytes((x + 1) % E.P) + E.fe_to_bytes(y),
+        bytes(112),                                                         # (0, 0)
+        b"\xff" * 112,
+    ]
+    flip = bytearray(good[5])
+    flip[70] ^= 4
+    bad.append(bytes(flip))
+    res = capy.ops.ed448_validate_batch(good + bad)
+    assert res == [True] * len(good) + [False] * len(bad)
+    assert all(O.ed448_on_curve(p) for p in good)
 
 
 def _rfc():
@@ -315,8 +378,8 @@ def test_dev_api_protocols_roundtrip(capy, O):
     h = torch.zeros(n * 56, dtype=torch.uint8, device="cuda")
     z = torch.zeros(n * 56, dtype=torch.uint8, device="cuda")
     st = torch.full((n,), 9, dtype=torch.int32, device="cuda")
-    _lib.check(lib.capy_keypair_batch_dev(d, n, pws.data_ptr(), 32, pubs.data_ptr(), None))
-    _lib.check(lib.capy_schnorr_sign_batch_dev(d, n, pws.data_ptr(), 32, msgs.data_ptr(), None, L, stride, h.data_ptr(),
+    _lib.check(lib.capy_keypair_batch_dev(d, n, pws.data_ptr(), 32, None, pubs.data_ptr(), None))
+    _lib.check(lib.capy_schnorr_sign_batch_dev(d, n, pws.data_ptr(), 32, None, msgs.data_ptr(), None, L, stride, h.data_ptr(),
                                                z.data_ptr(), None))
     _lib.check(lib.capy_schnorr_verify_batch_dev(d, n, pubs.data_ptr(), msgs.data_ptr(), None, L, stride, h.data_ptr(),
                                                  z.data_ptr(), st.data_ptr(), None))
@@ -337,7 +400,7 @@ def test_dev_api_protocols_roundtrip(capy, O):
     hc, hk = bytes(work.cpu().numpy()), bytes(kr.cpu().numpy())
     ect, ez, etag = O.key_encrypt(hpub[:112], hk[:56], hm[:L], d)
     assert hc[:L] == ect and bytes(zxy[:112].cpu().numpy()) == ez and bytes(tags[:56].cpu().numpy()) == etag
-    _lib.check(lib.capy_key_decrypt_batch_dev(d, n, pws.data_ptr(), 32, zxy.data_ptr(), work.data_ptr(), None, L, stride,
+    _lib.check(lib.capy_key_decrypt_batch_dev(d, n, pws.data_ptr(), 32, None, zxy.data_ptr(), work.data_ptr(), None, L, stride,
                                               tags.data_ptr(), st.data_ptr(), None))
     torch.cuda.synchronize()
     assert not st.cpu().numpy().any() and bytes(work.cpu().numpy()) == hm

@@ -61,11 +61,11 @@ def test_config2_full_batch_units_are_batch_size_independent():
     n = 1 << 20
     keys = _rand(n * 64, 0xCA9C0002)
     out = torch.zeros(n * 1024, dtype=torch.uint8, device="cuda")
-    _lib.check(lib.capy_kmac_xof_batch_dev(512, n, keys.data_ptr(), 64, 64, None, None, 0, 0, 8192, b"SKE", 3,
+    _lib.check(lib.capy_kmac_xof_batch_dev(512, n, keys.data_ptr(), 64, 64, None, None, None, 0, 0, 8192, b"SKE", 3,
                                            out.data_ptr(), 1024, None))
     s0, m = 777777, 512
     out2 = torch.zeros(m * 1024, dtype=torch.uint8, device="cuda")
-    _lib.check(lib.capy_kmac_xof_batch_dev(512, m, keys.data_ptr() + s0 * 64, 64, 64, None, None, 0, 0, 8192, b"SKE", 3,
+    _lib.check(lib.capy_kmac_xof_batch_dev(512, m, keys.data_ptr() + s0 * 64, 64, 64, None, None, None, 0, 0, 8192, b"SKE", 3,
                                            out2.data_ptr(), 1024, None))
     torch.cuda.synchronize()
     assert torch.equal(out[s0 * 1024:(s0 + m) * 1024], out2)
@@ -88,13 +88,13 @@ def test_config3_per_gpu_share_round_trips():
     pws, zs = _rand(n * 64, 31), _rand(n * 512, 32)
     tags = torch.zeros(n * 64, dtype=torch.uint8, device="cuda")
     status = torch.full((n,), 5, dtype=torch.int32, device="cuda")
-    _lib.check(lib.capy_sha3_encrypt_batch_dev(512, n, pws.data_ptr(), 64, zs.data_ptr(), msgs.data_ptr(), None, MIB5, MIB5,
+    _lib.check(lib.capy_sha3_encrypt_batch_dev(512, n, pws.data_ptr(), 64, None, 0, zs.data_ptr(), msgs.data_ptr(), None, MIB5, MIB5,
                                                tags.data_ptr(), None))
     torch.cuda.synchronize()
     assert not torch.equal(msgs, plain)
     cipher = msgs.clone()
     tags[64 * 77 + 9] ^= 4
-    _lib.check(lib.capy_sha3_decrypt_batch_dev(512, n, pws.data_ptr(), 64, zs.data_ptr(), msgs.data_ptr(), None, MIB5, MIB5,
+    _lib.check(lib.capy_sha3_decrypt_batch_dev(512, n, pws.data_ptr(), 64, None, 0, zs.data_ptr(), msgs.data_ptr(), None, MIB5, MIB5,
                                                tags.data_ptr(), status.data_ptr(), None))
     torch.cuda.synchronize()
     st = status.cpu().numpy()
@@ -120,8 +120,8 @@ def test_config5_full_batch_sign_then_verify():
     h = torch.zeros(n * 56, dtype=torch.uint8, device="cuda")
     z = torch.zeros(n * 56, dtype=torch.uint8, device="cuda")
     st = torch.full((n,), 9, dtype=torch.int32, device="cuda")
-    _lib.check(lib.capy_keypair_batch_dev(512, n, pws.data_ptr(), 64, pubs.data_ptr(), None))
-    _lib.check(lib.capy_schnorr_sign_batch_dev(512, n, pws.data_ptr(), 64, msgs.data_ptr(), None, L, L, h.data_ptr(),
+    _lib.check(lib.capy_keypair_batch_dev(512, n, pws.data_ptr(), 64, None, pubs.data_ptr(), None))
+    _lib.check(lib.capy_schnorr_sign_batch_dev(512, n, pws.data_ptr(), 64, None, msgs.data_ptr(), None, L, L, h.data_ptr(),
                                                z.data_ptr(), None))
     _lib.check(lib.capy_schnorr_verify_batch_dev(512, n, pubs.data_ptr(), msgs.data_ptr(), None, L, L, h.data_ptr(),
                                                  z.data_ptr(), st.data_ptr(), None))

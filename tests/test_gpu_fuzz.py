@@ -57,17 +57,23 @@ def test_sponge_fuzz_against_oracle(lanes, seed):
                 assert got[i] == O.cshake(msgs[i], lbits, b"FN", cs, d), ("cshake", d, lens[i], lbits)
 
             klen = rng.choice([0, 1, 32, 56, 64, 130, 200])
-            keys = [rng.randbytes(klen) for _ in range(n)]
+            # half of the draws: one key / password length per ITEM (the reference takes any &[u8] per message,
+            # src/sha3/hashable.rs:33-35, src/sha3/encryptable.rs:29), incl. the lengths around the bytepad boundary
+            r2 = RATES[d][1]
+            ragged_keys = rng.random() < 0.5
+            def klen_i():
+                return rng.choice([0, 1, 31, 32, 33, 56, 64, r2 - 5, r2 - 4, r2 - 3, r2, 2 * r2 - 4, 300]) if ragged_keys else klen
+            keys = [rng.randbytes(klen_i()) for _ in range(n)]
             got = ops.kmac_xof_batch(keys, msgs, lbits, cs, d)
             for i in picks:
-                assert got[i] == O.kmac_xof(keys[i], msgs[i], lbits, cs, d), ("kmac", d, klen, lens[i], lbits)
+                assert got[i] == O.kmac_xof(keys[i], msgs[i], lbits, cs, d), ("kmac", d, len(keys[i]), lens[i], lbits)
 
-            pws = [rng.randbytes(klen) for _ in range(n)]
+            pws = [rng.randbytes(klen_i()) for _ in range(n)]
             zs = [rng.randbytes(512) for _ in range(n)]
             cts, tags = ops.sha3_encrypt_batch(pws, zs, msgs, d)
             for i in picks:
                 ect, etag = O.sha3_encrypt(pws[i], zs[i], msgs[i], d)
-                assert cts[i] == ect and tags[i] == etag, ("encrypt", d, klen, lens[i])
+                assert cts[i] == ect and tags[i] == etag, ("encrypt", d, len(pws[i]), lens[i])
             bad = rng.randrange(n)
             tags2 = list(tags)
             tags2[bad] = bytes([tags[bad][0] ^ 0x40]) + tags[bad][1:]

@@ -322,7 +322,7 @@ def test_dev_api_uniform_batches_all_instances(capy, O, n, L):
     dig = torch.zeros(n * 32, dtype=torch.uint8, device="cuda")
     _lib.check(lib.capy_sha3_batch_dev(256, n, msgs.data_ptr(), None, L, stride, dig.data_ptr(), None))
     out = torch.zeros(n * 72, dtype=torch.uint8, device="cuda")
-    _lib.check(lib.capy_kmac_xof_batch_dev(512, n, keys.data_ptr(), 64, 64, msgs.data_ptr(), None, L, stride, 576,
+    _lib.check(lib.capy_kmac_xof_batch_dev(512, n, keys.data_ptr(), 64, 64, None, msgs.data_ptr(), None, L, stride, 576,
                                            b"T", 1, out.data_ptr(), 72, None))
     torch.cuda.synchronize()
     hd, ho = bytes(dig.cpu().numpy()), bytes(out.cpu().numpy())
@@ -335,7 +335,7 @@ def test_dev_api_uniform_batches_all_instances(capy, O, n, L):
         work = msgs.clone()
         tags = torch.zeros(n * 64, dtype=torch.uint8, device="cuda")
         status = torch.full((n,), 7, dtype=torch.int32, device="cuda")
-        _lib.check(lib.capy_sha3_encrypt_batch_dev(d, n, keys.data_ptr(), 64, zs.data_ptr(), work.data_ptr(), None, L,
+        _lib.check(lib.capy_sha3_encrypt_batch_dev(d, n, keys.data_ptr(), 64, None, 0, zs.data_ptr(), work.data_ptr(), None, L,
                                                    stride, tags.data_ptr(), None))
         torch.cuda.synchronize()
         hc, ht = bytes(work.cpu().numpy()), bytes(tags.cpu().numpy())
@@ -346,7 +346,7 @@ def test_dev_api_uniform_batches_all_instances(capy, O, n, L):
         # corrupt one tag: that item must fail and keep its ciphertext, all others decrypt
         bad = n // 3
         tags[64 * bad] ^= 1
-        _lib.check(lib.capy_sha3_decrypt_batch_dev(d, n, keys.data_ptr(), 64, zs.data_ptr(), work.data_ptr(), None, L,
+        _lib.check(lib.capy_sha3_decrypt_batch_dev(d, n, keys.data_ptr(), 64, None, 0, zs.data_ptr(), work.data_ptr(), None, L,
                                                    stride, tags.data_ptr(), status.data_ptr(), None))
         torch.cuda.synchronize()
         st = status.cpu().numpy()
@@ -451,7 +451,7 @@ def test_kmac_rotating_schedule_with_per_item_keys(capy, O, sponge_lanes):
         for lanes in (1, 3):
             _lib.check(lib.capy_set_sponge_lanes(lanes))
             out = torch.zeros(n * 64, dtype=torch.uint8, device="cuda")
-            _lib.check(lib.capy_kmac_xof_batch_dev(d, n, keys.data_ptr(), klen, klen, msgs.data_ptr(), None, L, stride, 512,
+            _lib.check(lib.capy_kmac_xof_batch_dev(d, n, keys.data_ptr(), klen, klen, None, msgs.data_ptr(), None, L, stride, 512,
                                                    b"T", 1, out.data_ptr(), 64, None))
             torch.cuda.synchronize()
             outs.append(out)
@@ -485,9 +485,9 @@ def test_wave_quantisation_split_matches_one_lane(capy, O, sponge_lanes):
         work = msgs.clone()
         tags = torch.zeros(n * 64, dtype=torch.uint8, device="cuda")
         _lib.check(lib.capy_sha3_batch_dev(256, n, msgs.data_ptr(), None, L, stride, dig.data_ptr(), None))
-        _lib.check(lib.capy_kmac_xof_batch_dev(512, n, keys.data_ptr(), 64, 64, msgs.data_ptr(), None, L, stride, 512,
+        _lib.check(lib.capy_kmac_xof_batch_dev(512, n, keys.data_ptr(), 64, 64, None, msgs.data_ptr(), None, L, stride, 512,
                                                b"T", 1, out.data_ptr(), 64, None))
-        _lib.check(lib.capy_sha3_encrypt_batch_dev(512, n, keys.data_ptr(), 64, zs.data_ptr(), work.data_ptr(), None, L,
+        _lib.check(lib.capy_sha3_encrypt_batch_dev(512, n, keys.data_ptr(), 64, None, 0, zs.data_ptr(), work.data_ptr(), None, L,
                                                    stride, tags.data_ptr(), None))
         torch.cuda.synchronize()
         res.append((dig, out, work, tags))
@@ -535,7 +535,7 @@ def test_dev_api_ragged_offsets_longest_first(capy, O):
     dig = torch.zeros(n * 32, dtype=torch.uint8, device="cuda")
     _lib.check(lib.capy_sha3_batch_dev(256, n, data.data_ptr(), d_offs.data_ptr(), 0, 0, dig.data_ptr(), None))
     out = torch.zeros(n * 40, dtype=torch.uint8, device="cuda")
-    _lib.check(lib.capy_kmac_xof_batch_dev(256, n, keys.data_ptr(), 64, 64, data.data_ptr(), d_offs.data_ptr(), 0, 0, 320,
+    _lib.check(lib.capy_kmac_xof_batch_dev(256, n, keys.data_ptr(), 64, 64, None, data.data_ptr(), d_offs.data_ptr(), 0, 0, 320,
                                            b"T", 1, out.data_ptr(), 40, None))
     torch.cuda.synchronize()
     hd, ho = bytes(dig.cpu().numpy()), bytes(out.cpu().numpy())
@@ -547,7 +547,7 @@ def test_dev_api_ragged_offsets_longest_first(capy, O):
     work = data.clone()
     tags = torch.zeros(n * 64, dtype=torch.uint8, device="cuda")
     status = torch.full((n,), 9, dtype=torch.int32, device="cuda")
-    _lib.check(lib.capy_sha3_encrypt_batch_dev(512, n, keys.data_ptr(), 64, zs.data_ptr(), work.data_ptr(),
+    _lib.check(lib.capy_sha3_encrypt_batch_dev(512, n, keys.data_ptr(), 64, None, 0, zs.data_ptr(), work.data_ptr(),
                                                d_offs.data_ptr(), 0, 0, tags.data_ptr(), None))
     torch.cuda.synchronize()
     hc, ht = bytes(work.cpu().numpy()), bytes(tags.cpu().numpy())
@@ -556,7 +556,7 @@ def test_dev_api_ragged_offsets_longest_first(capy, O):
         assert hc[offs[i]:offs[i] + plens[i]] == ect and ht[64 * i:64 * i + 64] == etag, i
     bad = next(i for i in range(n // 2, n) if plens[i] > 0)
     tags[64 * bad + 3] ^= 0x10
-    _lib.check(lib.capy_sha3_decrypt_batch_dev(512, n, keys.data_ptr(), 64, zs.data_ptr(), work.data_ptr(),
+    _lib.check(lib.capy_sha3_decrypt_batch_dev(512, n, keys.data_ptr(), 64, None, 0, zs.data_ptr(), work.data_ptr(),
                                                d_offs.data_ptr(), 0, 0, tags.data_ptr(), status.data_ptr(), None))
     torch.cuda.synchronize()
     st = status.cpu().numpy()

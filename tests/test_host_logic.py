@@ -148,3 +148,109 @@ def test_message_json_layout_is_serde_jsons_for_the_sponge_side_fields(tmp_path)
 
     with pytest.raises(Exception):
         Message.from_json(ref_doc.replace('"D512"', '"D500"'))
+
+
+def test_keypair_json_layout_and_round_trip(tmp_path):
+    """src/ecc/keypair.rs:11-22, 56-77: serde_json::to_string_pretty of {owner, pub_key, priv_key, date_created}.  A file
+    written by the reference carries pub_key in the absent curve crate's layout: kept verbatim, written back unchanged."""
+    import json
+
+    from capycrypt_amd.message import KeyPair
+
+    ref_doc = {"owner": "test key", "pub_key": {"X": [1, 2], "Y": [3], "Z": [4], "T": [5]}, "priv_key": [112, 119, 0, 255],
+               "date_created": "2024-05-01 10:20:30"}
+    kp = KeyPair.from_json(json.dumps(ref_doc, indent=2))
+    assert kp.owner == "test key" and kp.priv_key == b"pw\x00\xff" and kp.date_created == "2024-05-01 10:20:30"
+    assert kp.pub_key == b""  # opaque until derive_pub_key(d) recomputes it on the GPU
+    text = kp.to_json()
+    assert json.loads(text) == ref_doc
+    assert list(json.loads(text)) == ["owner", "pub_key", "priv_key", "date_created"]  # declaration order
+    assert text.startswith('{\n  "owner": "test key",\n  "pub_key": {')  # to_string_pretty: two-space indent
+    own = KeyPair("me", bytes(range(112)), b"secret", "2026-01-01 00:00:00")
+    p = tmp_path / "k.json"
+    own.write_to_file(str(p))
+    back = KeyPair.read_from_file(str(p))
+    assert (back.owner, back.pub_key, back.priv_key, back.date_created) == (own.owner, own.pub_key, own.priv_key, own.date_created)
+    with pytest.raises(ValueError):
+        KeyPair.from_json('{"owner": "x", "priv_key": [], "date_created": ""}')
+    bad = json.loads(own.to_json())
+    bad["pub_key"] = bad["pub_key"][:100]
+    with pytest.raises(ValueError):
+        KeyPair.from_json(json.dumps(bad))
+
+
+def test_ops_reject_malformed_arguments_before_the_library_sees_them():
+    """fields that come from an untrusted Message file must not make libcapyhip read past a short
+    buffer.  Every count / fixed-size mismatch is a ValueError raised in python; nothing here needs a GPU."""
+    from capycrypt_amd import ops
+
+    z, t64, t56, pt, sc = bytes(512), bytes(64), bytes(56), bytes(112), bytes(56)
+    with pytest.raises(ValueError):
+        ops.sha3_decrypt_batch([b"pw"], [z[:100]], [b"m"], [t64], 512)  # short nonce
+    with pytest.raises(ValueError):
+        ops.sha3_decrypt_batch([b"pw"], [z], [b"m"], [t64[:10]], 512)  # short tag
+    with pytest.raises(ValueError):
+        ops.sha3_decrypt_batch([b"pw"], [z], [b"m"], [t64 + b"x"], 512)  # a longer tag with a matching prefix
+    with pytest.raises(ValueError):
+        ops.sha3_decrypt_batch([b"pw", b"pw2"], [z], [b"m"], [t64], 512)  # counts differ
+    with pytest.raises(ValueError):
+        ops.sha3_encrypt_batch([b"pw"], [], [b"m"], 512)
+    with pytest.raises(ValueError):
+        ops.kem_sponge_decrypt_batch([bytes(32)], [z], [b"m"], [t64[:63]], 512)
+    with pytest.raises(ValueError):
+        ops.kem_sponge_encrypt_batch([bytes(32), bytes(31)], [z, z], [b"m", b"n"], 512)
+    with pytest.raises(ValueError):
+        ops.schnorr_verify_batch([pt], [b"m"], [(t56[:55], sc)], 512)
+    with pytest.raises(ValueError):
+        ops.schnorr_verify_batch([pt[:111]], [b"m"], [(t56, sc)], 512)
+    with pytest.raises(ValueError):
+        ops.key_encrypt_batch([pt], [sc[:20]], [b"m"], 512)  # a short k_rand would pull heap bytes into the key
+    with pytest.raises(ValueError):
+        ops.key_decrypt_batch([b"pw"], [pt], [b"m"], [t56 + b"\0"], 512)
+    with pytest.raises(ValueError):
+        ops.ed448_scalarmul_batch([sc], [pt, pt])
+    with pytest.raises(ValueError):
+        ops.ed448_basemul_batch([sc[:55]])
+    with pytest.raises(ValueError):
+        ops.kmac_xof_batch([b"k"], [b"a", b"b"], 256, b"", 256)
+    with pytest.raises(ValueError):
+        ops.keypair_batch([bytes((1 << 20) + 1)], 512)
+
+
+def test_message_rejects_malformed_fields_like_the_reference():
+    """A digest of the wrong length can never equal the recomputed tag (src/sha3/encryptable.rs:77,
+    src/ecc/encryptable.rs:88): the operation fails and msg is left as it was, without a GPU call."""
+    from capycrypt_amd import Message, OperationError, SecParam
+    from capycrypt_amd.message import Signature
+
+    m = Message(b"ciphertext")
+    m.d, m.sym_nonce, m.digest = SecParam.D512, bytes(512), bytes(63)
+    with pytest.raises(OperationError) as e:
+        m.sha3_decrypt(b"pw")
+    assert e.value.variant == "SHA3DecryptionFailure" and bytes(m.msg) == b"ciphertext"
+    m.digest = bytes(64)
+    m.sym_nonce = bytes(100)
+    with pytest.raises(ValueError):
+        m.sha3_decrypt(b"pw")
+    k = Message(b"ct")
+    k.d, k.asym_nonce, k.digest = SecParam.D256, bytes(112), bytes(64)
+    with pytest.raises(OperationError) as e:
+        k.key_decrypt(b"pw")
+    assert e.value.variant == "KeyDecryptionError" and bytes(k.msg) == b"ct"
+    s = Message(b"x")
+    s.d, s.sig = SecParam.D256, Signature(bytes(10), bytes(56))
+    with pytest.raises(OperationError) as e:
+        s.verify(bytes(112))
+    assert e.value.variant == "SignatureVerificationFailure"
+
+
+def test_header_declares_the_multi_device_and_per_item_key_interface():
+    with open(os.path.join(ROOT, "include", "capyhip.h")) as f:
+        txt = f.read()
+    assert "capy_set_devices(const int *ids, int n)" in txt and "capy_get_devices" in txt
+    for fn in ("capy_kmac_xof_batch", "capy_keypair_batch", "capy_schnorr_sign_batch", "capy_key_decrypt_batch",
+               "capy_sha3_encrypt_batch", "capy_sha3_decrypt_batch"):
+        decl = txt[txt.index("int %s(" % fn):]
+        decl = decl[:decl.index(";")]
+        assert "_offsets" in decl.split("msgs")[0].split("xs")[0], fn  # a per-item key / password offsets argument
+    assert "capy_ed448_validate_batch" in txt

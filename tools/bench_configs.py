@@ -46,7 +46,7 @@ n = 1 << 20
 keys = rand(n * 64, 2)
 out = torch.empty(n * 1024, dtype=torch.uint8, device=dev)
 # a 1.2-1.5 ms launch: 3 repetitions only see the clock settle (686-743 M units/s); 30 reach the steady state
-s = timeit(lambda: _lib.check(lib.capy_kmac_xof_batch_dev(512, n, keys.data_ptr(), 64, 64, None, None, 0, 0, 8192,
+s = timeit(lambda: _lib.check(lib.capy_kmac_xof_batch_dev(512, n, keys.data_ptr(), 64, 64, None, None, None, 0, 0, 8192,
                                                           b"SKE", 3, out.data_ptr(), 1024, sp)), reps=30)
 emit(config=2, what="2^20 x KMACXOF256 1 KiB squeeze (64-B keys)", seconds=s, units_per_s=n / s,
      out_GBps=n * 1024 / s / 1e9,
@@ -65,11 +65,11 @@ for nmsg in (128, 2048, 16384):
     before = msgs[:4096].clone()
 
     def enc():
-        _lib.check(lib.capy_sha3_encrypt_batch_dev(512, nmsg, pws.data_ptr(), 64, zs.data_ptr(), msgs.data_ptr(), None,
+        _lib.check(lib.capy_sha3_encrypt_batch_dev(512, nmsg, pws.data_ptr(), 64, None, 0, zs.data_ptr(), msgs.data_ptr(), None,
                                                    MIB5, MIB5, tags.data_ptr(), sp))
 
     def dec():
-        _lib.check(lib.capy_sha3_decrypt_batch_dev(512, nmsg, pws.data_ptr(), 64, zs.data_ptr(), msgs.data_ptr(), None,
+        _lib.check(lib.capy_sha3_decrypt_batch_dev(512, nmsg, pws.data_ptr(), 64, None, 0, zs.data_ptr(), msgs.data_ptr(), None,
                                                    MIB5, MIB5, tags.data_ptr(), status.data_ptr(), sp))
 
     torch.cuda.synchronize()
@@ -111,12 +111,12 @@ pubs_h = (C.c_uint8 * (n * 112))()
 h_h = (C.c_uint8 * (n * 56))()
 z_h = (C.c_uint8 * (n * 56))()
 st_h = (C.c_int32 * n)()
-_lib.check(lib.capy_keypair_batch(512, n, pws_h, 64, pubs_h))  # warm (fixed-base table build)
+_lib.check(lib.capy_keypair_batch(512, n, pws_h, 64, None, pubs_h))  # warm (fixed-base table build)
 t0 = time.perf_counter()
-_lib.check(lib.capy_keypair_batch(512, n, pws_h, 64, pubs_h))
+_lib.check(lib.capy_keypair_batch(512, n, pws_h, 64, None, pubs_h))
 tk = time.perf_counter() - t0
 t0 = time.perf_counter()
-_lib.check(lib.capy_schnorr_sign_batch(512, n, pws_h, 64, msgs_h, offs_h, h_h, z_h))
+_lib.check(lib.capy_schnorr_sign_batch(512, n, pws_h, 64, None, msgs_h, offs_h, h_h, z_h))
 ts = time.perf_counter() - t0
 t0 = time.perf_counter()
 _lib.check(lib.capy_schnorr_verify_batch(512, n, pubs_h, msgs_h, offs_h, h_h, z_h, st_h))
