@@ -29,6 +29,40 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # register-resident loop of nothing but permutations tops out at 10.68e9 permutations/s (16k waves, best loop
 # form), i.e. 1453 GB/s of absorbed message at 136 B per permutation ("Rooflines").
 VALU_CEIL_GBS = 10.68e9 * 136.0 / 1e9
+# What MI355X_MICROARCH.md's SIMD-32 figure (one wave64 VALU instruction per 2 cycles per SIMD) would allow for the
+# 4320 VALU instructions of one permutation of a wave's 64 sponges: 1024 SIMDs x 2.4 GHz / 2 / 4320 x 64 x 136 B.  Not reachable for this
+# instruction mix: with every SIMD busy the chip sustains one instruction of it per ~1.45-1.7 ns per SIMD whatever
+# the number of waves (profiles/r02_second_issue_slot.txt); reported beside the measured ceiling for reference.
+VALU_ARCH_CEIL_GBS = 1024 * 2.4e9 / 2 / 4320 * 64 * 136.0 / 1e9
+
+
+def kernel_source_digest():
+    """sha256 over the kernel sources: a PMC summary in profiles/ is only used for the build it was taken on."""
+    import glob
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "capycrypt_amd", "csrc", "*.h")) +
+                    glob.glob(os.path.join(ROOT, "capycrypt_amd", "csrc", "*.hip"))):
+        with open(f, "rb") as fh:
+            h.update(os.path.basename(f).encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_summary():
+    """The newest profiles/rNN_pmc_summary.json taken on THIS build of the kernels (matching source digest), or None."""
+    import glob
+
+    dig = kernel_source_digest()
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")), reverse=True):
+        try:
+            with open(f) as fh:
+                pm = json.load(fh)
+        except (OSError, ValueError):
+            continue
+        if pm.get("_meta", {}).get("kernel_source_digest") == dig:
+            return os.path.basename(f), pm
+    return None, None
 
 
 def parse():
@@ -278,23 +312,45 @@ def main():
     kind, phases = C.c_int(0), C.c_int(1)
     _lib.check(lib.capy_sha3_launch_plan(256, B, MSG_BYTES, MSG_STRIDE, C.byref(kind), C.byref(phases)))
     kname = {1: "sponge_kernel<17, false, 0>", 2: "sponge_kernel_k2<17, 0>", 3: "sponge_mixed_kernel<17>",
-             4: "sponge_kernel<17, true, 0>"}[kind.value]
-    launches = phases.value
+             4: "sponge_kernel<17, true, 0>",
+             5: "sponge_kernel<17, false, 0> head + remainder (wave-quantisation split)"}[kind.value]
+    launches = phases.value if kind.value != 5 else 1  # a split launch is priced as one step-long launch
 
     # HBM traffic of the dominant kernel: PMC counters cannot be collected from inside the timed process, so the
     # figure measured with `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` on this same command (separate passes,
     # gfx950 x2 read correction per MI355X_MICROARCH.md) is read from profiles/ when it was taken for the same kernel
     # at the same batch.  Per launch, like `achieved`.
+    # The summary is used only if it was taken on this build (kernel source digest), for this kernel, batch and stride;
+    # otherwise traffic is null rather than stale.
     traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as f:
-            pm = json.load(f)
+    pm_file, pm = pmc_summary()
+    ed_pmc = None
+    if pm:
+        meta = pm.get("_meta", {})
         for k, e in pm.items():
-            if kname.split("<")[0] + "<" in k and int(e.get("_items", e.get("_grid", 0))) == B and \
-                    "hbm_read_bytes_corrected_x2" in e:
+            if k == "_meta":
+                continue
+            if kname.split("<")[0] + "<" in k and int(e.get("_items", 0)) == B and \
+                    int(meta.get("msg_stride", 0)) == MSG_STRIDE and "hbm_read_bytes_corrected_x2" in e:
                 traffic = e["hbm_read_bytes_corrected_x2"] + e.get("hbm_write_bytes", 0.0)
-    except (OSError, ValueError):
-        pass
+            if k.startswith("capy::vb2_kernel") or k.startswith("capy::vb_kernel"):
+                if "valu_insts_per_wave" in e and (ed_pmc is None or k.startswith("capy::vb2_kernel")):
+                    ed_pmc = (k, e)
+
+    # measured VALU ceiling of this box, live: nothing but permutations, 16 waves per SIMD, rolled form with the round
+    # constants fetched one trip ahead (the best form, profiles/r01_keccak_loop_forms.txt)
+    valu_live = None
+    if rank == 0:
+        chk = torch.zeros(1, dtype=torch.int64, device=dev)
+        n_states, iters = 16384 * 64, 600
+        _lib.check(lib.capy_keccak_valu_probe_dev(n_states, (2 << 30) | 60, chk.data_ptr(), sp))
+        torch.cuda.synchronize()
+        p0, p1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        p0.record(stream)
+        _lib.check(lib.capy_keccak_valu_probe_dev(n_states, (2 << 30) | iters, chk.data_ptr(), sp))
+        p1.record(stream)
+        torch.cuda.synchronize()
+        valu_live = n_states * iters / (p0.elapsed_time(p1) * 1e-3) * 136.0 / 1e9
 
     if rank == 0:
         total_bytes = world * B * MSG_BYTES * a.steps
@@ -323,16 +379,41 @@ def main():
                        "parallelism": "batch-sharded x%d, no collective" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_note": "bytes per launch from profiles/r01_pmc_summary.json (rocprofv3 PMC: FETCH_SIZE x2 "
-                                         "= TCC_EA0_RDREQ x 128 B, all requests are 128-B; + WRITE_SIZE); "
-                                         "algorithmic per launch = %d"
-                                         % algo_bytes,
+                         "traffic_note": ("bytes per launch from profiles/%s (rocprofv3 PMC on this build of the kernels: "
+                                          "FETCH_SIZE x2 = TCC_EA0_RDREQ x 128 B, all requests are 128-B; + WRITE_SIZE)"
+                                          % pm_file) if traffic is not None else
+                                         "no PMC summary in profiles/ for this build / kernel / batch / stride",
+                         "algorithmic_bytes_per_launch": algo_bytes,
                          "kernel": kname, "launches_per_step": launches, "kernel_ms": launch_ms,
-                         "valu_ceiling_GBs": VALU_CEIL_GBS, "frac_of_valu_ceiling": achieved / VALU_CEIL_GBS},
+                         # the binding resource is integer VALU issue, not HBM: measured ceilings
+                         "binding_resource": "valu",
+                         "valu_ceiling_GBs": valu_live if valu_live else VALU_CEIL_GBS,
+                         "valu_ceiling_source": "bare permutation loop at 16 waves per SIMD, measured in this run"
+                                                if valu_live else "profiles/r01_keccak_loop_forms.txt",
+                         "frac_of_valu_ceiling": achieved / (valu_live if valu_live else VALU_CEIL_GBS),
+                         "valu_arch_ceiling_GBs": VALU_ARCH_CEIL_GBS,
+                         "frac_of_valu_arch_ceiling": achieved / VALU_ARCH_CEIL_GBS},
         }
         if ed:
             res["ed448_scalar_mults_per_s"] = ed["scalar_mults_per_s"]
             res["ed448"] = ed
+            # Ed448 is integer-multiply VALU bound: instructions per scalar multiplication from the PMC
+            # summary of this build, achieved wave-instructions/s from the live kernel time, against the single-issue
+            # ceiling of 1024 SIMDs (one VALU instruction per ~4 cycles per wave, two waves per SIMD gain nothing for
+            # the v_mad_u64_u32-heavy mix: profiles/r01_valu_microbench.txt)
+            if ed_pmc:
+                kn, e = ed_pmc
+                per_lane = 2 if "vb2" in kn else 1
+                insts_unit = e["valu_insts_per_wave"] / per_lane
+                waves = (ed["pairs_per_gpu"] + 64 * per_lane - 1) // (64 * per_lane)
+                ach = waves * e["valu_insts_per_wave"] / (ed["kernel_ms"] * 1e-3)
+                clk = e.get("effective_clock_GHz", 2.4)
+                ceil_ = 1024 * clk * 1e9 / 4.0
+                ed["roofline"] = {"bound": "valu (integer multiply-add issue)", "kernel": kn.split("(")[0],
+                                  "valu_insts_per_unit": insts_unit, "achieved": ach / 1e9, "unit": "G wave-instructions/s",
+                                  "peak": ceil_ / 1e9, "frac": ach / ceil_, "clock_GHz": clk,
+                                  "peak_note": "1024 SIMDs x clock / 4 cycles per instruction (single-wave issue rate)",
+                                  "source": "profiles/%s" % pm_file}
         if not a.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(a.cpu_seconds)
             if ed:

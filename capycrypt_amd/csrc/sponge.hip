@@ -301,6 +301,8 @@ static const size_t FUSED_MAX_ITEMS = 16384;  // 16 items per wave x one wave pe
 //                    latency-tuned instance
 
 static std::atomic<bool> g_mixed_enabled{true};
+// largest batch that takes the one-wave-per-item encrypt kernel: half a wave per SIMD (CAPY_WIDE_MAX overrides)
+static size_t wide_max_items();
 
 // SIMDs of the current device (4 per CU)
 static unsigned device_simds()
@@ -316,6 +318,15 @@ static unsigned device_simds()
         cached[dev].store(v);
     }
     return v;
+}
+
+static size_t wide_max_items()
+{
+    static const long forced = [] {
+        const char *e = getenv("CAPY_WIDE_MAX");
+        return e ? atol(e) : -1L;
+    }();
+    return forced >= 0 ? (size_t)forced : device_simds() / 2;
 }
 
 // speed of the two-lane form relative to the one-lane form, per sponge, one wave per SIMD (40.4 vs 59.7 ms per MiB of
@@ -419,6 +430,20 @@ static int sponge_plan(int rw, const SpongeParams &p, int *phases)
     if ((forced == 3 || (forced == 0 && g_mixed_enabled.load())) && mixed_plan(rw, p, forced == 3, m)) {
         *phases = (int)m.P;
         return 3;
+    }
+    // the wave-quantisation split of launch_sponge(): a full-chip head of 64 S one-lane sponges + a remainder that
+    // takes the two-lane kernel or the rotating schedule
+    if (forced == 0 && !p.offsets && !p.mask && !p.order && p.n > 64 * simds && p.n < 128 * simds) {
+        SpongeParams tail = p;
+        tail.n = p.n - 64 * simds;
+        if (tail.n <= 32 * simds) {
+            *phases = 2;
+            return 5;
+        }
+        if (g_mixed_enabled.load() && mixed_plan(rw, tail, false, m)) {
+            *phases = 1 + (int)m.P;
+            return 5;
+        }
     }
     if (forced == 2 || ((forced == 0 || forced == 3) && p.n <= 32 * simds)) return 2;
     return p.n > 128 * simds ? 4 : 1;
@@ -594,12 +619,16 @@ static int sha3_launch(int d, size_t n, const MsgView &m, uint8_t *digests, uint
 }
 
 // cSHAKE (cshake, shake_functions.rs:49-64): N, S shared by the batch, no per-item head
+// body_has_trailer: the messages already end in the reference's `04 || 06 || pad` trailer (the N = S = "" corner,
+// see capy_cshake_batch); no suffix is appended, only the final pad-if-unaligned of sponge_absorb.
 static int cshake_launch(int d, size_t n, const MsgView &m, size_t l_bits, const uint8_t *fn, size_t fn_len,
-                         const uint8_t *cs, size_t cs_len, uint8_t *outs, uint64_t out_stride, hipStream_t s)
+                         const uint8_t *cs, size_t cs_len, uint8_t *outs, uint64_t out_stride, hipStream_t s,
+                         bool body_has_trailer = false)
 {
     if (!valid_d(d)) return fail(CAPY_ERR_UNSUPPORTED_SECPARAM, "unsupported security parameter");
-    if (fn_len == 0 && cs_len == 0)
-        return fail(CAPY_ERR_UNSUPPORTED, "cshake with empty N and S (shake_functions.rs:59-61) is not exposed");
+    if (fn_len == 0 && cs_len == 0 && !body_has_trailer)
+        return fail(CAPY_ERR_UNSUPPORTED,
+                    "cshake with empty N and S (shake_functions.rs:59-61) is served by the host-buffer entry point only");
     Framing f = cshake_framing(d);
     SpongeParams p;
     memset(&p, 0, sizeof p);
@@ -608,7 +637,7 @@ static int cshake_launch(int d, size_t n, const MsgView &m, size_t l_bits, const
     body_args(p, m);
     p.absorb_body = 1;
     p.suffix = 0x04;
-    p.suffix_len = 1;
+    p.suffix_len = body_has_trailer ? 0 : 1;
     p.stride_bytes = f.stride;
     p.out_mode = 0;
     p.sq_words = f.sq_words;
@@ -851,6 +880,14 @@ int symmetric_crypt_dev(bool encrypt, int d, size_t n, const uint8_t *keka, size
         fp.tag_len = (uint32_t)tag_len;
         fp.decrypt = encrypt ? 0 : 1;
         fp.n = n;
+        // One wave per item (sponge_wide.h) while every wave still has most of a SIMD pair's LDS bandwidth to itself:
+        // 1.3x per permutation at n = 128, break-even near one wave per SIMD (profiles/r02_wide_lane_probe.txt).
+        // Worth it only when the serial chains are long; debug bits 4 / 5: never / always (A/B and tests).
+        {
+            const unsigned dbg = g_debug_flags.load();
+            const uint64_t max_len = m.offsets ? ~0ULL : m.uniform_len;
+            fp.wide = (dbg & 32) || (!(dbg & 16) && n <= wide_max_items() && max_len >= 64 * 1024) ? 1 : 0;
+        }
         fp.tags = encrypt ? tags : tag2;
         CAPY_HIP(launch_sponge_fused(ff.rw, fp, s));
         if (encrypt) return CAPY_OK;
@@ -1159,12 +1196,42 @@ int capy_cshake_batch(int d, size_t n, const uint8_t *xs, const uint64_t *offset
     CAPY_SHARD(n, offsets, capy_cshake_batch(d, count, xs, offsets + first, l_bits, fn_name, fn_len, custom, custom_len,
                                              outs + first * (l_bits / 8)));
     PackedBatch b;
-    int rc = b.upload(n, xs, offsets);
+    int rc;
+    const bool empty_ns = fn_len == 0 && custom_len == 0;
+    if (empty_ns) {
+        // cshake(x, l, "", "", d), shake_functions.rs:59-61: the reference runs shake() on the framed buffer, drops its
+        // digest and KEEPS its mutation -- the SHA3 suffix (06, or 86 when the length is 135 mod 136) and, when the
+        // result is not a multiple of the SHA3-d rate (1600 - 2d)/8, pad10*1 up to it -- and then absorbs that buffer
+        // at capacity d.  Unreachable through the public API (kmac_xof passes N = "KMAC"); reproduced here by giving
+        // every message its trailer on the host and absorbing it without a further suffix.
+        const uint64_t w = (1600 - (uint64_t)d) / 8, r1 = (1600 - 2 * (uint64_t)d) / 8;
+        std::vector<uint8_t> ys;
+        std::vector<uint64_t> yoff(n + 1, 0);
+        for (size_t i = 0; i < n; i++) {
+            if (offsets[i + 1] < offsets[i]) return fail(CAPY_ERR_ARG, "offsets must be non-decreasing");
+            const uint64_t len = offsets[i + 1] - offsets[i];
+            if (len) ys.insert(ys.end(), xs + offsets[i], xs + offsets[i + 1]);
+            ys.push_back(0x04);
+            uint64_t L = w + len + 1;  // bytepad(encode_string("") || encode_string(""), w) is exactly one block of w bytes
+            ys.push_back((136 - L % 136) == 1 ? 0x86 : 0x06);
+            L += 1;
+            if (L % r1) {
+                const uint64_t q = r1 - L % r1;
+                ys.insert(ys.end(), q, 0);
+                ys.back() = 0x80;
+            }
+            yoff[i + 1] = ys.size();
+        }
+        rc = b.upload(n, ys.data(), yoff.data());
+    } else {
+        rc = b.upload(n, xs, offsets);
+    }
     if (rc) return rc;
     const size_t ol = l_bits / 8, os = (ol + 7) & ~(size_t)7;
     DevBuf out;
     CAPY_HIP(out.alloc(n * os));
-    rc = cshake_launch(d, n, view_of(b), l_bits, fn_name, fn_len, custom, custom_len, out.as<uint8_t>(), os, nullptr);
+    rc = cshake_launch(d, n, view_of(b), l_bits, fn_name, fn_len, custom, custom_len, out.as<uint8_t>(), os, nullptr,
+                       empty_ns);
     if (rc) return rc;
     if (ol) CAPY_HIP(hipMemcpy2D(outs, ol, out.p, os, ol, n, hipMemcpyDeviceToHost));
     return CAPY_OK;

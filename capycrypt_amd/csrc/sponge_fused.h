@@ -39,6 +39,7 @@ struct FusedParams {
     uint32_t tag_len;
     uint32_t decrypt;
     const uint32_t *order;  // optional processing order, see SpongeParams::order
+    uint32_t wide;          // launcher's choice: 1 = one wave per item (sponge_wide.h), 0 = four lanes per item (here)
     uint64_t n;
 };
 

@@ -1,11 +1,22 @@
 // sponge_fused.hip — instances of sponge_fused_crypt_kernel<RW> (see sponge_fused.h)
 #include "sponge_fused.h"
+#include "sponge_wide.h"
 #include "sponge_launch.h"
 
 namespace capy {
 
 hipError_t launch_sponge_fused(int rw, const FusedParams &fp, hipStream_t s)
 {
+    if (fp.wide) {  // very small batches: one wave per item, a sponge spread over 25 lanes
+        const dim3 wgrid((unsigned)fp.n), wblock(64);
+        switch (rw) {
+        case 17: hipLaunchKernelGGL(sponge_wide_crypt_kernel<17>, wgrid, wblock, 0, s, fp); break;
+        case 19: hipLaunchKernelGGL(sponge_wide_crypt_kernel<19>, wgrid, wblock, 0, s, fp); break;
+        case 21: hipLaunchKernelGGL(sponge_wide_crypt_kernel<21>, wgrid, wblock, 0, s, fp); break;
+        default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     const dim3 grid((unsigned)((fp.n + 15) / 16)), block(64);
     switch (rw) {
     case 17: hipLaunchKernelGGL(sponge_fused_crypt_kernel<17>, grid, block, 0, s, fp); break;

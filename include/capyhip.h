@@ -78,8 +78,9 @@ int capy_sha3_batch_dev(int d, size_t n, const uint8_t *msgs, const uint64_t *of
                         uint64_t msg_stride, uint8_t *digests, void *stream);
 
 /* cSHAKE: out_i = cshake(x_i, l_bits, N, S, d).  outs: n * l_bits/8 bytes.
- * Replaces cshake(), src/sha3/shake_functions.rs:49-64 (capacity = d).  N = S = "" is rejected with
- * CAPY_ERR_UNSUPPORTED (crate-internal corner, :59-61, unreachable through kmac_xof). */
+ * Replaces cshake(), src/sha3/shake_functions.rs:49-64 (capacity = d), including its N = S = "" corner (:59-61: the
+ * dropped shake() call whose buffer mutation is kept), which the host-buffer form reproduces bit for bit; the device
+ * form answers that corner with CAPY_ERR_UNSUPPORTED (crate-internal, unreachable through kmac_xof). */
 int capy_cshake_batch(int d, size_t n, const uint8_t *xs, const uint64_t *offsets, size_t l_bits,
                       const uint8_t *fn_name, size_t fn_len, const uint8_t *custom, size_t custom_len,
                       uint8_t *outs);
@@ -199,7 +200,8 @@ int capy_set_sponge_lanes(int lanes);
 
 /* Which kernel a uniform, 8-byte aligned capy_sha3_batch_dev() launch of this shape takes on the current device
  * (so that a profile can be read against the right kernel name): *kind = 1 sponge_kernel<RW,false,0>,
- * 2 sponge_kernel_k2<RW,0>, 3 sponge_mixed_kernel<RW> launched *phases times, 4 sponge_kernel<RW,true,0>. */
+ * 2 sponge_kernel_k2<RW,0>, 3 sponge_mixed_kernel<RW> launched *phases times, 4 sponge_kernel<RW,true,0>,
+ * 5 a full-chip head on sponge_kernel<RW,false,0> plus a remainder on kind 2 or 3 (*phases = launches in all). */
 int capy_sha3_launch_plan(int d, size_t n, uint64_t uniform_len, uint64_t msg_stride, int *kind, int *phases);
 /* Fill a device buffer with the harness PRNG (SplitMix64 counter mode, seed + 8-byte word index). */
 int capy_fill_random_dev(uint8_t *dst, uint64_t nbytes, uint64_t seed, void *stream);

@@ -1,0 +1,89 @@
+// gen_ref_ed448.rs — emits tests/golden/ref_ed448.json from the REAL reference (crate capycrypt 0.7.5 with its
+// tiny_ed448_goldilocks 0.1.8), for the fixed (pw, msg, d) tuples and scalars of tests/golden/ed448_vectors.json.
+//
+// The build environment of capyhip has no Rust toolchain and the curve crate is not vendored, so this file has never
+// been compiled there: it is the recipe a maintainer with cargo runs ONCE to pin the Ed448 half of the oracle to
+// the reference itself ("parity unpinned").  Usage, from a checkout of Dustin-Ray/capyCRYPT:
+//
+//     mkdir -p examples && cp <capyhip>/tests/golden/gen_ref_ed448.rs examples/
+//     cargo run --release --example gen_ref_ed448 -- <capyhip>/tests/golden/ed448_vectors.json \
+//         > <capyhip>/tests/golden/ref_ed448.json
+//
+// tests/test_oracle_ed448.py::test_reference_emitted_vectors consumes ref_ed448.json when it exists (skips otherwise):
+// every public key, (h, z) signature and [k]G below must equal the oracle's, byte for byte.  That check machine-tests
+// the three assumptions DESIGN.md records about the absent crate: (i) ExtendedPoint::generator() is the RFC 8032 base
+// point, (ii) FieldElement::to_bytes() is 56-byte little-endian canonical, (iii) Scalar `*`, `-`, mul_mod are
+// arithmetic mod r with reduced results.
+//
+// Only public API of the two crates is used (the call sites of /root/reference/src/ecc/keypair.rs:41-51 and
+// src/ecc/signable.rs:40-57; byte conversions as src/sha3/aux_functions.rs:102-110).
+use capycrypt::{
+    ecc::{keypair::KeyPair, signable::Signable},
+    Message, SecParam,
+};
+use crypto_bigint::{Encoding, U448};
+use serde_json::{json, Value};
+use tiny_ed448_goldilocks::curve::{extended_edwards::ExtendedPoint, field::scalar::Scalar};
+
+fn sec_param(d: u64) -> SecParam {
+    match d {
+        224 => SecParam::D224,
+        256 => SecParam::D256,
+        384 => SecParam::D384,
+        512 => SecParam::D512,
+        _ => panic!("unsupported d"),
+    }
+}
+
+/// affine x || y, 56-byte little-endian each: the layout of every point at the capyhip C ABI
+fn point_xy_hex(p: &ExtendedPoint) -> String {
+    let a = p.to_affine();
+    let mut v = a.x.to_bytes().to_vec();
+    v.extend_from_slice(&a.y.to_bytes());
+    hex::encode(v)
+}
+
+fn main() {
+    let path = std::env::args().nth(1).expect("path to ed448_vectors.json");
+    let doc: Value = serde_json::from_str(&std::fs::read_to_string(path).unwrap()).unwrap();
+    let mut sign = Vec::new();
+    for t in doc["sign"].as_array().unwrap() {
+        let d = sec_param(t["d"].as_u64().unwrap());
+        let pw = hex::decode(t["pw"].as_str().unwrap()).unwrap();
+        let msg = hex::decode(t["msg"].as_str().unwrap()).unwrap();
+        let kp = KeyPair::new(&pw, "gen".to_string(), d);
+        let mut m = Message::new(msg);
+        m.sign(&kp, d);
+        assert!(m.verify(&kp.pub_key).is_ok());
+        let sig = m.sig.as_ref().unwrap();
+        sign.push(json!({
+            "d": t["d"], "pw": t["pw"], "msg": t["msg"],
+            "pub": point_xy_hex(&kp.pub_key),
+            "h": hex::encode(&sig.h),
+            "z": hex::encode(sig.z.val.to_be_bytes()),
+        }));
+    }
+    // [k]G for every committed scalar (56-byte big-endian, unreduced, exactly as bytes_to_scalar builds it)
+    let mut basemul = Vec::new();
+    for t in doc["scalarmul"].as_array().unwrap() {
+        let k = hex::decode(t["k"].as_str().unwrap()).unwrap();
+        let s = Scalar { val: U448::from_be_slice(&k) };
+        basemul.push(json!({ "k": t["k"], "out": point_xy_hex(&(ExtendedPoint::generator() * s)) }));
+    }
+    // the scalar-field identities assumption (iii) rests on: 4*k via mul_mod, via `*`, and k - h*s
+    let mut scalars = Vec::new();
+    for t in doc["scalarmul"].as_array().unwrap().iter().take(16) {
+        let k = Scalar { val: U448::from_be_slice(&hex::decode(t["k"].as_str().unwrap()).unwrap()) };
+        let four = Scalar::from(4_u64);
+        scalars.push(json!({
+            "k": t["k"],
+            "mul_mod_4": hex::encode(k.mul_mod(&four).val.to_be_bytes()),
+            "star_4": hex::encode((k * four).val.to_be_bytes()),
+            "k_minus_4k": hex::encode((k - k.mul_mod(&four)).val.to_be_bytes()),
+        }));
+    }
+    println!("{}", serde_json::to_string_pretty(&json!({
+        "_comment": "emitted by tests/golden/gen_ref_ed448.rs from capycrypt 0.7.5 / tiny_ed448_goldilocks 0.1.8",
+        "sign": sign, "basemul": basemul, "scalars": scalars,
+    })).unwrap());
+}

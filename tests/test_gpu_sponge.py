@@ -30,12 +30,13 @@ def O():
     return oracle
 
 
-@pytest.fixture(autouse=True, params=[1, 2, 1 | (1 << 16), 2 | (1 << 8)],
+@pytest.fixture(autouse=True, params=[1, 2, 1 | (1 << 16), 2 | (1 << 8), 2 | (32 << 8)],
                 ids=["lane-per-sponge", "two-lanes-per-sponge", "lane-per-sponge,two-pass-encrypt",
-                     "two-lanes,no-uniform-addressing"])
+                     "two-lanes,no-uniform-addressing", "two-lanes,wave-per-item-encrypt"])
 def sponge_lanes(request):
     """Every test runs against both sponge kernels (sponge_kernels.h / sponge_kernels_k2.h), with the fused
-    one-pass encrypt kernel (sponge_fused.h) on and off, and with the wave-uniform addressing path off."""
+    one-pass encrypt kernel (sponge_fused.h) on and off, with the wave-uniform addressing path off, and with the
+    one-wave-per-item encrypt kernel (sponge_wide.h) forced for every batch it can take."""
     from capycrypt_amd import _lib
 
     _lib.check(_lib.lib().capy_set_sponge_lanes(request.param))
@@ -113,12 +114,28 @@ def test_cshake_matches_oracle(capy, O, d):
         assert capy.ops.cshake_batch(msgs, l, n, s, d) == [O.cshake(m, l, n, s, d) for m in msgs]
 
 
-def test_cshake_empty_n_and_s_is_rejected(capy):
-    from capycrypt_amd._lib import CapyHipError
+@pytest.mark.parametrize("d", [224, 256, 384, 512])
+def test_cshake_empty_n_and_s_matches_the_reference_corner(capy, O, d):
+    """cshake(x, l, "", "", d), /root/reference/src/sha3/shake_functions.rs:59-61: the dropped shake() call mutates
+    the framed buffer (SHA3 suffix + pad to the SHA3-d rate) before the absorb at capacity d.  The oracle models it
+    (oracle_sponge.c, quirks = 1); lengths on both rates' block boundaries and the 135-mod-136 suffix switch."""
+    rng = random.Random(900 + d)
+    w, r1 = (1600 - d) // 8, (1600 - 2 * d) // 8
+    lens = sorted(set(LENS + [136 - (w + 1) % 136 + 135 - 136 * k for k in (0, -1)] + [r1 - 2, r1 - 1, r1, 2 * r1 - w % r1]))
+    msgs = [rng.randbytes(max(0, n)) for n in lens]
+    for l in (8, 256, 1600):
+        assert capy.ops.cshake_batch(msgs, l, b"", b"", d) == [O.cshake(m, l, b"", b"", d) for m in msgs]
 
-    with pytest.raises(CapyHipError) as e:
-        capy.ops.cshake_batch([b"abc"], 256, b"", b"", 256)
-    assert e.value.code == -4
+
+def test_cshake_empty_n_and_s_device_form_is_rejected(capy):
+    import torch
+
+    from capycrypt_amd import _lib
+
+    x = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    out = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    rc = _lib.lib().capy_cshake_batch_dev(256, 1, x.data_ptr(), None, 8, 8, 256, b"", 0, b"", 0, out.data_ptr(), 32, None)
+    assert rc == _lib.CAPY_ERR_UNSUPPORTED
 
 
 def test_unsupported_security_parameter(capy):

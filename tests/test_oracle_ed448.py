@@ -148,6 +148,31 @@ def test_golden_fixture_matches_oracle():
         assert O.keypair_pub(bytes.fromhex(t["pw"]), t["d"]).hex() == t["pub"]
 
 
+def test_reference_emitted_vectors():
+    """tests/golden/ref_ed448.json is emitted by tests/golden/gen_ref_ed448.rs from the REAL reference crate (a
+    maintainer with cargo runs it; this build environment has no Rust toolchain).  When the file exists every public
+    key, signature, [k]G and scalar identity in it must equal the oracle's -- which pins assumptions (i)-(iii) of
+    DESIGN.md section 2 to the reference itself."""
+    import pytest
+
+    path = os.path.join(HERE, "golden", "ref_ed448.json")
+    if not os.path.exists(path):
+        pytest.skip("ref_ed448.json not generated (needs cargo + the reference crate, see gen_ref_ed448.rs)")
+    with open(path) as f:
+        v = json.load(f)
+    for t in v["sign"]:
+        pw, msg = H(t["pw"]), H(t["msg"])
+        assert O.keypair_pub(pw, t["d"]).hex() == t["pub"]
+        h, z = O.sign(pw, msg, t["d"])
+        assert (h.hex(), z.hex()) == (t["h"], t["z"])
+    for t in v["basemul"]:
+        assert O.ed448_basemul(H(t["k"])).hex() == t["out"]
+    for t in v["scalars"]:
+        k = int(t["k"], 16)
+        assert t["mul_mod_4"] == t["star_4"] == E.sc_to_bytes(4 * k % E.R).hex()
+        assert t["k_minus_4k"] == E.sc_to_bytes((k - 4 * k) % E.R).hex()
+
+
 def test_protocol_roundtrips():
     rng = random.Random(5)
     for d in (256, 512):

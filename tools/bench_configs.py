@@ -56,7 +56,7 @@ emit(config=2, what="2^20 x KMACXOF256 1 KiB squeeze (64-B keys)", seconds=s, un
 del keys, out
 
 # ---- config 3: sha3_encrypt D512 over 5 MiB messages: 128 per GPU (the 8-GPU split of 1024) and a larger batch
-for nmsg in (128, 2048, 16384):
+for nmsg in (128, 512, 2048, 16384):
     msgs = rand(nmsg * MIB5, 3)
     pws = rand(nmsg * 64, 31)
     zs = rand(nmsg * 512, 32)
@@ -82,8 +82,22 @@ for nmsg in (128, 2048, 16384):
     torch.cuda.synchronize()
     td = time.perf_counter() - t0
     ok = bool((status == 0).all().item()) and bool((msgs[:4096] == before).all().item())
+    # Every sponge is a strict chain of permutations; with fewer sponges than the chip has lanes the call cannot be
+    # faster than ONE chain.  blocks: bytepad(encode_string(ka)) 1 + message 38 550 full + tail/suffix 1 + the
+    # keystream sponge's suffix step 1.  Bounds per permutation: the two-lane form's issue bound (24 rounds x 120 VALU
+    # x 4.04 cycles), and for the one-wave-per-item form (n <= 512, sponge_wide.h) an estimated floor of three
+    # dependent LDS round trips (~64 cycles each) + ~22 VALU x 4 cycles per round; 2.38 GHz.
+    perms = MIB5 // 136 + 3
+    two_lane_bound = perms * 24 * 120 * 4.04 / 2.38e9
+    wide_floor = perms * 24 * (3 * 64 + 22 * 4) / 2.38e9
+    kernel = "sponge_wide_crypt_kernel<17>" if nmsg <= 512 else "sponge_fused_crypt_kernel<17>"
+    bound = wide_floor if nmsg <= 512 else two_lane_bound
     emit(config=3, what="sha3_encrypt / sha3_decrypt D512, %d x 5 MiB" % nmsg, enc_seconds=te, dec_seconds=td,
-         enc_GiBps=nmsg * MIB5 / te / 2**30, dec_GiBps=nmsg * MIB5 / td / 2**30, roundtrip_ok=ok)
+         enc_GiBps=nmsg * MIB5 / te / 2**30, dec_GiBps=nmsg * MIB5 / td / 2**30, roundtrip_ok=ok, kernel=kernel,
+         algorithmic_GBps=2 * nmsg * MIB5 / te / 1e9, frac_of_hbm_peak=2 * nmsg * MIB5 / te / 8e12,
+         chain={"permutations_per_sponge": perms, "us_per_permutation": te / perms * 1e6,
+                "two_lane_issue_bound_s": two_lane_bound, "wide_latency_floor_s": wide_floor,
+                "chain_bound_s": bound, "frac_of_chain_bound": bound / te})
     del msgs
 
 # ---- config 4: Ed448 variable-base / fixed-base / double-scalar, 2^18 pairs

@@ -4,7 +4,7 @@
 # Writes raw rocprofv3 output under gpurun_out/ and the summaries under profiles/<round>_*.
 # Counter passes are separate runs (rocprofv3 refuses / mis-handles large counter sets; never mix --pmc with traces).
 set -o pipefail
-R=${1:-r01}
+R=${1:-r02}
 export TMPDIR=/tmp
 OUT=gpurun_out
 mkdir -p $OUT profiles
@@ -19,7 +19,9 @@ for C in "FETCH_SIZE" "WRITE_SIZE" \
         python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/pmc_$n.log 2>&1 || echo "PMC pass $n failed"
 done
 B=$(python -c "import json;print(json.load(open('profiles/${R}_bench_line.json'))['config']['batch_per_gpu'])")
-CAPY_PMC_ITEMS=$B python tools/summarize_pmc.py profiles/${R}_pmc_summary.json $OUT/pmc_${R}_FETCH_SIZE $OUT/pmc_${R}_WRITE_SIZE $OUT/pmc_${R}_SQ_WAVES
+S=$(python -c "import json;print(json.load(open('profiles/${R}_bench_line.json'))['config']['msg_stride'])")
+D=$(python -c "import bench;print(bench.kernel_source_digest())")
+CAPY_PMC_ITEMS=$B CAPY_PMC_STRIDE=$S CAPY_PMC_DIGEST=$D python tools/summarize_pmc.py profiles/${R}_pmc_summary.json $OUT/pmc_${R}_FETCH_SIZE $OUT/pmc_${R}_WRITE_SIZE $OUT/pmc_${R}_SQ_WAVES
 # the contract line last: bench.py reads the traffic figure from the summary written above
 python bench.py --steps 5 --warmup 1 > $OUT/bench.json 2> $OUT/bench.err && tail -1 $OUT/bench.json > profiles/${R}_bench_line.json
 python tools/bench_configs.py 2> /dev/null > $OUT/configs.jsonl && cp $OUT/configs.jsonl profiles/${R}_configs_2_to_5.jsonl

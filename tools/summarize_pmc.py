@@ -22,7 +22,8 @@ for d in dirs:
             agg[k]["_vgpr"] = int(r["VGPR_Count"]) + int(r["Accum_VGPR_Count"])
             if os.environ.get("CAPY_PMC_ITEMS") and "sponge_" in k:
                 agg[k]["_items"] = int(os.environ["CAPY_PMC_ITEMS"])  # batch size behind the grid (bench.py matches on it)
-res = {}
+res = {"_meta": {"kernel_source_digest": os.environ.get("CAPY_PMC_DIGEST", ""),
+                 "msg_stride": int(os.environ.get("CAPY_PMC_STRIDE", "0")), "items": int(os.environ.get("CAPY_PMC_ITEMS", "0"))}}
 for k, c in agg.items():
     e = dict(c)
     if "FETCH_SIZE" in c:
@@ -43,4 +44,4 @@ for k, c in agg.items():
     res[k] = e
 with open(out, "w") as f:
     json.dump(res, f, indent=1, sort_keys=True)
-print("wrote", out, "kernels:", ", ".join(sorted(res)))
+print("wrote", out, "kernels:", ", ".join(sorted(k for k in res if k != "_meta")))
