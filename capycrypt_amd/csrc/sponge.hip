@@ -498,7 +498,16 @@ static int launch_sponge(int rw, const SpongeParams &p, hipStream_t s)
             return launch_sponge(rw, tail, s);
         }
     }
-    if (forced == 2 || ((forced == 0 || forced == 3) && p.n <= 32 * simds))
+    // Very small digest batches of long messages: one sponge per 25 lanes (sponge_wide.h), 1.3x the two-lane kernel per
+    // permutation while every wave has most of a SIMD pair's LDS bandwidth to itself (n / 2 waves <= SIMDs / 2).
+    // Debug bit 4 / 5: never / always.
+    const bool wide_ok = p.out_mode == 0 && p.pre_len == 0 && p.stride_bytes == (uint32_t)rw * 8 && !p.resume_state &&
+                         !p.head_state;
+    const uint64_t max_len = p.offsets ? ~0ULL : p.uniform_len;  // lengths of a ragged device batch are not known here
+    if (wide_ok && (((q.debug_flags & 32) && p.n <= 4096) || (forced == 0 && !(q.debug_flags & 16) && p.n <= 2 * wide_max_items() &&
+                                             p.absorb_body && max_len >= 64 * 1024)))
+        e = launch_sponge_wide_digest(rw, p2, s);
+    else if (forced == 2 || ((forced == 0 || forced == 3) && p.n <= 32 * simds))
         e = launch_sponge_k2(rw, (int)p.out_mode, p2, s);
     // ragged batches stay on the latency-tuned instance at every size: its ragged path keeps the source pointers in
     // registers and prefetches a block ahead, which the 128-VGPR issue-tuned instance cannot afford (2^18 ragged
@@ -886,7 +895,7 @@ int symmetric_crypt_dev(bool encrypt, int d, size_t n, const uint8_t *keka, size
         {
             const unsigned dbg = g_debug_flags.load();
             const uint64_t max_len = m.offsets ? ~0ULL : m.uniform_len;
-            fp.wide = (dbg & 32) || (!(dbg & 16) && n <= wide_max_items() && max_len >= 64 * 1024) ? 1 : 0;
+            fp.wide = ((dbg & 32) && n <= 4096) || (!(dbg & 16) && n <= wide_max_items() && max_len >= 64 * 1024) ? 1 : 0;
         }
         fp.tags = encrypt ? tags : tag2;
         CAPY_HIP(launch_sponge_fused(ff.rw, fp, s));

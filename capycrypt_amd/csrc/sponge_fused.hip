@@ -27,4 +27,19 @@ hipError_t launch_sponge_fused(int rw, const FusedParams &fp, hipStream_t s)
     return hipGetLastError();
 }
 
+hipError_t launch_sponge_wide_digest(int rw, const SpongeParams &p, hipStream_t s)
+{
+    const dim3 grid((unsigned)((p.n + 1) / 2)), block(64);
+    switch (rw) {
+    case 9: hipLaunchKernelGGL(sponge_wide_digest_kernel<9>, grid, block, 0, s, p); break;
+    case 13: hipLaunchKernelGGL(sponge_wide_digest_kernel<13>, grid, block, 0, s, p); break;
+    case 17: hipLaunchKernelGGL(sponge_wide_digest_kernel<17>, grid, block, 0, s, p); break;
+    case 18: hipLaunchKernelGGL(sponge_wide_digest_kernel<18>, grid, block, 0, s, p); break;
+    case 19: hipLaunchKernelGGL(sponge_wide_digest_kernel<19>, grid, block, 0, s, p); break;
+    case 21: hipLaunchKernelGGL(sponge_wide_digest_kernel<21>, grid, block, 0, s, p); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 }  // namespace capy

@@ -17,4 +17,7 @@ struct MixedParams;
 hipError_t launch_sponge_mixed(int rw, const MixedParams &q, unsigned waves, hipStream_t s);
 struct FusedParams;
 hipError_t launch_sponge_fused(int rw, const FusedParams &fp, hipStream_t s);
+// digests of very small batches of long messages: two items per wave, a sponge spread over 25 lanes (sponge_wide.h);
+// rw in {9, 13, 17, 18, 19, 21}, digest mode only, no raw prefix bytes
+hipError_t launch_sponge_wide_digest(int rw, const SpongeParams &p, hipStream_t s);
 }  // namespace capy

@@ -38,6 +38,7 @@ void ht_scalarmul(const uint8_t *k_be, const uint8_t *p_xy, uint8_t *out_xy)
     Pt r = vb_scalarmul(k_be, pt_from_affine_bytes(p_xy), t);
     pt_to_affine_bytes(out_xy, r);
 }
+int ht_validate(const uint8_t *p_xy) { return pt_validate_bytes(p_xy) ? 1 : 0; }
 void ht_add(const uint8_t *p, const uint8_t *q, uint8_t *out) { pt_to_affine_bytes(out, pt_add(pt_from_affine_bytes(p), pt_from_affine_bytes(q))); }
 void ht_dbl(const uint8_t *p, uint8_t *out) { pt_to_affine_bytes(out, pt_dbl<true>(pt_from_affine_bytes(p))); }
 // projective (X, Y, Z) x 2 as raw field bytes -> two affine points through the shared inversion; out = 224 bytes

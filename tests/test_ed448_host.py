@@ -144,3 +144,23 @@ def test_pair_affine_shares_one_inversion(L):
         assert out == affine_bytes(pts[3]) + bytes(112)
     out = call(L, "ht_pair_affine", fb(5) + fb(7) + bytes(56), fb(1) + fb(2) + bytes(56), outlen=224)
     assert out == bytes(224)
+
+
+def test_point_validation_on_the_host_build(L):
+    """pt_validate_bytes (the body of capy_ed448_validate_batch): canonical coordinates and the curve equation; the RFC 8032
+    public keys (decoded) are valid points, non-canonical encodings and off-curve pairs are not."""
+    import json
+    import os
+
+    from oracle import ed448_ref as E
+
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rfc_ed448.json")) as f:
+        v = json.load(f)
+    for t in v["rfc8032_7_4"]:
+        assert L.ht_validate(C.c_char_p(E.pt_to_bytes(E.rfc8032_decode(bytes.fromhex(t["public"]))))) == 1
+    x, y = E.scalarmul(77, E.G)
+    assert L.ht_validate(C.c_char_p(E.pt_to_bytes((0, 1)))) == 1
+    assert L.ht_validate(C.c_char_p(E.P.to_bytes(56, "little") + E.fe_to_bytes(1))) == 0        # x = p: not canonical
+    assert L.ht_validate(C.c_char_p(E.fe_to_bytes(0) + (E.P + 1).to_bytes(56, "little"))) == 0   # y = p + 1
+    assert L.ht_validate(C.c_char_p(E.fe_to_bytes(x) + E.fe_to_bytes((y + 1) % E.P))) == 0       # off the curve
+    assert L.ht_validate(C.c_char_p(bytes(112))) == 0
