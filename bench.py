@@ -333,9 +333,10 @@ def main():
             if kname.split("<")[0] + "<" in k and int(e.get("_items", 0)) == B and \
                     int(meta.get("msg_stride", 0)) == MSG_STRIDE and "hbm_read_bytes_corrected_x2" in e:
                 traffic = e["hbm_read_bytes_corrected_x2"] + e.get("hbm_write_bytes", 0.0)
-            if k.startswith("capy::vb2_kernel") or k.startswith("capy::vb_kernel"):
-                if "valu_insts_per_wave" in e and (ed_pmc is None or k.startswith("capy::vb2_kernel")):
-                    ed_pmc = (k, e)
+            # the variable-base kernel this run launches: two items per lane from 262 144 pairs (ed448.hip: pair_min_items)
+            want = "capy::vb2_kernel" if a.ed448_pairs >= 262144 else "capy::vb_kernel"
+            if k.startswith(want) and "valu_insts_per_wave" in e:
+                ed_pmc = (k, e)
 
     # measured VALU ceiling of this box, live: nothing but permutations, 16 waves per SIMD, rolled form with the round
     # constants fetched one trip ahead (the best form, profiles/r01_keccak_loop_forms.txt)
