@@ -28,7 +28,7 @@ def rand(nbytes, seed):
 
 print("# sha3_encrypt D512, n x %d bytes; seconds per call (second of two calls)" % L)
 print("%8s %12s %12s %8s %14s %14s" % ("n", "fused s", "wide s", "ratio", "wide GiB/s", "round trip"))
-for n in (32, 128, 256, 512, 1024, 2048):
+for n in [int(x) for x in os.environ.get("N_LIST", "32,128,256,512,1024,2048").split(",")]:
     msgs = rand(n * L, 3)
     plain = msgs.clone()
     pws, zs = rand(n * 64, 31), rand(n * 512, 32)
