@@ -37,13 +37,15 @@ VALU_ARCH_CEIL_GBS = 1024 * 2.4e9 / 2 / 4320 * 64 * 136.0 / 1e9
 
 
 def kernel_source_digest():
-    """sha256 over the kernel sources: a PMC summary in profiles/ is only used for the build it was taken on."""
+    """sha256 over the device code of the measured kernels (every header under csrc/ -- the sponge kernels live in
+    headers -- and ed448.hip, which holds the curve kernels): a PMC summary in profiles/ is only used for the kernels
+    it was taken on.  Host-side launch logic (sponge.hip) is covered by the kernel-name / batch / stride match."""
     import glob
     import hashlib
 
     h = hashlib.sha256()
     for f in sorted(glob.glob(os.path.join(ROOT, "capycrypt_amd", "csrc", "*.h")) +
-                    glob.glob(os.path.join(ROOT, "capycrypt_amd", "csrc", "*.hip"))):
+                    [os.path.join(ROOT, "capycrypt_amd", "csrc", "ed448.hip")]):
         with open(f, "rb") as fh:
             h.update(os.path.basename(f).encode() + b"\0" + fh.read())
     return h.hexdigest()[:16]
@@ -313,7 +315,8 @@ def main():
     _lib.check(lib.capy_sha3_launch_plan(256, B, MSG_BYTES, MSG_STRIDE, C.byref(kind), C.byref(phases)))
     kname = {1: "sponge_kernel<17, false, 0>", 2: "sponge_kernel_k2<17, 0>", 3: "sponge_mixed_kernel<17>",
              4: "sponge_kernel<17, true, 0>",
-             5: "sponge_kernel<17, false, 0> head + remainder (wave-quantisation split)"}[kind.value]
+             5: "sponge_kernel<17, false, 0> head + remainder (wave-quantisation split)",
+             6: "sponge_wide_digest_kernel<17>"}[kind.value]
     launches = phases.value if kind.value != 5 else 1  # a split launch is priced as one step-long launch
 
     # HBM traffic of the dominant kernel: PMC counters cannot be collected from inside the timed process, so the

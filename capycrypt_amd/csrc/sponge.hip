@@ -427,6 +427,8 @@ static int sponge_plan(int rw, const SpongeParams &p, int *phases)
     const size_t simds = device_simds();
     *phases = 1;
     MixedPlan m;
+    const unsigned dbg = g_debug_flags.load();
+    if (forced == 0 && !(dbg & 16) && !p.offsets && p.n <= 2 * wide_max_items() && p.uniform_len >= 64 * 1024) return 6;
     if ((forced == 3 || (forced == 0 && g_mixed_enabled.load())) && mixed_plan(rw, p, forced == 3, m)) {
         *phases = (int)m.P;
         return 3;

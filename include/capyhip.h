@@ -193,15 +193,18 @@ int capy_key_decrypt_batch_dev(int d, size_t n, const uint8_t *pws, size_t pw_le
 
 /* ------------------------------------------------------------------ measurement helpers */
 
-/* Tuning knob: GPU lanes per sponge. 0 = automatic (2 for batches of at most 32 items per SIMD, the rotating
- * one-/two-lane schedule for uniform digest batches between 32 and 64 items per SIMD, else 1), 1 or 2 = forced,
- * 3 = the rotating schedule wherever it is eligible. Results are identical either way; process-wide. */
+/* Tuning / test knob: GPU lanes per sponge. 0 = automatic (a wave per item or per two items for very small batches of
+ * long messages, 2 lanes for batches of at most 32 items per SIMD, the rotating one-/two-lane schedule for uniform
+ * digest batches between 32 and 64 items per SIMD, else 1), 1 or 2 = forced, 3 = the rotating schedule wherever it is
+ * eligible. Results are identical either way. Process-wide and not synchronised with calls in flight: set it before
+ * the threads that use the library start, not while they run. */
 int capy_set_sponge_lanes(int lanes);
 
 /* Which kernel a uniform, 8-byte aligned capy_sha3_batch_dev() launch of this shape takes on the current device
  * (so that a profile can be read against the right kernel name): *kind = 1 sponge_kernel<RW,false,0>,
  * 2 sponge_kernel_k2<RW,0>, 3 sponge_mixed_kernel<RW> launched *phases times, 4 sponge_kernel<RW,true,0>,
- * 5 a full-chip head on sponge_kernel<RW,false,0> plus a remainder on kind 2 or 3 (*phases = launches in all). */
+ * 5 a full-chip head on sponge_kernel<RW,false,0> plus a remainder on kind 2 or 3 (*phases = launches in all),
+ * 6 sponge_wide_digest_kernel<RW> (two items per wave, very small batches of long messages). */
 int capy_sha3_launch_plan(int d, size_t n, uint64_t uniform_len, uint64_t msg_stride, int *kind, int *phases);
 /* Fill a device buffer with the harness PRNG (SplitMix64 counter mode, seed + 8-byte word index). */
 int capy_fill_random_dev(uint8_t *dst, uint64_t nbytes, uint64_t seed, void *stream);
