@@ -29,6 +29,7 @@ SIGNATURES = {
     "capy_set_device": (C.c_int, [C.c_int]),
     "capy_set_devices": (C.c_int, [vp, C.c_int]),
     "capy_get_devices": (C.c_int, [vp, C.c_int]),
+    "capy_shard_plan": (C.c_int, [sz, C.c_int, vp, vp]),
     "capy_device_synchronize": (C.c_int, []),
     "capy_release_workspace": (C.c_int, []),
     "capy_sha3_batch": (C.c_int, [C.c_int, sz, vp, vp, vp]),

@@ -1146,6 +1146,14 @@ int capy_set_devices(const int *ids, int n)
     return CAPY_OK;
 }
 
+int capy_shard_plan(size_t n, int n_devices, const uint64_t *byte_offsets, uint64_t *bounds)
+{
+    if (n_devices < 1 || !bounds) return fail(CAPY_ERR_ARG, "bad shard plan request");
+    const std::vector<size_t> b = shard_bounds(n, (size_t)n_devices, byte_offsets);
+    for (int r = 0; r <= n_devices; r++) bounds[r] = b[r];
+    return CAPY_OK;
+}
+
 int capy_get_devices(int *ids, int capacity)
 {
     std::lock_guard<std::mutex> lk(g_dev_mu);

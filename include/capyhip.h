@@ -64,6 +64,10 @@ int capy_set_device(int device); /* device used by the calling thread's subseque
  * capy_get_devices writes at most `capacity` ids and returns the length of the configured list. */
 int capy_set_devices(const int *ids, int n);
 int capy_get_devices(int *ids, int capacity);
+/* The cut capy_set_devices uses: bounds[r] .. bounds[r+1] is the item range of device r of n_devices (bounds has
+ * n_devices + 1 entries).  byte_offsets = the n+1 message offsets of the call (balance by bytes: an item goes to the
+ * shard its midpoint falls in), or NULL (balance by count).  Pure host arithmetic. */
+int capy_shard_plan(size_t n, int n_devices, const uint64_t *byte_offsets, uint64_t *bounds);
 int capy_device_synchronize(void); /* every configured device, else the current one */
 /* Free the calling thread's pooled device scratch on every device (synchronises); also done when the thread ends. */
 int capy_release_workspace(void);

@@ -254,3 +254,37 @@ def test_header_declares_the_multi_device_and_per_item_key_interface():
         decl = decl[:decl.index(";")]
         assert "_offsets" in decl.split("msgs")[0].split("xs")[0], fn  # a per-item key / password offsets argument
     assert "capy_ed448_validate_batch" in txt
+
+
+def test_library_shard_plan_matches_the_python_sharding_rule():
+    """capy_set_devices cuts a batch exactly as capycrypt_amd/sharding.py does (contiguous, byte-balanced by item
+    midpoints, or count-balanced): capy_shard_plan is pure host arithmetic, no GPU involved."""
+    import ctypes as C
+    import random
+
+    from capycrypt_amd import _lib
+    from capycrypt_amd.sharding import shard_by_bytes, shard_range
+
+    lib = _lib.lib()
+    rng = random.Random(8)
+    for trial in range(60):
+        n = rng.choice([0, 1, 2, 7, 64, 1000, 4097])
+        world = rng.choice([1, 2, 3, 4, 8])
+        lens = [rng.choice([0, 0, 1, 100, 5000, rng.randrange(1, 1 << 20)]) for _ in range(n)]
+        offs = [0]
+        for x in lens:
+            offs.append(offs[-1] + x)
+        base = rng.randrange(0, 1000)  # offsets need not start at zero (a shard of a larger batch)
+        arr = (C.c_uint64 * (n + 1))(*[o + base for o in offs])
+        out = (C.c_uint64 * (world + 1))()
+        _lib.check(lib.capy_shard_plan(n, world, arr, out))
+        got = [(out[r], out[r + 1]) for r in range(world)]
+        assert got[0][0] == 0 and got[-1][1] == n and all(a <= b for a, b in got)
+        if sum(lens):
+            assert got == shard_by_bytes(lens, world), (n, world)
+        _lib.check(lib.capy_shard_plan(n, world, None, out))
+        assert [(out[r], out[r + 1]) for r in range(world)] == [shard_range(n, r, world) for r in range(world)]
+    assert lib.capy_shard_plan(5, 0, None, out) == _lib.CAPY_ERR_ARG
+    # no device list configured by default; an empty list is always accepted
+    assert lib.capy_get_devices(None, 0) == 0
+    _lib.check(lib.capy_set_devices(None, 0))
