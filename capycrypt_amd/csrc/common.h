@@ -89,6 +89,21 @@ int run_sharded(const std::vector<int> &ids, size_t n, const uint64_t *byte_offs
             return capy::run_sharded(_ids, (n), (byte_offsets), [&](size_t first, size_t count) { return (call); }); \
     } while (0)
 
+// Argument checks of the device-buffer entry points: a null pointer that a kernel would dereference must come back as
+// CAPY_ERR_ARG, never as a GPU fault.  Message / key buffers may be null only when they are empty by construction.
+#define CAPY_REQUIRE(cond, what)                                              \
+    do {                                                                       \
+        if (!(cond)) return capy::fail(CAPY_ERR_ARG, "null or invalid argument: " what); \
+    } while (0)
+inline bool msgs_ok(const uint8_t *msgs, const uint64_t *offsets, uint64_t uniform_len)
+{
+    return msgs != nullptr || (offsets == nullptr && uniform_len == 0);
+}
+inline bool keys_ok(const uint8_t *keys, size_t key_len, const uint64_t *key_offsets)
+{
+    return keys != nullptr || (key_offsets == nullptr && key_len == 0);
+}
+
 // longest per-item key / password (the per-item head builder of the kernels encodes 8*|K| in at most three bytes)
 constexpr size_t CAPY_MAX_KEY_LEN = (size_t)1 << 20;
 

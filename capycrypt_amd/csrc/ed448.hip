@@ -425,6 +425,7 @@ extern "C" {
 int capy_ed448_scalarmul_batch_dev(size_t n, const uint8_t *scalars_be, const uint8_t *points_xy, uint8_t *out_xy,
                                    void *stream)
 {
+    if (n) CAPY_REQUIRE(scalars_be && points_xy && out_xy, "scalars / points / out");
     return vb_launch(n, scalars_be, 56, points_xy, 112, out_xy, (hipStream_t)stream);
 }
 
@@ -443,6 +444,7 @@ int capy_ed448_scalarmul_batch(size_t n, const uint8_t *scalars_be, const uint8_
 
 int capy_ed448_basemul_batch_dev(size_t n, const uint8_t *scalars_be, uint8_t *out_xy, void *stream)
 {
+    if (n) CAPY_REQUIRE(scalars_be && out_xy, "scalars / out");
     return fb_launch(n, scalars_be, out_xy, (hipStream_t)stream);
 }
 
@@ -523,6 +525,8 @@ int capy_keypair_batch_dev(int d, size_t n, const uint8_t *pws, size_t pw_len, c
 {
     if (!valid_d(d)) return fail(CAPY_ERR_UNSUPPORTED_SECPARAM, "unsupported security parameter");
     if (!n) return CAPY_OK;
+    CAPY_REQUIRE(pub_xy, "pub_xy");
+    CAPY_REQUIRE(keys_ok(pws, pw_len, pw_offsets), "pws");
     hipStream_t st = (hipStream_t)stream;
     CAPY_WS(s_be, uint8_t *, st, WS_A, n * 56);
     TRY(derive_s_dev(d, n, dev_keys(pws, pw_len, pw_offsets), s_be, st));
@@ -537,6 +541,9 @@ int capy_schnorr_sign_batch_dev(int d, size_t n, const uint8_t *pws, size_t pw_l
 {
     if (!valid_d(d)) return fail(CAPY_ERR_UNSUPPORTED_SECPARAM, "unsupported security parameter");
     if (!n) return CAPY_OK;
+    CAPY_REQUIRE(h && z_be, "h / z_be");
+    CAPY_REQUIRE(keys_ok(pws, pw_len, pw_offsets), "pws");
+    CAPY_REQUIRE(msgs_ok(msgs, offsets, uniform_len), "msgs");
     return sign_dev(d, n, dev_keys(pws, pw_len, pw_offsets), view_dev(msgs, offsets, uniform_len, msg_stride), h, z_be,
                     (hipStream_t)stream);
 }
@@ -547,6 +554,8 @@ int capy_schnorr_verify_batch_dev(int d, size_t n, const uint8_t *pub_xy, const 
 {
     if (!valid_d(d)) return fail(CAPY_ERR_UNSUPPORTED_SECPARAM, "unsupported security parameter");
     if (!n) return CAPY_OK;
+    CAPY_REQUIRE(pub_xy && h && z_be && status, "pub_xy / h / z_be / status");
+    CAPY_REQUIRE(msgs_ok(msgs, offsets, uniform_len), "msgs");
     return verify_dev(d, n, pub_xy, view_dev(msgs, offsets, uniform_len, msg_stride), h, z_be, status,
                       (hipStream_t)stream);
 }
@@ -557,6 +566,8 @@ int capy_key_encrypt_batch_dev(int d, size_t n, const uint8_t *pub_xy, const uin
 {
     if (!valid_d(d)) return fail(CAPY_ERR_UNSUPPORTED_SECPARAM, "unsupported security parameter");
     if (!n) return CAPY_OK;
+    CAPY_REQUIRE(pub_xy && k_rand && z_xy && tags, "pub_xy / k_rand / z_xy / tags");
+    CAPY_REQUIRE(msgs_ok(msgs, offsets, uniform_len), "msgs");
     return key_encrypt_dev(d, n, pub_xy, k_rand, view_dev(msgs, offsets, uniform_len, msg_stride), z_xy, tags,
                            (hipStream_t)stream);
 }
@@ -567,6 +578,9 @@ int capy_key_decrypt_batch_dev(int d, size_t n, const uint8_t *pws, size_t pw_le
 {
     if (!valid_d(d)) return fail(CAPY_ERR_UNSUPPORTED_SECPARAM, "unsupported security parameter");
     if (!n) return CAPY_OK;
+    CAPY_REQUIRE(z_xy && tags && status, "z_xy / tags / status");
+    CAPY_REQUIRE(keys_ok(pws, pw_len, pw_offsets), "pws");
+    CAPY_REQUIRE(msgs_ok(msgs, offsets, uniform_len), "msgs");
     return key_decrypt_dev(d, n, dev_keys(pws, pw_len, pw_offsets), z_xy, view_dev(msgs, offsets, uniform_len, msg_stride),
                            tags, status, (hipStream_t)stream);
 }

@@ -1183,6 +1183,10 @@ int capy_device_synchronize(void)
 int capy_sha3_batch_dev(int d, size_t n, const uint8_t *msgs, const uint64_t *offsets, uint64_t uniform_len,
                         uint64_t msg_stride, uint8_t *digests, void *stream)
 {
+    if (n) {
+        CAPY_REQUIRE(digests, "digests");
+        CAPY_REQUIRE(msgs_ok(msgs, offsets, uniform_len), "msgs");
+    }
     return sha3_launch(d, n, view_dev(msgs, offsets, uniform_len, msg_stride), digests, (uint64_t)(d / 8),
                        (hipStream_t)stream);
 }
@@ -1261,6 +1265,7 @@ int capy_cshake_batch_dev(int d, size_t n, const uint8_t *xs, const uint64_t *of
                           const uint8_t *custom, size_t custom_len, uint8_t *outs, uint64_t out_stride, void *stream)
 {
     if (n && !outs) return fail(CAPY_ERR_ARG, "null argument");
+    if (n) CAPY_REQUIRE(msgs_ok(xs, offsets, uniform_len), "xs");
     if (out_stride < l_bits / 8) return fail(CAPY_ERR_ARG, "out_stride shorter than the output");
     return cshake_launch(d, n, view_dev(xs, offsets, uniform_len, msg_stride), l_bits, fn_name, fn_len, custom,
                          custom_len, outs, out_stride, (hipStream_t)stream);
@@ -1271,6 +1276,12 @@ int capy_kmac_xof_batch_dev(int d, size_t n, const uint8_t *keys, size_t key_len
                             uint64_t msg_stride, size_t l_bits, const uint8_t *custom, size_t custom_len, uint8_t *outs,
                             uint64_t out_stride, void *stream)
 {
+    if (n) {
+        CAPY_REQUIRE(outs, "outs");
+        CAPY_REQUIRE(out_stride >= l_bits / 8, "out_stride shorter than the output");
+        CAPY_REQUIRE(keys_ok(keys, key_len, key_offsets), "keys");
+        CAPY_REQUIRE(msgs_ok(xs, offsets, uniform_len), "xs");
+    }
     KeyView kv = fixed_keys(keys, key_len, key_stride);
     kv.key_offsets = key_offsets;
     return kmac_launch(d, n, kv, view_dev(xs, offsets, uniform_len, msg_stride), true, custom, custom_len, 0, outs,
@@ -1320,6 +1331,11 @@ int capy_sha3_encrypt_batch_dev(int d, size_t n, const uint8_t *pws, size_t pw_l
                                 uint64_t pws_bytes, const uint8_t *zs, uint8_t *msgs, const uint64_t *offsets,
                                 uint64_t uniform_len, uint64_t msg_stride, uint8_t *tags, void *stream)
 {
+    if (n) {
+        CAPY_REQUIRE(zs && tags, "zs / tags");
+        CAPY_REQUIRE(keys_ok(pws, pw_len, pw_offsets), "pws");
+        CAPY_REQUIRE(msgs_ok(msgs, offsets, uniform_len), "msgs");
+    }
     return sha3_crypt_dev(true, d, n, dev_keys(pws, pw_len, pw_offsets), pws_bytes, zs,
                           view_dev(msgs, offsets, uniform_len, msg_stride), tags, nullptr, (hipStream_t)stream);
 }
@@ -1329,6 +1345,11 @@ int capy_sha3_decrypt_batch_dev(int d, size_t n, const uint8_t *pws, size_t pw_l
                                 uint64_t uniform_len, uint64_t msg_stride, const uint8_t *tags, int32_t *status,
                                 void *stream)
 {
+    if (n) {
+        CAPY_REQUIRE(zs && tags && status, "zs / tags / status");
+        CAPY_REQUIRE(keys_ok(pws, pw_len, pw_offsets), "pws");
+        CAPY_REQUIRE(msgs_ok(msgs, offsets, uniform_len), "msgs");
+    }
     return sha3_crypt_dev(false, d, n, dev_keys(pws, pw_len, pw_offsets), pws_bytes, zs,
                           view_dev(msgs, offsets, uniform_len, msg_stride), const_cast<uint8_t *>(tags), status,
                           (hipStream_t)stream);

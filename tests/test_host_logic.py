@@ -288,3 +288,29 @@ def test_library_shard_plan_matches_the_python_sharding_rule():
     # no device list configured by default; an empty list is always accepted
     assert lib.capy_get_devices(None, 0) == 0
     _lib.check(lib.capy_set_devices(None, 0))
+
+
+def test_device_entry_points_reject_null_pointers_without_touching_the_gpu():
+    """A null pointer a kernel would dereference must come back as CAPY_ERR_ARG, never as a GPU fault (which can reset
+    every GPU of the host).  The checks run before any HIP call, so this needs no GPU."""
+    from capycrypt_amd import _lib
+
+    lib = _lib.lib()
+    E = _lib.CAPY_ERR_ARG
+    assert lib.capy_sha3_batch_dev(256, 4, 0x1000, None, 100, 104, None, None) == E       # no digests
+    assert lib.capy_sha3_batch_dev(256, 4, None, None, 100, 104, 0x1000, None) == E       # no messages but a length
+    assert lib.capy_cshake_batch_dev(256, 4, None, None, 8, 8, 256, b"N", 1, b"", 0, 0x1000, 32, None) == E
+    assert lib.capy_kmac_xof_batch_dev(256, 4, None, 16, 16, None, None, None, 0, 0, 256, b"", 0, 0x1000, 32, None) == E  # keys
+    assert lib.capy_kmac_xof_batch_dev(256, 4, 0x1000, 16, 16, None, None, None, 0, 0, 512, b"", 0, 0x1000, 32, None) == E  # stride
+    assert lib.capy_sha3_encrypt_batch_dev(512, 2, 0x1000, 8, None, 0, None, 0x1000, None, 64, 64, 0x1000, None) == E   # zs
+    assert lib.capy_sha3_decrypt_batch_dev(512, 2, 0x1000, 8, None, 0, 0x1000, 0x1000, None, 64, 64, 0x1000, None, None) == E  # status
+    assert lib.capy_ed448_scalarmul_batch_dev(2, 0x1000, None, 0x1000, None) == E
+    assert lib.capy_ed448_basemul_batch_dev(2, None, 0x1000, None) == E
+    assert lib.capy_ed448_validate_batch_dev(2, 0x1000, None, None) == E
+    assert lib.capy_keypair_batch_dev(512, 2, None, 8, None, 0x1000, None) == E
+    assert lib.capy_schnorr_sign_batch_dev(512, 2, 0x1000, 8, None, 0x1000, None, 64, 64, None, 0x1000, None) == E
+    assert lib.capy_schnorr_verify_batch_dev(512, 2, 0x1000, 0x1000, None, 64, 64, 0x1000, 0x1000, None, None) == E
+    assert lib.capy_key_encrypt_batch_dev(512, 2, 0x1000, None, 0x1000, None, 64, 64, 0x1000, 0x1000, None) == E
+    assert lib.capy_key_decrypt_batch_dev(512, 2, 0x1000, 8, None, 0x1000, 0x1000, None, 64, 64, None, 0x1000, None) == E
+    # n = 0 is always fine
+    assert lib.capy_sha3_batch_dev(256, 0, None, None, 0, 0, None, None) == 0
