@@ -223,6 +223,21 @@ static const uint8_t G_XY[112] = {
     0xe6, 0x1c, 0xff, 0xd3, 0x3a, 0xd7, 0xc2, 0xa0, 0x05, 0x1e, 0x9c, 0x78, 0x87, 0x40, 0x98, 0xa3, 0x6c, 0x73, 0x73,
     0xea, 0x4b, 0x62, 0xc7, 0xc9, 0x56, 0x37, 0x20, 0x76, 0x88, 0x24, 0xbc, 0xb6, 0x6e, 0x71, 0x46, 0x3f, 0x69};
 
+// The generator in use.  Default: the RFC 8032 base point above -- what `ExtendedPoint::generator()` of the absent curve
+// crate is ASSUMED to be (assumption (i)).  capy_ed448_set_generator replaces it, so that a
+// maintainer who finds the crate's generator to be a different point of the curve aligns the library in one call
+// instead of a rebuild; every fixed-base table is rebuilt lazily from the new point.
+static uint8_t g_gen_xy[112];
+static bool g_gen_set = false;
+static const uint8_t *current_generator()  // caller holds g_gtab_mu
+{
+    if (!g_gen_set) {
+        memcpy(g_gen_xy, G_XY, 112);
+        g_gen_set = true;
+    }
+    return g_gen_xy;
+}
+
 static int ensure_gtab(const uint32_t **out)
 {
     int dev = 0;
@@ -237,7 +252,7 @@ static int ensure_gtab(const uint32_t **out)
             uint32_t acc[14] = {0};
             for (int j = 0; j < FB_TAB_ENTRIES; j++) {
                 sc_to_be(sc.data() + (size_t)(row * FB_TAB_ENTRIES + j) * 56, acc);
-                memcpy(pts.data() + (size_t)(row * FB_TAB_ENTRIES + j) * 112, G_XY, 112);
+                memcpy(pts.data() + (size_t)(row * FB_TAB_ENTRIES + j) * 112, current_generator(), 112);
                 sc_add_mod(acc, pw);
             }
             for (int d = 0; d < FB_WBITS; d++) sc_dbl_mod(pw);
@@ -473,6 +488,36 @@ int capy_ed448_add_batch(size_t n, const uint8_t *p_xy, const uint8_t *q_xy, uin
                        o.as<uint8_t>());
     CAPY_HIP(hipGetLastError());
     return down(out_xy, o, n * 112);
+}
+
+int capy_ed448_get_generator(uint8_t *xy)
+{
+    if (!xy) return fail(CAPY_ERR_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(g_gtab_mu);
+    memcpy(xy, current_generator(), 112);
+    return CAPY_OK;
+}
+
+int capy_ed448_set_generator(const uint8_t *xy)
+{
+    if (xy && !pt_validate_bytes(xy)) return fail(CAPY_ERR_ARG, "generator is not a canonical point of the curve");
+    std::lock_guard<std::mutex> lk(g_gtab_mu);
+    const uint8_t *want = xy ? xy : G_XY;
+    if (memcmp(current_generator(), want, 112) == 0) return CAPY_OK;
+    // drop every device's table (built lazily again from the new point); wait for work that may still read it
+    int cur = 0;
+    const bool have_dev = hipGetDevice(&cur) == hipSuccess;
+    for (int dev = 0; dev < 64; dev++) {
+        if (!g_gtab[dev]) continue;
+        if (hipSetDevice(dev) == hipSuccess) {
+            (void)hipDeviceSynchronize();
+            (void)hipFree(g_gtab[dev]);
+        }
+        g_gtab[dev] = nullptr;
+    }
+    if (have_dev) (void)hipSetDevice(cur);
+    memcpy(g_gen_xy, want, 112);
+    return CAPY_OK;
 }
 
 int capy_ed448_validate_batch_dev(size_t n, const uint8_t *points_xy, int32_t *status, void *stream)

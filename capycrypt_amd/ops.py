@@ -183,6 +183,19 @@ def ed448_validate_batch(points_xy):
     return [status[i] == 0 for i in range(n)]
 
 
+def ed448_set_generator(xy=None):
+    """Replace the point that stands for ExtendedPoint::generator() (None: back to the RFC 8032 base point)."""
+    if xy is not None and len(bytes(xy)) != 112:
+        raise ValueError("the generator is 112 bytes (affine x || y, little-endian)")
+    L.check(L.lib().capy_ed448_set_generator(None if xy is None else L.buf(xy)))
+
+
+def ed448_get_generator():
+    out = (C.c_uint8 * 112)()
+    L.check(L.lib().capy_ed448_get_generator(out))
+    return bytes(out)
+
+
 def keypair_batch(pws, d):
     """KeyPair::new, /root/reference/src/ecc/keypair.rs:41-51 -> public keys; one password per key, any lengths."""
     d = _d(d)

@@ -142,6 +142,12 @@ int capy_kem_sponge_decrypt_batch(int d, size_t n, const uint8_t *secrets, size_
 int capy_ed448_scalarmul_batch(size_t n, const uint8_t *scalars_be, const uint8_t *points_xy, uint8_t *out_xy);
 int capy_ed448_scalarmul_batch_dev(size_t n, const uint8_t *scalars_be, const uint8_t *points_xy,
                                    uint8_t *out_xy, void *stream);
+/* The point `ExtendedPoint::generator()` stands for.  Default: the RFC 8032 Ed448 base point -- an ASSUMPTION about the
+ * absent curve crate; capy_ed448_set_generator(xy) replaces it (xy must pass the validation below;
+ * NULL restores the default) for every later fixed-base multiplication, key pair, signature and ECDHIES call of the
+ * process; the per-device fixed-base tables are rebuilt on next use.  Call it while no Ed448 work is in flight. */
+int capy_ed448_set_generator(const uint8_t *xy);
+int capy_ed448_get_generator(uint8_t *xy);
 /* out_i = [scalar_i] G — `ExtendedPoint::generator() * Scalar`
  * (src/ecc/keypair.rs:44, src/ecc/signable.rs:48,77, src/ecc/encryptable.rs:38). */
 int capy_ed448_basemul_batch(size_t n, const uint8_t *scalars_be, uint8_t *out_xy);

@@ -485,3 +485,42 @@ def test_reading_writing_keypair_and_message(capy, tmp_path):
     doc["pub_key"] = {"opaque": "whatever tiny_ed448_goldilocks writes"}
     foreign = capy.KeyPair.from_json(json.dumps(doc))
     assert foreign.pub_key == b"" and foreign.derive_pub_key(512) == kp.pub_key
+
+
+def test_generator_can_be_replaced(capy, O):
+    """capy_ed448_set_generator: the hedge for assumption (i) of DESIGN.md section 2.  With G' = [5]G every fixed-base
+    result moves to the new base ([k]G' = [5k]G), key pairs / signatures / ECDHIES stay self-consistent, and NULL
+    restores the RFC 8032 base point (the RFC key pairs come out again).  Off-curve generators are refused."""
+    from capycrypt_amd import _lib
+    from oracle import ed448_ref as E
+
+    rng = random.Random(55)
+    G = capy.ops.ed448_get_generator()
+    assert G == E.pt_to_bytes(E.G) == O.ed448_generator()
+    ks = [rng.randbytes(56) for _ in range(70)]
+    try:
+        g5 = O.ed448_basemul(E.sc_to_bytes(5))
+        capy.ops.ed448_set_generator(g5)
+        assert capy.ops.ed448_get_generator() == g5
+        assert capy.ops.ed448_basemul_batch(ks) == [O.ed448_scalarmul(k, g5) for k in ks]
+        pts = [O.ed448_basemul(rng.randbytes(56)) for _ in ks]
+        exp = [O.ed448_add(O.ed448_scalarmul(a, g5), O.ed448_scalarmul(b, p)) for a, b, p in zip(ks, ks[::-1], pts)]
+        assert capy.ops.ed448_double_scalarmul_batch(ks, ks[::-1], pts) == exp
+        pws = [rng.randbytes(rng.randrange(1, 80)) for _ in range(20)]
+        msgs = [rng.randbytes(rng.randrange(0, 500)) for _ in range(20)]
+        pubs = capy.ops.keypair_batch(pws, 512)
+        assert pubs != [O.keypair_pub(p, 512) for p in pws]  # a different base: different public keys
+        sigs = capy.ops.schnorr_sign_batch(pws, msgs, 512)
+        assert all(capy.ops.schnorr_verify_batch(pubs, msgs, sigs, 512))
+        cts, zs, tags = capy.ops.key_encrypt_batch(pubs, ks[:20], msgs, 512)
+        out, ok = capy.ops.key_decrypt_batch(pws, zs, cts, tags, 512)
+        assert all(ok) and out == msgs
+        bad = bytearray(g5)
+        bad[60] ^= 1
+        with pytest.raises(_lib.CapyHipError):
+            capy.ops.ed448_set_generator(bytes(bad))
+        assert capy.ops.ed448_get_generator() == g5
+    finally:
+        capy.ops.ed448_set_generator(None)
+    assert capy.ops.ed448_get_generator() == G
+    assert capy.ops.ed448_basemul_batch(ks) == [O.ed448_basemul(k) for k in ks]

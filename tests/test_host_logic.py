@@ -314,3 +314,30 @@ def test_device_entry_points_reject_null_pointers_without_touching_the_gpu():
     assert lib.capy_key_decrypt_batch_dev(512, 2, 0x1000, 8, None, 0x1000, 0x1000, None, 64, 64, None, 0x1000, None) == E
     # n = 0 is always fine
     assert lib.capy_sha3_batch_dev(256, 0, None, None, 0, 0, None, None) == 0
+
+
+def test_generator_setting_is_validated_on_the_host():
+    """capy_ed448_set_generator validates with the host build of the device code: no GPU needed to refuse a bad point."""
+    import ctypes as C
+
+    from capycrypt_amd import _lib
+    from oracle import ed448_ref as E
+
+    lib = _lib.lib()
+    out = (C.c_uint8 * 112)()
+    _lib.check(lib.capy_ed448_get_generator(out))
+    assert bytes(out) == E.pt_to_bytes(E.G)
+    x, y = E.scalarmul(9, E.G)
+    off = E.fe_to_bytes(x) + E.fe_to_bytes((y + 1) % E.P)
+    assert lib.capy_ed448_set_generator(_lib.buf(off)) == _lib.CAPY_ERR_ARG
+    noncanon = (x + E.P).to_bytes(57, "little")[:56] + E.fe_to_bytes(y)  # only differs when x + p < 2^448: skip otherwise
+    if x + E.P < 2 ** 448:
+        assert lib.capy_ed448_set_generator(_lib.buf(noncanon)) == _lib.CAPY_ERR_ARG
+    try:
+        _lib.check(lib.capy_ed448_set_generator(_lib.buf(E.pt_to_bytes((x, y)))))
+        _lib.check(lib.capy_ed448_get_generator(out))
+        assert bytes(out) == E.pt_to_bytes((x, y))
+    finally:
+        _lib.check(lib.capy_ed448_set_generator(None))
+    _lib.check(lib.capy_ed448_get_generator(out))
+    assert bytes(out) == E.pt_to_bytes(E.G)
