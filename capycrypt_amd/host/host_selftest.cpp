@@ -134,6 +134,30 @@ int main()
         EXPECT(kok[0] && kok[1] && !kok[2] && kok[3] && kok[4]);
         for (size_t i = 0; i < a.size(); i++) EXPECT((a[i].msg == plain[i]) == (i != 2));
     }
+    // multi-device sharding inside the library (capy_set_devices): the device list {0, 0} runs two worker threads on the
+    // one card; results must equal the single-device call
+    {
+        std::vector<Message> a, b;
+        std::vector<Bytes> pws, zs;
+        for (int i = 0; i < 37; i++) {
+            Bytes body = get_random_bytes(1 + 3001 * (size_t)i);
+            a.emplace_back(body);
+            b.emplace_back(body);
+            pws.push_back(get_random_bytes((size_t)i));
+            zs.push_back(get_random_bytes(512));
+        }
+        std::vector<Message *> pa, pb;
+        for (auto &m : a) pa.push_back(&m);
+        for (auto &m : b) pb.push_back(&m);
+        sha3_encrypt_many(pa, pws, SecParam::D512, &zs);
+        const int ids[2] = {0, 0};
+        EXPECT(capy_set_devices(ids, 2) == CAPY_OK);
+        sha3_encrypt_many(pb, pws, SecParam::D512, &zs);
+        for (size_t i = 0; i < a.size(); i++) EXPECT(a[i].msg == b[i].msg && a[i].digest == b[i].digest);
+        std::vector<bool> ok = sha3_decrypt_many(pb, pws);
+        for (size_t i = 0; i < ok.size(); i++) EXPECT(ok[i]);
+        EXPECT(capy_set_devices(nullptr, 0) == CAPY_OK);
+    }
     // the nonce source is the operating system's CSPRNG (getrandom): draws differ and are not degenerate
     {
         Bytes r1 = get_random_bytes(4096), r2 = get_random_bytes(4096);

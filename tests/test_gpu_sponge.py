@@ -682,3 +682,76 @@ def test_concurrent_host_threads(capy, O):
         for sha, kmac, (cts, tags) in results[i]:
             assert sha == exp_sha and kmac == exp_kmac
             assert cts == [e[0] for e in exp_enc] and tags == [e[1] for e in exp_enc]
+
+
+def test_d224_prefix_is_staged_without_synchronising(capy, O, sponge_lanes):
+    """cSHAKE / KMAC at d = 224 carry raw prefix bytes (r = 172 but 168 consumed per block, sponge.rs:48-55).  The *_dev
+    entry points stage them through the argument of a writer kernel -- stream-ordered, no host synchronisation -- and
+    fall back to a synchronous copy only for customisation strings beyond the inline buffer.  Back-to-back launches with
+    DIFFERENT prefixes on one stream must each see their own bytes."""
+    import torch
+
+    from capycrypt_amd import _lib
+
+    lib = _lib.lib()
+    n, L, stride = 200, 500, 504
+    msgs = _dev_rand(n * stride, 61)
+    keys = _dev_rand(n * 32, 62)
+    customs = [b"", b"A", b"Email Signature", b"x" * 100, b"y" * 161, b"z" * 163, b"w" * 400]
+    outs = [torch.zeros(n * 64, dtype=torch.uint8, device="cuda") for _ in customs]
+    for cs, out in zip(customs, outs):  # all enqueued before any is read back
+        _lib.check(lib.capy_kmac_xof_batch_dev(224, n, keys.data_ptr(), 32, 32, None, msgs.data_ptr(), None, L, stride, 512,
+                                               cs, len(cs), out.data_ptr(), 64, None))
+    torch.cuda.synchronize()
+    hk = bytes(keys.cpu().numpy())
+    for cs, out in zip(customs, outs):
+        ho = bytes(out.cpu().numpy())
+        for i in (0, 63, 64, n - 1):
+            m = bytes(msgs[i * stride:i * stride + L].cpu().numpy())
+            assert ho[64 * i:64 * i + 64] == O.kmac_xof(hk[32 * i:32 * i + 32], m, 512, cs, 224), (len(cs), i)
+
+
+def test_device_key_offsets_and_workspace_release(capy, O, sponge_lanes):
+    """Per-item key lengths through the DEVICE entry points (key_offsets / pw_offsets are device arrays), and
+    capy_release_workspace(): scratch is handed back and the next call simply allocates again."""
+    import torch
+
+    from capycrypt_amd import _lib
+
+    lib = _lib.lib()
+    rng = random.Random(5)
+    n, L, stride = 150, 300, 304
+    msgs = _dev_rand(n * stride, 71)
+    klens = [rng.choice([0, 1, 31, 64, 130, 131, 132, 200, 333]) for _ in range(n)]
+    keys_h = [rng.randbytes(k) for k in klens]
+    offs = [0]
+    for k in klens:
+        offs.append(offs[-1] + k)
+    kbuf = torch.tensor(list(b"".join(keys_h)) or [0], dtype=torch.uint8, device="cuda")
+    koff = torch.tensor(offs, dtype=torch.int64, device="cuda")
+    out = torch.zeros(n * 56, dtype=torch.uint8, device="cuda")
+    zs = _dev_rand(n * 512, 72)
+    tags = torch.zeros(n * 64, dtype=torch.uint8, device="cuda")
+    status = torch.ones(n, dtype=torch.int32, device="cuda")
+    plain = msgs.clone()
+    for round_ in range(2):
+        _lib.check(lib.capy_kmac_xof_batch_dev(512, n, kbuf.data_ptr(), 0, 0, koff.data_ptr(), msgs.data_ptr(), None, L, stride,
+                                               448, b"T", 1, out.data_ptr(), 56, None))
+        torch.cuda.synchronize()
+        ho = bytes(out.cpu().numpy())
+        for i in range(0, n, 7):
+            m = bytes(msgs[i * stride:i * stride + L].cpu().numpy())
+            assert ho[56 * i:56 * i + 56] == O.kmac_xof(keys_h[i], m, 448, b"T", 512), (klens[i], i)
+        _lib.check(lib.capy_sha3_encrypt_batch_dev(256, n, kbuf.data_ptr(), 0, koff.data_ptr(), offs[-1], zs.data_ptr(),
+                                                   msgs.data_ptr(), None, L, stride, tags.data_ptr(), None))
+        torch.cuda.synchronize()
+        hz = bytes(zs.cpu().numpy())
+        for i in (0, 1, 77, n - 1):
+            ect, etag = O.sha3_encrypt(keys_h[i], hz[512 * i:512 * i + 512], bytes(plain[i * stride:i * stride + L].cpu().numpy()), 256)
+            assert bytes(msgs[i * stride:i * stride + L].cpu().numpy()) == ect
+            assert bytes(tags[64 * i:64 * i + 64].cpu().numpy()) == etag
+        _lib.check(lib.capy_sha3_decrypt_batch_dev(256, n, kbuf.data_ptr(), 0, koff.data_ptr(), offs[-1], zs.data_ptr(),
+                                                   msgs.data_ptr(), None, L, stride, tags.data_ptr(), status.data_ptr(), None))
+        torch.cuda.synchronize()
+        assert not status.cpu().numpy().any() and torch.equal(msgs, plain)
+        _lib.check(lib.capy_release_workspace())  # the second round runs on freshly allocated scratch
