@@ -36,18 +36,21 @@ VALU_CEIL_GBS = 10.68e9 * 136.0 / 1e9
 VALU_ARCH_CEIL_GBS = 1024 * 2.4e9 / 2 / 4320 * 64 * 136.0 / 1e9
 
 
+DEVICE_HEADERS = ("keccak_dev.h", "sponge_params.h", "sponge_kernels.h", "sponge_kernels_k2.h", "sponge_mixed.h",
+                  "sponge_fused.h", "sponge_wide.h", "ed448_dev.h", "ed448_algo.h")
+
+
 def kernel_source_digest():
-    """sha256 over the device code of the measured kernels (every header under csrc/ -- the sponge kernels live in
-    headers -- and ed448.hip, which holds the curve kernels): a PMC summary in profiles/ is only used for the kernels
-    it was taken on.  Host-side launch logic (sponge.hip) is covered by the kernel-name / batch / stride match."""
-    import glob
+    """sha256 over the headers that hold the DEVICE code of the measured kernels (the sponge kernels and the whole
+    Ed448 arithmetic live in headers; the .hip files add launchers and thin __global__ wrappers): a PMC summary in
+    profiles/ is only used for the kernels it was taken on.  Host-side launch logic is covered by the kernel-name /
+    batch / stride match."""
     import hashlib
 
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "capycrypt_amd", "csrc", "*.h")) +
-                    [os.path.join(ROOT, "capycrypt_amd", "csrc", "ed448.hip")]):
-        with open(f, "rb") as fh:
-            h.update(os.path.basename(f).encode() + b"\0" + fh.read())
+    for name in DEVICE_HEADERS:
+        with open(os.path.join(ROOT, "capycrypt_amd", "csrc", name), "rb") as fh:
+            h.update(name.encode() + b"\0" + fh.read())
     return h.hexdigest()[:16]
 
 
