@@ -206,8 +206,14 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     backend = os.environ.get("CAPY_BENCH_BACKEND", "nccl")  # "gloo" only for single-GPU rehearsals of the N>1 path
-    if world > 1:
+    # CAPY_BENCH_FORCE_DIST=1: run the process-group code path (init, barrier, max-reduce) with a single rank too --
+    # the only way to exercise the RCCL calls of the N > 1 path on a one-GPU box (two ranks cannot share a device)
+    use_dist = world > 1 or os.environ.get("CAPY_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -238,7 +244,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             if backend == "nccl":
                 dist.barrier(device_ids=[dev_index])
             else:
@@ -263,7 +269,7 @@ def main():
     barrier()
     el = time.perf_counter() - t0
     kern_ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / max(1, a.steps)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([el], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
@@ -302,7 +308,7 @@ def main():
             e1.record(stream)
             barrier()
             eel = time.perf_counter() - t1
-            if world > 1:
+            if use_dist:
                 t = torch.tensor([eel], dtype=torch.float64, device=red_dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 eel = float(t.item())
@@ -426,7 +432,7 @@ def main():
             if ed:
                 res["ed448"]["cpu_port_scalar_mults_per_s_1thread"] = cpu_baseline_ed448(min(5.0, a.cpu_seconds), ed_sample)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
