@@ -62,6 +62,19 @@ int run_sharded(const std::vector<int> &ids, size_t n, const uint64_t *byte_offs
                 const std::function<int(size_t, size_t)> &body)
 {
     const size_t world = ids.size();
+    if (world == 1) {  // one device: no worker thread, just run there
+        int cur = 0;
+        const bool have = hipGetDevice(&cur) == hipSuccess;
+        if (hipSetDevice(ids[0]) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(CAPY_ERR_HIP, "hipSetDevice(" + std::to_string(ids[0]) + ") failed");
+        }
+        g_in_shard = true;
+        const int rc = body(0, n);
+        g_in_shard = false;
+        if (have) (void)hipSetDevice(cur);
+        return rc;
+    }
     const std::vector<size_t> b = shard_bounds(n, world, byte_offsets);
     std::vector<int> rcs(world, CAPY_OK);
     std::vector<std::string> errs(world);

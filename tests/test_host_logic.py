@@ -377,3 +377,23 @@ def test_cpp_mirror_json(tmp_path):
     assert json.loads(through_cpp("keypair", kp.to_json())) == json.loads(kp.to_json())
     assert through_cpp("keypair", json.dumps(json.loads(kp.to_json()), indent=2, ensure_ascii=False)) == \
         json.dumps(json.loads(kp.to_json()), indent=2, ensure_ascii=False)
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/capyhip.h is the drop-in boundary: it must compile as C99 (what cgo / bindgen / a Rust build.rs see),
+    and a C program linked against libcapyhip.so must resolve every declared symbol."""
+    import subprocess
+
+    from capycrypt_amd import _lib
+
+    names = _declared_symbols()
+    src = tmp_path / "abi.c"
+    src.write_text('#include "capyhip.h"\n#include <stdio.h>\ntypedef void (*fn)(void);\nint main(void) {\n  fn p[] = {%s};\n'
+                   '  printf("%%d\\n", (int)(sizeof p / sizeof p[0]));\n  return capy_version() == 0;\n}\n'
+                   % ", ".join("(fn)%s" % n for n in names))
+    exe = tmp_path / "abi"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src),
+                           "-o", str(exe), "-L", libdir, "-lcapyhip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0 and int(out.stdout) == len(names)
