@@ -2,6 +2,7 @@
 // (KeyPair::new, Signable, KeyEncryptable) composed from the sponge and curve kernels on device buffers.
 // No CPU fallback: every scalar multiplication, KMAC and mod-r operation of the data path runs on the GPU.
 #include <string.h>
+#include <atomic>
 #include <mutex>
 #include "common.h"
 #include "ed448_algo.h"
@@ -29,6 +30,28 @@ __global__ __launch_bounds__(64, CAPY_ED448_WAVES) void vb_kernel(uint64_t n, co
     const Pt P = pt_from_affine_bytes(points_xy + i * point_stride);
     const Pt r = vb_scalarmul(scalars_be + i * scalar_stride, P, table_ws + i * VB_TABLE_DWORDS);
     pt_to_affine_bytes(out_xy + i * 112, r);
+}
+
+// hardened form: constant-address table lookups (ed448_algo.h: vb_add_digit_ct); also serves [k]G with point_stride 0
+__global__ __launch_bounds__(64, CAPY_ED448_WAVES) void vb_ct_kernel(uint64_t n, const uint8_t *scalars_be, uint64_t scalar_stride,
+                                                   const uint8_t *points_xy, uint64_t point_stride, uint8_t *out_xy,
+                                                   uint32_t *table_ws)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    const Pt P = pt_from_affine_bytes(points_xy + i * point_stride);
+    // the wave's table, interleaved across its 64 lanes (the scratch is sized in whole waves by the launcher)
+    const CtTable t = {table_ws + (uint64_t)blockIdx.x * 64 * VB_TABLE_DWORDS, threadIdx.x, 64};
+    const Pt r = vb_scalarmul_ct(scalars_be + i * scalar_stride, P, t);
+    pt_to_affine_bytes(out_xy + i * 112, r);
+}
+
+__global__ __launch_bounds__(64, CAPY_ED448_WAVES) void fb_ct_kernel(uint64_t n, const uint8_t *scalars_be, uint8_t *out_xy,
+                                                   const uint32_t *gtab_ct)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    pt_to_affine_bytes(out_xy + i * 112, fb_scalarmul_ct(scalars_be + i * 56, gtab_ct));
 }
 
 __global__ __launch_bounds__(64, CAPY_ED448_WAVES) void fb_kernel(uint64_t n, const uint8_t *scalars_be, uint8_t *out_xy,
@@ -194,12 +217,20 @@ static size_t pair_min_items()
     return v;
 }
 
+// Hardened mode (capy_ed448_set_hardened): table reads that do not depend on the scalar.  Variable base: vb_ct_kernel
+// reads all 17 rows of the (lane-interleaved) per-item table per window.  Fixed base: the 12-bit table cannot be read
+// in full per window (2049 rows), so fb_ct_kernel uses a second shared table with 4-bit windows (9 rows, 113 windows).
+static std::atomic<bool> g_hardened{false};
+
 static int vb_launch(size_t n, const uint8_t *scalars, uint64_t scalar_stride, const uint8_t *points,
                      uint64_t point_stride, uint8_t *out, hipStream_t s)
 {
     if (!n) return CAPY_OK;
-    CAPY_WS(tab, uint32_t *, s, WS_TABLE, n * VB_TABLE_DWORDS * 4);
-    if (n >= pair_min_items()) {
+    CAPY_WS(tab, uint32_t *, s, WS_TABLE, (n + 63) / 64 * 64 * VB_TABLE_DWORDS * 4);
+    if (g_hardened.load()) {
+        hipLaunchKernelGGL(vb_ct_kernel, grid64(n), dim3(64), 0, s, (uint64_t)n, scalars, scalar_stride, points, point_stride,
+                           out, tab);
+    } else if (n >= pair_min_items()) {
         hipLaunchKernelGGL(vb2_kernel, dim3((unsigned)((n + 127) / 128)), dim3(64), 0, s, (uint64_t)n, scalars, scalar_stride,
                            points, point_stride, out, tab);
     } else {
@@ -238,49 +269,69 @@ static const uint8_t *current_generator()  // caller holds g_gtab_mu
     return g_gen_xy;
 }
 
-static int ensure_gtab(const uint32_t **out)
+static uint32_t *g_gtab_ct[64] = {nullptr};  // the hardened table (FBCT_WBITS-bit windows), built on first hardened use
+
+// rows x entries table of j * 2^(wbits row) * G in affine cached form, built by the variable-base kernel on G itself
+static int build_gtab(int rows, int entries, int wbits, uint32_t **slot)
+{
+    const size_t n = (size_t)rows * entries;
+    std::vector<uint8_t> sc(n * 56), pts(n * 112);
+    uint32_t pw[14] = {1};  // 2^(wbits row) mod r
+    for (int row = 0; row < rows; row++) {
+        uint32_t acc[14] = {0};
+        for (int j = 0; j < entries; j++) {
+            sc_to_be(sc.data() + (size_t)(row * entries + j) * 56, acc);
+            memcpy(pts.data() + (size_t)(row * entries + j) * 112, current_generator(), 112);
+            sc_add_mod(acc, pw);
+        }
+        for (int d = 0; d < wbits; d++) sc_dbl_mod(pw);
+    }
+    DevBuf dsc, dpts, dout, dtab;
+    CAPY_HIP(dsc.alloc(sc.size()));
+    CAPY_HIP(dpts.alloc(pts.size()));
+    CAPY_HIP(dout.alloc(n * 112));
+    CAPY_HIP(dtab.alloc(n * VB_TABLE_DWORDS * 4));
+    CAPY_HIP(hipMemcpy(dsc.p, sc.data(), sc.size(), hipMemcpyHostToDevice));
+    CAPY_HIP(hipMemcpy(dpts.p, pts.data(), pts.size(), hipMemcpyHostToDevice));
+    uint32_t *gt = nullptr;
+    CAPY_HIP(hipMalloc((void **)&gt, n * FB_ENTRY_DWORDS * 4));
+    hipLaunchKernelGGL(vb_kernel, grid64(n), dim3(64), 0, nullptr, (uint64_t)n, dsc.as<uint8_t>(), (uint64_t)56,
+                       dpts.as<uint8_t>(), (uint64_t)112, dout.as<uint8_t>(), dtab.as<uint32_t>());
+    hipLaunchKernelGGL(gtab_pack_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, nullptr, (uint32_t)n,
+                       dout.as<uint8_t>(), gt);
+    CAPY_HIP(hipGetLastError());
+    CAPY_HIP(hipDeviceSynchronize());
+    *slot = gt;
+    return CAPY_OK;
+}
+
+static int ensure_gtab(const uint32_t **out, bool hardened_table = false)
 {
     int dev = 0;
     CAPY_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64) return fail(CAPY_ERR_ARG, "device index out of range");
     std::lock_guard<std::mutex> lk(g_gtab_mu);
-    if (!g_gtab[dev]) {
-        const size_t n = (size_t)FB_ROWS * FB_TAB_ENTRIES;
-        std::vector<uint8_t> sc(n * 56), pts(n * 112);
-        uint32_t pw[14] = {1};  // 2^(FB_WBITS row) mod r
-        for (int row = 0; row < FB_ROWS; row++) {
-            uint32_t acc[14] = {0};
-            for (int j = 0; j < FB_TAB_ENTRIES; j++) {
-                sc_to_be(sc.data() + (size_t)(row * FB_TAB_ENTRIES + j) * 56, acc);
-                memcpy(pts.data() + (size_t)(row * FB_TAB_ENTRIES + j) * 112, current_generator(), 112);
-                sc_add_mod(acc, pw);
-            }
-            for (int d = 0; d < FB_WBITS; d++) sc_dbl_mod(pw);
-        }
-        DevBuf dsc, dpts, dout, dtab;
-        CAPY_HIP(dsc.alloc(sc.size()));
-        CAPY_HIP(dpts.alloc(pts.size()));
-        CAPY_HIP(dout.alloc(n * 112));
-        CAPY_HIP(dtab.alloc(n * VB_TABLE_DWORDS * 4));
-        CAPY_HIP(hipMemcpy(dsc.p, sc.data(), sc.size(), hipMemcpyHostToDevice));
-        CAPY_HIP(hipMemcpy(dpts.p, pts.data(), pts.size(), hipMemcpyHostToDevice));
-        uint32_t *gt = nullptr;
-        CAPY_HIP(hipMalloc((void **)&gt, (size_t)FB_TABLE_DWORDS * 4));
-        hipLaunchKernelGGL(vb_kernel, grid64(n), dim3(64), 0, nullptr, (uint64_t)n, dsc.as<uint8_t>(), (uint64_t)56,
-                           dpts.as<uint8_t>(), (uint64_t)112, dout.as<uint8_t>(), dtab.as<uint32_t>());
-        hipLaunchKernelGGL(gtab_pack_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, nullptr, (uint32_t)n,
-                           dout.as<uint8_t>(), gt);
-        CAPY_HIP(hipGetLastError());
-        CAPY_HIP(hipDeviceSynchronize());
-        g_gtab[dev] = gt;
+    uint32_t **slot = hardened_table ? &g_gtab_ct[dev] : &g_gtab[dev];
+    if (!*slot) {
+        const int rc = hardened_table ? build_gtab(FBCT_ROWS, FBCT_ENTRIES, FBCT_WBITS, slot)
+                                      : build_gtab(FB_ROWS, FB_TAB_ENTRIES, FB_WBITS, slot);
+        if (rc) return rc;
     }
-    *out = g_gtab[dev];
+    *out = *slot;
     return CAPY_OK;
 }
 
 static int fb_launch(size_t n, const uint8_t *scalars, uint8_t *out, hipStream_t s)
 {
     if (!n) return CAPY_OK;
+    if (g_hardened.load()) {  // every row of a 4-bit-window table is read per window: no address depends on the scalar
+        const uint32_t *gct = nullptr;
+        int rc = ensure_gtab(&gct, true);
+        if (rc) return rc;
+        hipLaunchKernelGGL(fb_ct_kernel, grid64(n), dim3(64), 0, s, (uint64_t)n, scalars, out, gct);
+        CAPY_HIP(hipGetLastError());
+        return CAPY_OK;
+    }
     const uint32_t *gt = nullptr;
     int rc = ensure_gtab(&gt);
     if (rc) return rc;
@@ -490,6 +541,12 @@ int capy_ed448_add_batch(size_t n, const uint8_t *p_xy, const uint8_t *q_xy, uin
     return down(out_xy, o, n * 112);
 }
 
+int capy_ed448_set_hardened(int on)
+{
+    g_hardened.store(on != 0);
+    return CAPY_OK;
+}
+
 int capy_ed448_get_generator(uint8_t *xy)
 {
     if (!xy) return fail(CAPY_ERR_ARG, "null argument");
@@ -508,12 +565,14 @@ int capy_ed448_set_generator(const uint8_t *xy)
     int cur = 0;
     const bool have_dev = hipGetDevice(&cur) == hipSuccess;
     for (int dev = 0; dev < 64; dev++) {
-        if (!g_gtab[dev]) continue;
+        if (!g_gtab[dev] && !g_gtab_ct[dev]) continue;
         if (hipSetDevice(dev) == hipSuccess) {
             (void)hipDeviceSynchronize();
-            (void)hipFree(g_gtab[dev]);
+            if (g_gtab[dev]) (void)hipFree(g_gtab[dev]);
+            if (g_gtab_ct[dev]) (void)hipFree(g_gtab_ct[dev]);
         }
         g_gtab[dev] = nullptr;
+        g_gtab_ct[dev] = nullptr;
     }
     if (have_dev) (void)hipSetDevice(cur);
     memcpy(g_gen_xy, want, 112);

@@ -76,6 +76,82 @@ CAPY_HD inline Pt vb_add_digit(const Pt &acc, const uint32_t *tab, int digit)
     return pt_add_cached(acc, X2, Y2, Z2, Td2);
 }
 
+// The same with a CONSTANT ADDRESS STREAM: every row of the table is read and the wanted one is kept by masking, so
+// that neither control flow nor any address depends on the (secret) digit -- what the reference's curve crate means
+// by its fixed-time table lookup (/root/reference/tests/integration_tests.rs:131-134).  Used when
+// capy_ed448_set_hardened(1) is in force.  Since every lane reads EVERY row, the table of a wave is interleaved across
+// its lanes -- 16-byte quad q of field element f of entry j of lane l sits at ((j*16 + f*4 + q) * nlanes + l) * 4 dwords
+// -- so that each load instruction of the wave covers one contiguous KiB (the lane-major layout of the indexed form
+// would touch 64 different lines per instruction).  17x the table reads and 1088 more VALU per window.
+struct CtTable {
+    uint32_t *base;   // the wave's table: TAB_ENTRIES * 64 dwords per lane, interleaved
+    uint32_t lane;    // my lane within the wave (0 on the host)
+    uint32_t nlanes;  // 64 on the device, 1 in the host unit test
+};
+CAPY_HD inline void store_fe_ct(const CtTable &t, int row4, const Fe &a)
+{
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        uint4 v = {a.l[4 * q], a.l[4 * q + 1], a.l[4 * q + 2], a.l[4 * q + 3]};
+        *reinterpret_cast<uint4 *>(t.base + ((size_t)(row4 + q) * t.nlanes + t.lane) * 4) = v;
+    }
+}
+CAPY_HD inline void vb_build_table_ct(const CtTable &t, const Pt &P)
+{
+    const Fe Pd = fe_mul_d(P.T);
+    Pt acc = pt_identity();
+#pragma unroll 1
+    for (int j = 0; j < TAB_ENTRIES; j++) {
+        store_fe_ct(t, j * 16, acc.X);
+        store_fe_ct(t, j * 16 + 4, acc.Y);
+        store_fe_ct(t, j * 16 + 8, acc.Z);
+        store_fe_ct(t, j * 16 + 12, fe_mul_d(acc.T));
+        if (j + 1 < TAB_ENTRIES) acc = pt_add_cached(acc, P.X, P.Y, P.Z, Pd);
+    }
+}
+CAPY_HD inline Pt vb_add_digit_ct(const Pt &acc, const CtTable &t, int digit)
+{
+    const bool neg = digit < 0;
+    const uint32_t idx = (uint32_t)(neg ? -digit : digit);
+    Fe sel[4] = {fe_zero(), fe_zero(), fe_zero(), fe_zero()};  // X, Y, Z, dT
+#pragma unroll 1
+    for (uint32_t j = 0; j < (uint32_t)TAB_ENTRIES; j++) {
+        const uint32_t m = 0u - (uint32_t)(j == idx);
+#pragma unroll
+        for (int f = 0; f < 4; f++) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(t.base + ((size_t)(j * 16 + f * 4 + q) * t.nlanes + t.lane) * 4);
+                sel[f].l[4 * q] |= v.x & m;
+                sel[f].l[4 * q + 1] |= v.y & m;
+                sel[f].l[4 * q + 2] |= v.z & m;
+                sel[f].l[4 * q + 3] |= v.w & m;
+            }
+        }
+    }
+    sel[0] = fe_select(neg, sel[0], fe_neg_nr(sel[0]));
+    sel[3] = fe_select(neg, sel[3], fe_neg_nr(sel[3]));
+    return pt_add_cached(acc, sel[0], sel[1], sel[2], sel[3]);
+}
+
+// [k]P with constant-address table lookups
+CAPY_HD_INLINE Pt vb_scalarmul_ct(const uint8_t *k_be, const Pt &P, const CtTable &t)
+{
+    vb_build_table_ct(t, P);
+    uint32_t k[14], w[15];
+    sc_from_be(k, k_be);
+    const uint32_t top = sc_recode_signed<WBITS>(w, k);
+    sc_msb_align<WBITS>(w);
+    Pt acc = vb_add_digit_ct(pt_identity(), t, (int)top);
+#pragma unroll 1
+    for (int i = 0; i < NWIN; i++) {
+        CAPY_UNROLL(CAPY_ED448_DBL_UNROLL)
+        for (int j = 0; j < WBITS; j++) acc = pt_dbl<true>(acc);
+        acc = vb_add_digit_ct(acc, t, sc_next_digit_msb<WBITS>(w));
+    }
+    return acc;
+}
+
 // [k]P, k = 56 big-endian bytes (all 448 bits used), tab = VB_TABLE_DWORDS of scratch for this item.
 CAPY_HD_INLINE Pt vb_scalarmul(const uint8_t *k_be, const Pt &P, uint32_t *tab)
 {
@@ -106,6 +182,49 @@ CAPY_HD inline Pt fb_add_digit(const Pt &acc, const uint32_t *gtab, int row, int
     x2 = fe_select(neg, x2, fe_neg_nr(x2));
     td2 = fe_select(neg, td2, fe_neg_nr(td2));
     return pt_add_affine_cached(acc, x2, y2, td2);
+}
+
+// Hardened fixed base: a second shared table with FBCT_WBITS-bit signed windows -- few enough rows (9) to read ALL of
+// them per window and keep the wanted one by masking.  The rows are the same for every lane of a wave, so the scan is
+// uniform-address traffic out of the L2; one mixed addition per window (113 of them).
+constexpr int FBCT_WBITS = 4;
+using FbCtWin = Win<FBCT_WBITS>;
+constexpr int FBCT_ROWS = FbCtWin::NWIN + 1;
+constexpr int FBCT_ENTRIES = FbCtWin::ENTRIES;
+constexpr int FBCT_TABLE_DWORDS = FBCT_ROWS * FBCT_ENTRIES * FB_ENTRY_DWORDS;
+
+CAPY_HD inline Pt fb_add_digit_ct(const Pt &acc, const uint32_t *gtab, int row, int digit)
+{
+    const bool neg = digit < 0;
+    const uint32_t idx = (uint32_t)(neg ? -digit : digit);
+    Fe x2 = fe_zero(), y2 = fe_zero(), td2 = fe_zero();
+#pragma unroll 1
+    for (uint32_t j = 0; j < (uint32_t)FBCT_ENTRIES; j++) {
+        const uint32_t m = 0u - (uint32_t)(j == idx);
+        const uint32_t *e = gtab + ((size_t)row * FBCT_ENTRIES + j) * FB_ENTRY_DWORDS;
+        const Fe x = load_fe(e), y = load_fe(e + 16), t = load_fe(e + 32);
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            x2.l[i] |= x.l[i] & m;
+            y2.l[i] |= y.l[i] & m;
+            td2.l[i] |= t.l[i] & m;
+        }
+    }
+    x2 = fe_select(neg, x2, fe_neg_nr(x2));
+    td2 = fe_select(neg, td2, fe_neg_nr(td2));
+    return pt_add_affine_cached(acc, x2, y2, td2);
+}
+
+// [k]G with constant-address table lookups, from gtab[FBCT_TABLE_DWORDS]
+CAPY_HD_INLINE Pt fb_scalarmul_ct(const uint8_t *k_be, const uint32_t *gtab)
+{
+    uint32_t k[14], w[15];
+    sc_from_be(k, k_be);
+    const uint32_t top = sc_recode_signed<FBCT_WBITS>(w, k);
+    Pt acc = fb_add_digit_ct(pt_identity(), gtab, FbCtWin::NWIN, (int)top);
+#pragma unroll 1
+    for (int i = 0; i < FbCtWin::NWIN; i++) acc = fb_add_digit_ct(acc, gtab, i, sc_next_digit_lsb<FBCT_WBITS>(w));
+    return acc;
 }
 
 // [k]G from the shared table gtab[FB_TABLE_DWORDS]

@@ -183,6 +183,11 @@ def ed448_validate_batch(points_xy):
     return [status[i] == 0 for i in range(n)]
 
 
+def ed448_set_hardened(on):
+    """Constant-address table lookups for every scalar multiplication (include/capyhip.h: capy_ed448_set_hardened)."""
+    L.check(L.lib().capy_ed448_set_hardened(1 if on else 0))
+
+
 def ed448_set_generator(xy=None):
     """Replace the point that stands for ExtendedPoint::generator() (None: back to the RFC 8032 base point)."""
     if xy is not None and len(bytes(xy)) != 112:

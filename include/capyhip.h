@@ -158,6 +158,16 @@ int capy_ed448_add_batch(size_t n, const uint8_t *p_xy, const uint8_t *q_xy, uin
 int capy_ed448_double_scalarmul_batch(size_t n, const uint8_t *a_be, const uint8_t *b_be,
                                       const uint8_t *points_xy, uint8_t *out_xy);
 
+/* Side-channel hardening (process-wide, default off).  By default the window tables of the scalar multiplications are
+ * indexed by digits of the scalar: control flow is uniform but the ADDRESS stream depends on the secret (a
+ * cache-timing channel on a GPU shared with untrusted tenants; the reference's curve crate advertises fixed-time
+ * lookups).  With capy_ed448_set_hardened(1) every scalar multiplication of every entry point -- variable base, fixed
+ * base, key pairs, signatures, ECDHIES -- reads its whole 17-row window table per window and keeps the wanted row by
+ * masking (fixed base: a second shared table with 4-bit windows, all 9 rows read per window): no address and no branch
+ * depends on a scalar.  Results are bit-identical; the cost is measured in profiles/r02_ed448_hardened.txt.
+ * (Signable::verify handles public values only and keeps the fast path.) */
+int capy_ed448_set_hardened(int on);
+
 /* status[i] = CAPY_ITEM_OK iff point i has canonical coordinates (both < p) and lies on the curve.  The multiplication
  * and protocol entry points do NOT validate their point inputs (results for off-curve or non-canonical input are
  * unspecified, as with the reference's ExtendedPoint built from raw coordinates); callers that take points from

@@ -38,6 +38,14 @@ void ht_scalarmul(const uint8_t *k_be, const uint8_t *p_xy, uint8_t *out_xy)
     Pt r = vb_scalarmul(k_be, pt_from_affine_bytes(p_xy), t);
     pt_to_affine_bytes(out_xy, r);
 }
+void ht_scalarmul_ct(const uint8_t *k_be, const uint8_t *p_xy, uint8_t *out_xy)
+{
+    std::vector<uint32_t> tab(VB_TABLE_DWORDS + 4);
+    uint32_t *t = (uint32_t *)(((uintptr_t)tab.data() + 15) & ~(uintptr_t)15);
+    const CtTable ct = {t, 0, 1};
+    Pt r = vb_scalarmul_ct(k_be, pt_from_affine_bytes(p_xy), ct);
+    pt_to_affine_bytes(out_xy, r);
+}
 int ht_validate(const uint8_t *p_xy) { return pt_validate_bytes(p_xy) ? 1 : 0; }
 void ht_add(const uint8_t *p, const uint8_t *q, uint8_t *out) { pt_to_affine_bytes(out, pt_add(pt_from_affine_bytes(p), pt_from_affine_bytes(q))); }
 void ht_dbl(const uint8_t *p, uint8_t *out) { pt_to_affine_bytes(out, pt_dbl<true>(pt_from_affine_bytes(p))); }
@@ -107,6 +115,33 @@ void ht_build_gtab(const uint8_t *g_xy)
         }
         for (int d = 0; d < FB_WBITS; d++) base = pt_dbl<true>(base);
     }
+}
+// the hardened fixed-base table (4-bit windows) and multiplication
+static std::vector<uint32_t> g_tab_ct;
+void ht_build_gtab_ct(const uint8_t *g_xy)
+{
+    g_tab_ct.assign(FBCT_TABLE_DWORDS + 4, 0);
+    uint32_t *t = (uint32_t *)(((uintptr_t)g_tab_ct.data() + 15) & ~(uintptr_t)15);
+    Pt base = pt_from_affine_bytes(g_xy);
+    for (int row = 0; row < FBCT_ROWS; row++) {
+        Pt acc = pt_identity();
+        for (int j = 0; j < FBCT_ENTRIES; j++) {
+            uint8_t xy[112];
+            pt_to_affine_bytes(xy, acc);
+            Fe x = fe_from_bytes(xy), y = fe_from_bytes(xy + 56);
+            uint32_t *e = t + (row * FBCT_ENTRIES + j) * FB_ENTRY_DWORDS;
+            store_fe(e, x);
+            store_fe(e + 16, y);
+            store_fe(e + 32, fe_mul_d(fe_mul(x, y)));
+            acc = pt_add(acc, base);
+        }
+        for (int d = 0; d < FBCT_WBITS; d++) base = pt_dbl<true>(base);
+    }
+}
+void ht_basemul_ct(const uint8_t *k_be, uint8_t *out_xy)
+{
+    const uint32_t *t = (const uint32_t *)(((uintptr_t)g_tab_ct.data() + 15) & ~(uintptr_t)15);
+    pt_to_affine_bytes(out_xy, fb_scalarmul_ct(k_be, t));
 }
 void ht_basemul(const uint8_t *k_be, uint8_t *out_xy) { pt_to_affine_bytes(out_xy, fb_scalarmul(k_be, gtab_aligned())); }
 void ht_double_scalarmul(const uint8_t *a_be, const uint8_t *b_be, const uint8_t *p_xy, uint8_t *out_xy)

@@ -164,3 +164,18 @@ def test_point_validation_on_the_host_build(L):
     assert L.ht_validate(C.c_char_p(E.fe_to_bytes(0) + (E.P + 1).to_bytes(56, "little"))) == 0   # y = p + 1
     assert L.ht_validate(C.c_char_p(E.fe_to_bytes(x) + E.fe_to_bytes((y + 1) % E.P))) == 0       # off the curve
     assert L.ht_validate(C.c_char_p(bytes(112))) == 0
+
+
+def test_constant_address_variant_equals_the_indexed_one(L):
+    """vb_scalarmul<true> (every table row read, the wanted one kept by masking: capy_ed448_set_hardened) against the
+    oracle for edge scalars and random pairs."""
+    from oracle import oracle as O
+
+    rng = random.Random(21)
+    ks = [0, 1, 2, 15, 16, 17, 31, 32, 33, E.R - 1, E.R, 2**448 - 1] + [rng.getrandbits(448) for _ in range(12)]
+    L.ht_build_gtab_ct(C.c_char_p(E.pt_to_bytes(E.G)))
+    for k in ks:
+        P = E.pt_to_bytes(E.scalarmul(rng.getrandbits(446), E.G))
+        kb = E.sc_to_bytes(k)
+        assert call(L, "ht_scalarmul_ct", kb, P, outlen=112) == O.ed448_scalarmul(kb, P)
+        assert call(L, "ht_basemul_ct", kb, outlen=112) == O.ed448_basemul(kb)

@@ -524,3 +524,36 @@ def test_generator_can_be_replaced(capy, O):
         capy.ops.ed448_set_generator(None)
     assert capy.ops.ed448_get_generator() == G
     assert capy.ops.ed448_basemul_batch(ks) == [O.ed448_basemul(k) for k in ks]
+
+
+def test_hardened_mode_is_bit_identical(capy, O):
+    """capy_ed448_set_hardened(1): every scalar multiplication reads its whole window table per window (no address
+    depends on a scalar); fixed-base multiplications become variable-base multiplications of the generator.  Every
+    result must equal the default mode's and the oracle's: raw operations, key pairs, signatures, ECDHIES."""
+    rng = random.Random(0xC7)
+    n = 130
+    ks = [rng.randbytes(56) for _ in range(n)]
+    ks[0], ks[1], ks[2] = bytes(56), bytes(55) + b"\x01", b"\xff" * 56
+    pts = [O.ed448_basemul(rng.randbytes(56)) for _ in range(n)]
+    pws = [rng.randbytes(rng.randrange(0, 90)) for _ in range(n)]
+    msgs = [rng.randbytes(rng.randrange(0, 600)) for _ in range(n)]
+
+    def run():
+        r = {"vb": capy.ops.ed448_scalarmul_batch(ks, pts), "fb": capy.ops.ed448_basemul_batch(ks),
+             "pub": capy.ops.keypair_batch(pws, 512), "sig": capy.ops.schnorr_sign_batch(pws, msgs, 512)}
+        r["ver"] = capy.ops.schnorr_verify_batch(r["pub"], msgs, r["sig"], 512)
+        r["enc"] = capy.ops.key_encrypt_batch(r["pub"], ks, msgs, 512)
+        c, z, t = r["enc"]
+        r["dec"] = capy.ops.key_decrypt_batch(pws, z, c, t, 512)
+        return r
+
+    plain = run()
+    try:
+        capy.ops.ed448_set_hardened(True)
+        hard = run()
+    finally:
+        capy.ops.ed448_set_hardened(False)
+    for k in plain:
+        assert hard[k] == plain[k], k
+    assert plain["vb"] == [O.ed448_scalarmul(k, p) for k, p in zip(ks, pts)]
+    assert plain["fb"] == [O.ed448_basemul(k) for k in ks] and all(plain["ver"]) and all(plain["dec"][1])
