@@ -158,6 +158,19 @@ int main()
         for (size_t i = 0; i < ok.size(); i++) EXPECT(ok[i]);
         EXPECT(capy_set_devices(nullptr, 0) == CAPY_OK);
     }
+    // hardened mode (constant-address table lookups): same key pair, same signature
+    {
+        Bytes pw = get_random_bytes(40);
+        Message a(get_random_bytes(5000)), b(a.msg);
+        KeyPair k1 = KeyPair::new_(pw, "k", SecParam::D256);
+        a.sign(k1, SecParam::D256);
+        EXPECT(capy_ed448_set_hardened(1) == CAPY_OK);
+        KeyPair k2 = KeyPair::new_(pw, "k", SecParam::D256);
+        b.sign(k2, SecParam::D256);
+        EXPECT(capy_ed448_set_hardened(0) == CAPY_OK);
+        EXPECT(k1.pub_key == k2.pub_key && a.sig->h == b.sig->h && a.sig->z == b.sig->z);
+        b.verify(k1.pub_key);
+    }
     // the nonce source is the operating system's CSPRNG (getrandom): draws differ and are not degenerate
     {
         Bytes r1 = get_random_bytes(4096), r2 = get_random_bytes(4096);
