@@ -196,6 +196,43 @@ def test_rfc7748_x448_through_the_variable_base_kernel(capy):
     assert k.hex() == it["after_1000"]
 
 
+def test_openssl_generated_vectors_on_gpu(capy):
+    """The OpenSSL-generated fixture (tests/golden/openssl_ed448.json, an independent implementation) through the C
+    ABI, batched: 24 public keys on the fixed-base kernel; 24 verification equations R = [S]B + [L-k]A on the
+    double-multiplication kernel and [k]A on the variable-base kernel; 48 X448 shared secrets on the variable-base
+    kernel through the 4-isogeny."""
+    from oracle import ed448_ref as E
+
+    H = bytes.fromhex
+    with open(os.path.join(HERE, "golden", "openssl_ed448.json")) as f:
+        v = json.load(f)
+    ed = v["ed448"]
+    ss = [E.sc_to_bytes(E.rfc8032_secret_scalar(H(t["secret"]))[0]) for t in ed]
+    pubs = capy.ops.ed448_basemul_batch(ss)
+    assert [E.rfc8032_encode(E.pt_from_bytes(p)).hex() for p in pubs] == [t["public"] for t in ed]
+    a_be, b_be, ks, rs = [], [], [], []
+    for t in ed:
+        pk, msg, sig = H(t["public"]), H(t["message"]), H(t["signature"])
+        k = E.rfc8032_challenge(sig[:57], pk, msg)
+        a_be.append(E.sc_to_bytes(int.from_bytes(sig[57:], "little")))
+        b_be.append(E.sc_to_bytes((E.R - k) % E.R))
+        ks.append(E.sc_to_bytes(k))
+        rs.append(E.pt_to_bytes(E.rfc8032_decode(sig[:57])))
+    assert capy.ops.ed448_double_scalarmul_batch(a_be, b_be, pubs) == rs
+    ka = capy.ops.ed448_scalarmul_batch(ks, pubs)  # [k]A, A not the generator
+    assert capy.ops.ed448_add_batch(rs, ka) == capy.ops.ed448_basemul_batch(a_be)  # R + [k]A = [S]B
+    # X448: one batch of 48 variable-base multiplications of lifted public keys by clamped scalars / 4
+    scal, pts, want = [], [], []
+    for t in v["x448"]:
+        for priv, peer in ((t["a"], t["b_public"]), (t["b"], t["a_public"])):
+            u = int.from_bytes(H(peer), "little") % E.P
+            scal.append(E.sc_to_bytes(E.x448_clamp(H(priv)) // 4))
+            pts.append(E.pt_to_bytes(E.edwards_from_curve448(u, E.curve448_v(u))))
+            want.append(t["shared"])
+    got = capy.ops.ed448_scalarmul_batch(scal, pts)
+    assert [E.x448_u_from_edwards(E.pt_from_bytes(g)).to_bytes(56, "little").hex() for g in got] == want
+
+
 def test_variable_base_kernel_vs_montgomery_ladder(capy):
     """768 random (scalar, point) pairs in one batch, points anywhere on the curve (4-torsion components included):
     the variable-base kernel against the Montgomery ladder of RFC 7748 section 5, an algorithm that shares nothing with
