@@ -755,3 +755,20 @@ def test_device_key_offsets_and_workspace_release(capy, O, sponge_lanes):
         torch.cuda.synchronize()
         assert not status.cpu().numpy().any() and torch.equal(msgs, plain)
         _lib.check(lib.capy_release_workspace())  # the second round runs on freshly allocated scratch
+
+
+def test_kmac_against_openssl_generated_vectors_on_gpu(capy):
+    """The OpenSSL-generated KMACXOF fixture through the C ABI: per security parameter ONE batch per output length with
+    ragged key and message lengths; outside the documented conflict set (where the reference itself deviates from
+    SP 800-185) every output must equal OpenSSL's."""
+    from test_oracle_sponge import _openssl_kmac, kmac_conflicts_with_sp800_185
+
+    v = [t for t in _openssl_kmac() if not kmac_conflicts_with_sp800_185(t["d"], len(t["k"]) // 2, len(t["x"]) // 2)]
+    assert len(v) >= 70
+    groups = {}
+    for t in v:
+        groups.setdefault((t["d"], t["l_bits"], t["s"]), []).append(t)
+    for (d, l_bits, s), ts in groups.items():
+        got = capy.ops.kmac_xof_batch([bytes.fromhex(t["k"]) for t in ts], [bytes.fromhex(t["x"]) for t in ts], l_bits,
+                                      s.encode(), d)
+        assert [g.hex() for g in got] == [t["out"] for t in ts], (d, l_bits, s)

@@ -99,3 +99,40 @@ def test_sha3_encrypt_roundtrip_and_restore():
 def test_keccakf_zero_state():
     st = O.keccakf1600([0] * 25)
     assert st[0] == 0xF1258F7940E1DDE7 and st[24] == 0xEAF1FF7B5CECA249  # XKCP KeccakF-1600-IntermediateValues
+
+
+def _openssl_kmac():
+    import json
+    import os
+
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "openssl_kmac.json")) as f:
+        return json.load(f)["kmac_xof"]
+
+
+def kmac_conflicts_with_sp800_185(d, klen, xlen):
+    """Where the reference's kmac_xof differs from SP 800-185: the cSHAKE suffix byte
+    lands on a block boundary so that no 0x80 is ever added (sponge.rs:13), or bytepad(encode_string(K)) is already
+    aligned and byte_pad appends a whole extra block (aux_functions.rs:14)."""
+    w = (1600 - d) // 8
+    enc = 2 + len(O.left_encode(8 * klen)) + klen  # left_encode(w) || left_encode(8|K|) || K
+    return (xlen + 3) % w == 0 or enc % w == 0
+
+
+def test_kmac_against_openssl_generated_vectors():
+    """tests/golden/openssl_kmac.json: 96 KMACXOF128 / KMACXOF256 outputs from the OpenSSL command-line tool (an
+    independent implementation; tests/golden/gen_openssl_kmac.py), lengths drawn around the rate boundaries.  The
+    oracle's SP 800-185 mode (quirks = 0) must reproduce every one; its reference mode (quirks = 1, what the GPU path is
+    checked against) must reproduce every one OUTSIDE the documented conflict set and differ inside it."""
+    v = _openssl_kmac()
+    assert len(v) == 96
+    inside = 0
+    for t in v:
+        k, x, s = bytes.fromhex(t["k"]), bytes.fromhex(t["x"]), t["s"].encode()
+        assert O.kmac_xof(k, x, t["l_bits"], s, t["d"], quirks=0).hex() == t["out"]
+        ref = O.kmac_xof(k, x, t["l_bits"], s, t["d"], quirks=1).hex()
+        if kmac_conflicts_with_sp800_185(t["d"], len(k), len(x)):
+            inside += 1
+            assert ref != t["out"], (t["d"], len(k), len(x))
+        else:
+            assert ref == t["out"], (t["d"], len(k), len(x))
+    assert 8 <= inside <= 24
