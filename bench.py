@@ -141,6 +141,13 @@ def cpu_baseline(seconds):
     for t in thr:
         t.join()
     el_mt = time.perf_counter() - t1
+    # context only: a tuned library on the same core (the reference's README compares itself with OpenSSL, README.md:151)
+    t2 = time.perf_counter()
+    nlib = 0
+    while time.perf_counter() - t2 < 2.0:
+        hashlib.sha3_256(msg).digest()
+        nlib += 1
+    el_lib = time.perf_counter() - t2
     return {
         "value": n * MSG_BYTES / 2**30 / el,
         "unit": "GiB/s",
@@ -150,6 +157,8 @@ def cpu_baseline(seconds):
                                                                                             _cpu_model()),
         "multi_thread": {"value": sum(counts) * MSG_BYTES / 2**30 / el_mt, "unit": "GiB/s", "cores": nthr,
                          "sample": "%d x 5 MiB over %d threads (%.1f s)" % (sum(counts), nthr, el_mt)},
+        "tuned_library_1thread": {"value": nlib * MSG_BYTES / 2**30 / el_lib, "unit": "GiB/s",
+                                  "what": "python hashlib.sha3_256 (the interpreter's C implementation), context only"},
     }
 
 
