@@ -772,3 +772,28 @@ def test_kmac_against_openssl_generated_vectors_on_gpu(capy):
         got = capy.ops.kmac_xof_batch([bytes.fromhex(t["k"]) for t in ts], [bytes.fromhex(t["x"]) for t in ts], l_bits,
                                       s.encode(), d)
         assert [g.hex() for g in got] == [t["out"] for t in ts], (d, l_bits, s)
+
+
+def test_small_ragged_batches_of_long_messages(capy, O, sponge_lanes):
+    """Batches of a few hundred messages with widely different lengths (0 .. 300 KB): in automatic mode these take the
+    wave-per-item digest kernel (two items of different length per wave, length-sorted order), under the forced modes
+    the one- and two-lane kernels.  SHA3-256 against hashlib (FIPS 202 = the reference at d = 256), KMAC and SHA3-512
+    against the oracle for a sample."""
+    import hashlib
+
+    from capycrypt_amd import _lib
+
+    rng = random.Random(0x51AB)
+    n = 301
+    lens = [rng.choice([0, 1, 135, 136, 137, 4096]) if i % 5 == 0 else rng.randrange(0, 300000) for i in range(n)]
+    msgs = [rng.randbytes(x) for x in lens]
+    keys = [rng.randbytes(rng.randrange(0, 200)) for _ in range(n)]
+    for auto in (False, True):
+        if auto:
+            _lib.check(_lib.lib().capy_set_sponge_lanes(0))  # automatic choice: the wave-per-item kernel
+        assert capy.ops.sha3_batch(msgs, 256) == [hashlib.sha3_256(m).digest() for m in msgs]
+        got5 = capy.ops.sha3_batch(msgs, 512)
+        gotk = capy.ops.kmac_xof_batch(keys, msgs, 448, b"T", 512)
+        for i in range(0, n, 13):
+            assert got5[i] == O.sha3(msgs[i], 512), lens[i]
+            assert gotk[i] == O.kmac_xof(keys[i], msgs[i], 448, b"T", 512), (len(keys[i]), lens[i])
