@@ -83,8 +83,18 @@ CAPY_HD inline Pt vb_add_digit(const Pt &acc, const uint32_t *tab, int digit)
 // its lanes -- 16-byte quad q of field element f of entry j of lane l sits at ((j*16 + f*4 + q) * nlanes + l) * 4 dwords
 // -- so that each load instruction of the wave covers one contiguous KiB (the lane-major layout of the indexed form
 // would touch 64 different lines per instruction).  17x the table reads and 1088 more VALU per window.
+// The hardened form uses its own, narrower windows: every row is read per window, so fewer rows (9 instead of 17)
+// outweigh the extra windows (112 instead of 90): CAPY_ED448_CT_WBITS = 4 measured against 5 in
+// profiles/r02_ed448_hardened.txt.
+#ifndef CAPY_ED448_CT_WBITS
+#define CAPY_ED448_CT_WBITS 4
+#endif
+constexpr int CT_WBITS = CAPY_ED448_CT_WBITS;
+using CtWin = Win<CT_WBITS>;
+static_assert(CtWin::ENTRIES <= TAB_ENTRIES, "the hardened table lives in the same scratch as the indexed one");
+
 struct CtTable {
-    uint32_t *base;   // the wave's table: TAB_ENTRIES * 64 dwords per lane, interleaved
+    uint32_t *base;   // the wave's table: CtWin::ENTRIES * 64 dwords per lane, interleaved
     uint32_t lane;    // my lane within the wave (0 on the host)
     uint32_t nlanes;  // 64 on the device, 1 in the host unit test
 };
@@ -101,12 +111,12 @@ CAPY_HD inline void vb_build_table_ct(const CtTable &t, const Pt &P)
     const Fe Pd = fe_mul_d(P.T);
     Pt acc = pt_identity();
 #pragma unroll 1
-    for (int j = 0; j < TAB_ENTRIES; j++) {
+    for (int j = 0; j < CtWin::ENTRIES; j++) {
         store_fe_ct(t, j * 16, acc.X);
         store_fe_ct(t, j * 16 + 4, acc.Y);
         store_fe_ct(t, j * 16 + 8, acc.Z);
         store_fe_ct(t, j * 16 + 12, fe_mul_d(acc.T));
-        if (j + 1 < TAB_ENTRIES) acc = pt_add_cached(acc, P.X, P.Y, P.Z, Pd);
+        if (j + 1 < CtWin::ENTRIES) acc = pt_add_cached(acc, P.X, P.Y, P.Z, Pd);
     }
 }
 CAPY_HD inline Pt vb_add_digit_ct(const Pt &acc, const CtTable &t, int digit)
@@ -115,7 +125,7 @@ CAPY_HD inline Pt vb_add_digit_ct(const Pt &acc, const CtTable &t, int digit)
     const uint32_t idx = (uint32_t)(neg ? -digit : digit);
     Fe sel[4] = {fe_zero(), fe_zero(), fe_zero(), fe_zero()};  // X, Y, Z, dT
 #pragma unroll 1
-    for (uint32_t j = 0; j < (uint32_t)TAB_ENTRIES; j++) {
+    for (uint32_t j = 0; j < (uint32_t)CtWin::ENTRIES; j++) {
         const uint32_t m = 0u - (uint32_t)(j == idx);
 #pragma unroll
         for (int f = 0; f < 4; f++) {
@@ -140,14 +150,14 @@ CAPY_HD_INLINE Pt vb_scalarmul_ct(const uint8_t *k_be, const Pt &P, const CtTabl
     vb_build_table_ct(t, P);
     uint32_t k[14], w[15];
     sc_from_be(k, k_be);
-    const uint32_t top = sc_recode_signed<WBITS>(w, k);
-    sc_msb_align<WBITS>(w);
+    const uint32_t top = sc_recode_signed<CT_WBITS>(w, k);
+    sc_msb_align<CT_WBITS>(w);
     Pt acc = vb_add_digit_ct(pt_identity(), t, (int)top);
 #pragma unroll 1
-    for (int i = 0; i < NWIN; i++) {
+    for (int i = 0; i < CtWin::NWIN; i++) {
         CAPY_UNROLL(CAPY_ED448_DBL_UNROLL)
-        for (int j = 0; j < WBITS; j++) acc = pt_dbl<true>(acc);
-        acc = vb_add_digit_ct(acc, t, sc_next_digit_msb<WBITS>(w));
+        for (int j = 0; j < CT_WBITS; j++) acc = pt_dbl<true>(acc);
+        acc = vb_add_digit_ct(acc, t, sc_next_digit_msb<CT_WBITS>(w));
     }
     return acc;
 }
