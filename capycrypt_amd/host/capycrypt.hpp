@@ -288,6 +288,19 @@ inline void compute_sha3_hash_many(const std::vector<Message *> &ms, SecParam dd
     }
 }
 
+// compute_tagged_hash for a slice of messages: one KMACXOF batch, one password (any length) per message
+inline void compute_tagged_hash_many(const std::vector<Message *> &ms, const std::vector<Bytes> &pws, const std::string &s,
+                                     SecParam dd)
+{
+    detail::same_count(ms.size(), pws.size());
+    detail::Packed p = detail::pack_msgs(ms), k = detail::pack_bytes(pws);
+    const size_t dl = (size_t)dd / 8;
+    Bytes out(ms.size() * dl + 1);
+    detail::check(capy_kmac_xof_batch((int)dd, ms.size(), detail::ptr(k.data), 0, k.offs.data(), detail::ptr(p.data),
+                                      p.offs.data(), (size_t)dd, (const uint8_t *)s.data(), s.size(), out.data()));
+    for (size_t i = 0; i < ms.size(); i++) ms[i]->digest.assign(out.begin() + i * dl, out.begin() + (i + 1) * dl);
+}
+
 inline void sha3_encrypt_many(const std::vector<Message *> &ms, const std::vector<Bytes> &pws, SecParam dd,
                               const std::vector<Bytes> *zs_inject = nullptr)
 {

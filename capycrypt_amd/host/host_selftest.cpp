@@ -102,6 +102,11 @@ int main()
         std::vector<Message *> pa, pb;
         for (auto &m : a) pa.push_back(&m);
         for (auto &m : b) pb.push_back(&m);
+        compute_tagged_hash_many(pa, pws, "T", SecParam::D512);
+        for (size_t i = 0; i < b.size(); i++) {
+            b[i].compute_tagged_hash(pws[i], "T", SecParam::D512);
+            EXPECT(a[i].digest == b[i].digest && a[i].digest.size() == 64);
+        }
         sha3_encrypt_many(pa, pws, SecParam::D256, &zs);
         for (size_t i = 0; i < b.size(); i++) b[i].sha3_encrypt(pws[i], SecParam::D256, &zs[i]);
         for (size_t i = 0; i < b.size(); i++) EXPECT(a[i].msg == b[i].msg && a[i].digest == b[i].digest);

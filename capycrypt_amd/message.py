@@ -355,6 +355,15 @@ def compute_sha3_hash_many(messages, d):
         _append_shake_padding(m.msg, d)
 
 
+def compute_tagged_hash_many(messages, pws, s, d):
+    """src/sha3/hashable.rs:33-35 for a list of messages: one KMACXOF batch, one password (any length) per message."""
+    d = SecParam.try_from(d)
+    s = s.encode() if isinstance(s, str) else bytes(s)
+    digs = ops.kmac_xof_batch([bytes(p) for p in pws], [bytes(m.msg) for m in messages], int(d), s, d)
+    for m, dg in zip(messages, digs):
+        m.digest = dg
+
+
 def sha3_encrypt_many(messages, pws, d, zs=None):
     d = SecParam.try_from(d)
     zs = [get_random_bytes(512) for _ in messages] if zs is None else zs
@@ -387,3 +396,31 @@ def verify_many(messages, pub_keys):
     d = messages[0].d
     return ops.schnorr_verify_batch(pub_keys, [bytes(m.msg) for m in messages],
                                     [(m.sig.h, m.sig.z) for m in messages], d)
+
+
+def key_encrypt_many(messages, pub_keys, d, ks=None):
+    """src/ecc/encryptable.rs:34-50 for a list of messages: one batched call."""
+    d = SecParam.try_from(d)
+    ks = [get_random_bytes(56) for _ in messages] if ks is None else ks
+    cts, zs, tags = ops.key_encrypt_batch(pub_keys, ks, [bytes(m.msg) for m in messages], d)
+    for m, c, z, t in zip(messages, cts, zs, tags):
+        m.msg[:] = c
+        m.asym_nonce = z
+        m.digest = t
+        m.d = d
+
+
+def key_decrypt_many(messages, pws):
+    """src/ecc/encryptable.rs:72-94 for a list of messages; returns one flag per message (False = KeyDecryptionError,
+    the message is left as the ciphertext)."""
+    d = messages[0].d
+    wellformed = [m.asym_nonce is not None and len(m.asym_nonce) == 112 and len(m.digest) == 56 for m in messages]
+    out, ok = ops.key_decrypt_batch(pws, [m.asym_nonce if w else bytes(112) for m, w in zip(messages, wellformed)],
+                                    [bytes(m.msg) for m in messages],
+                                    [m.digest if w else bytes(56) for m, w in zip(messages, wellformed)], d)
+    res = []
+    for m, o, good, w in zip(messages, out, ok, wellformed):
+        if good and w:
+            m.msg[:] = o
+        res.append(bool(good and w))
+    return res

@@ -594,3 +594,30 @@ def test_hardened_mode_is_bit_identical(capy, O):
         assert hard[k] == plain[k], k
     assert plain["vb"] == [O.ed448_scalarmul(k, p) for k, p in zip(ks, pts)]
     assert plain["fb"] == [O.ed448_basemul(k) for k in ks] and all(plain["ver"]) and all(plain["dec"][1])
+
+
+def test_many_forms_of_the_python_mirror(capy, O):
+    """The batched helpers over lists of Message (capycrypt_amd/message.py) equal the one-at-a-time reference-shaped
+    methods: tagged hash, ECDHIES encrypt / decrypt incl. restore-on-failure, with ragged passwords."""
+    from capycrypt_amd.message import compute_tagged_hash_many, key_decrypt_many, key_encrypt_many
+
+    rng = random.Random(0xAB)
+    n = 40
+    pws = [rng.randbytes(rng.randrange(0, 100)) for _ in range(n)]
+    bodies = [rng.randbytes(rng.randrange(0, 3000)) for _ in range(n)]
+    ms = [capy.Message(b) for b in bodies]
+    compute_tagged_hash_many(ms, pws, "T", 512)
+    assert [m.digest for m in ms] == [O.kmac_xof(p, b, 512, b"T", 512) for p, b in zip(pws, bodies)]
+    kps = capy.KeyPair.new_many(pws, "k", 512)
+    ks = [rng.randbytes(56) for _ in range(n)]
+    key_encrypt_many(ms, [k.pub_key for k in kps], 512, ks)
+    one = capy.Message(bodies[7])
+    one.key_encrypt(kps[7].pub_key, 512, ks[7])
+    assert bytes(ms[7].msg) == bytes(one.msg) and ms[7].digest == one.digest and ms[7].asym_nonce == one.asym_nonce
+    wrong = list(pws)
+    wrong[3] = wrong[3] + b"?"
+    ms[9].digest = ms[9].digest[:10]  # malformed tag: a failure, message untouched
+    ct9 = bytes(ms[9].msg)
+    ok = key_decrypt_many(ms, wrong)
+    assert ok == [i not in (3, 9) for i in range(n)]
+    assert all(bytes(ms[i].msg) == bodies[i] for i in range(n) if i not in (3, 9)) and bytes(ms[9].msg) == ct9
