@@ -400,6 +400,7 @@ static int try_launch_mixed(int rw, const SpongeParams &p, bool forced, hipStrea
     memcpy(q.init_state, p.init_state, sizeof q.init_state);
     q.k1_count = m.nb1;
     q.k2_count = m.nb2;
+    q.staged = (g_debug_flags.load() & 64) ? 1 : 0;  // A/B switch (debug bit 6): LDS-staged loads
     const uint32_t hb = p.head_len / ((uint32_t)rw * 8);
     if (hb) {
         // per-item head blocks (KMAC keys) first: a head-only launch of the one-lane kernel seeds the state buffer

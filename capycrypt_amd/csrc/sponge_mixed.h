@@ -33,9 +33,15 @@ struct MixedParams {
     uint32_t k2_first, k2_count;
     // one-lane waves: items below k2_begin have had their fast phase already, items from k2_end on have not
     uint32_t k1_first_lo, k1_first_hi, k1_count;
+    uint32_t staged;  // A/B (debug bit 6): take sponge_mixed_staged_kernel, the round-1 form with LDS-staged loads
 };
 
-template <int RW>
+// STAGED = false (default): every lane loads the words of its own message straight into registers, the next block in
+// flight under the 24 rounds of the current one.  A lane's block lies in two or three 128-byte lines that stay in the
+// CU's vector cache between its 17 loads, so HBM sees each line once (profiles/r02_pmc_summary.json: traffic 1.03x).
+// STAGED = true: the wave loads 64 blocks cooperatively (coalesced) and transposes them through LDS; two barriers and
+// 2 x 17 LDS operations per block cost 2-4 % on the headline (profiles/r02_direct_loads_ab.txt).
+template <int RW, bool STAGED>
 __device__ __forceinline__ void mixed_body_k1(const MixedParams &q, uint32_t wave, uint64_t *s_stage)
 {
     constexpr uint32_t RB = RW * 8;
@@ -68,18 +74,38 @@ __device__ __forceinline__ void mixed_body_k1(const MixedParams &q, uint32_t wav
         }
     }
 
-    uint32_t voff[RW];
-#pragma unroll
-    for (int k = 0; k < RW; k++) {
-        const uint32_t i = k * 64 + lane;
-        uint32_t m = i / RW;
-        const uint32_t w = i - m * RW;
-        m = m < last ? m : (uint32_t)last;
-        voff[k] = m * (uint32_t)q.msg_stride + 8 * w;
-    }
-    const uint8_t *wave_base = q.msgs + item0 * q.msg_stride + (uint64_t)first * RB;
     const uint32_t nf = q.k1_count;
-    if (nf) {
+    if constexpr (!STAGED) {
+        if (nf) {
+        const uint8_t *mine = q.msgs + (active ? item : q.n - 1) * q.msg_stride + (uint64_t)first * RB;
+        uint64_t pf[RW];
+#pragma unroll
+        for (int w = 0; w < RW; w++) pf[w] = load_global_u64(mine + 8 * w);
+        for (uint32_t t = 0; t < nf; t++) {
+#pragma unroll
+            for (int w = 0; w < RW; w++) {
+                a.lo[w] ^= (uint32_t)pf[w];
+                a.hi[w] ^= (uint32_t)(pf[w] >> 32);
+            }
+            if (t + 1 < nf) {
+                mine += RB;
+#pragma unroll
+                for (int w = 0; w < RW; w++) pf[w] = load_global_u64(mine + 8 * w);
+            }
+            keccakf1600_unrolled(a);
+        }
+        }
+    } else if (nf) {
+        uint32_t voff[RW];
+#pragma unroll
+        for (int k = 0; k < RW; k++) {
+            const uint32_t i = k * 64 + lane;
+            uint32_t m = i / RW;
+            const uint32_t w = i - m * RW;
+            m = m < last ? m : (uint32_t)last;
+            voff[k] = m * (uint32_t)q.msg_stride + 8 * w;
+        }
+        const uint8_t *wave_base = q.msgs + item0 * q.msg_stride + (uint64_t)first * RB;
         uint64_t pf[RW];
 #pragma unroll
         for (int k = 0; k < RW; k++) pf[k] = *reinterpret_cast<const uint64_t *>(wave_base + voff[k]);
@@ -110,7 +136,7 @@ __device__ __forceinline__ void mixed_body_k1(const MixedParams &q, uint32_t wav
     }
 }
 
-template <int RW>
+template <int RW, bool STAGED>
 __device__ __forceinline__ void mixed_body_k2(const MixedParams &q, uint32_t wave, uint64_t *s_stage)
 {
     constexpr uint32_t RB = RW * 8;
@@ -136,18 +162,38 @@ __device__ __forceinline__ void mixed_body_k2(const MixedParams &q, uint32_t wav
         for (int i = 0; i < 25; i++) a.a[i] = h ? (uint32_t)(q.init_state[i] >> 32) : (uint32_t)q.init_state[i];
     }
 
-    uint32_t voff[NLOAD];
-#pragma unroll
-    for (int k = 0; k < NLOAD; k++) {
-        const uint32_t i = k * 64 + lane;
-        uint32_t m = i / RW;
-        const uint32_t w = i - m * RW;
-        m = m < last ? m : (uint32_t)last;  // also folds the elements past 32 sponges onto a valid address
-        voff[k] = m * (uint32_t)q.msg_stride + 8 * w;
-    }
-    const uint8_t *wave_base = q.msgs + item0 * q.msg_stride + (uint64_t)q.k2_first * RB;
     const uint32_t nf = q.k2_count;
-    if (nf) {
+    if constexpr (!STAGED) {
+        if (nf) {
+        // each lane of a pair loads its own 32-bit half of every word of its sponge's block, next block in flight
+        const uint8_t *mine = q.msgs + (active ? item : q.k2_end - 1) * q.msg_stride + (uint64_t)q.k2_first * RB + 4 * h;
+        uint32_t pf[RW];
+#pragma unroll
+        for (int w = 0; w < RW; w++)
+            pf[w] = *reinterpret_cast<const __attribute__((address_space(1))) uint32_t *>(reinterpret_cast<uintptr_t>(mine + 8 * w));
+        for (uint32_t t = 0; t < nf; t++) {
+#pragma unroll
+            for (int w = 0; w < RW; w++) a.a[w] ^= pf[w];
+            if (t + 1 < nf) {
+                mine += RB;
+#pragma unroll
+                for (int w = 0; w < RW; w++)
+                    pf[w] = *reinterpret_cast<const __attribute__((address_space(1))) uint32_t *>(reinterpret_cast<uintptr_t>(mine + 8 * w));
+            }
+            keccakf1600_k2_unrolled(a, hmask);
+        }
+        }
+    } else if (nf) {
+        uint32_t voff[NLOAD];
+#pragma unroll
+        for (int k = 0; k < NLOAD; k++) {
+            const uint32_t i = k * 64 + lane;
+            uint32_t m = i / RW;
+            const uint32_t w = i - m * RW;
+            m = m < last ? m : (uint32_t)last;  // also folds the elements past 32 sponges onto a valid address
+            voff[k] = m * (uint32_t)q.msg_stride + 8 * w;
+        }
+        const uint8_t *wave_base = q.msgs + item0 * q.msg_stride + (uint64_t)q.k2_first * RB;
         uint64_t pf[NLOAD];
 #pragma unroll
         for (int k = 0; k < NLOAD; k++) pf[k] = *reinterpret_cast<const uint64_t *>(wave_base + voff[k]);
@@ -179,12 +225,21 @@ __device__ __forceinline__ void mixed_body_k2(const MixedParams &q, uint32_t wav
 template <int RW>
 __global__ __launch_bounds__(64) void sponge_mixed_kernel(const MixedParams q)
 {
+    if (blockIdx.x < q.k2_waves)
+        mixed_body_k2<RW, false>(q, blockIdx.x, nullptr);
+    else
+        mixed_body_k1<RW, false>(q, blockIdx.x - q.k2_waves, nullptr);
+}
+
+template <int RW>
+__global__ __launch_bounds__(64) void sponge_mixed_staged_kernel(const MixedParams q)
+{
     // the two-lane role stages ceil(32 * RW / 64) * 64 words, the one-lane role 64 * RW
     __shared__ uint64_t s_stage[64 * RW];
     if (blockIdx.x < q.k2_waves)
-        mixed_body_k2<RW>(q, blockIdx.x, s_stage);
+        mixed_body_k2<RW, true>(q, blockIdx.x, s_stage);
     else
-        mixed_body_k1<RW>(q, blockIdx.x - q.k2_waves, s_stage);
+        mixed_body_k1<RW, true>(q, blockIdx.x - q.k2_waves, s_stage);
 }
 
 }  // namespace capy

@@ -396,16 +396,16 @@ def test_rotating_schedule_matches_one_lane_kernel(capy, sponge_lanes, d, n, L, 
     lib = _lib.lib()
     msgs = _dev_rand(n * stride, 11)
     outs = []
-    for lanes in (1, 3):
+    for lanes in (1, 3, 3 | (64 << 8)):  # one-lane kernel, rotating schedule, its LDS-staged A/B twin (debug bit 6)
         _lib.check(lib.capy_set_sponge_lanes(lanes))
         kind, phases = C.c_int(0), C.c_int(0)
         _lib.check(lib.capy_sha3_launch_plan(d, n, L, stride, C.byref(kind), C.byref(phases)))
-        assert (kind.value, phases.value >= 2) == ((3, True) if lanes == 3 else (1, False))
+        assert (kind.value, phases.value >= 2) == ((3, True) if lanes & 0xFF == 3 else (1, False))
         dig = torch.zeros(n * (d // 8), dtype=torch.uint8, device="cuda")
         _lib.check(lib.capy_sha3_batch_dev(d, n, msgs.data_ptr(), None, L, stride, dig.data_ptr(), None))
         torch.cuda.synchronize()
         outs.append(dig)
-    assert torch.equal(outs[0], outs[1])
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
     h = getattr(hashlib, "sha3_%d" % d)
     hd = bytes(outs[1].cpu().numpy())
     for i in sorted({0, 31, 32, 63, 64, n // 2, n - 65, n - 2, n - 1}):
