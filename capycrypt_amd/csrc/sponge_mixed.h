@@ -1,14 +1,15 @@
 // sponge_mixed.h — body absorb for batches that fill MORE than half but LESS than all of the chip's lanes.
 //
-// The headline workload is capacity-bound: 288 GB of HBM hold fewer than 55 k messages of 5 MiB, i.e. 768 waves of
-// one-lane-per-sponge work for 1024 SIMDs, and a quarter of the chip idles while every sponge advances at the
+// The headline workload is capacity-bound: 288 GB of HBM hold fewer than 56 k messages of 5 MiB, i.e. at most 870 waves
+// of one-lane-per-sponge work for 1024 SIMDs, and a sixth to a quarter of the chip idles while every sponge advances at the
 // one-lane rate (180 VALU per round).  The two-lane form (sponge_kernels_k2.h, 120 VALU per round) advances a sponge
 // 1.48x faster but needs twice the lanes, so it cannot take the whole batch either.  This kernel runs BOTH forms
 // side by side in one grid so that every SIMD holds exactly one wave: in each of P phases one group of n/P sponges is
 // processed two-lanes-wide while the others run one-lane-wide, the groups rotate, and the states cross phases through
 // a small HBM buffer (200 B per sponge).  Every sponge gets one fast phase of nb2 blocks and P-1 slow phases of nb1
 // blocks, nb2 / nb1 = the measured speed ratio, so all waves of a phase finish together.  Expected gain over the
-// one-lane kernel = (ratio + P - 1) / P: 1.16x at P = 3 (49 152 sponges on 1024 SIMDs).
+// one-lane kernel = (ratio + P - 1) / P: 1.16x at P = 3 (49 152 sponges on 1024 SIMDs), 1.10x at P = 5 (54 528, the
+// headline batch: 852 one-lane waves would leave 172 SIMDs idle).
 //
 // Scope: the uniform digest absorb only (equal lengths, fixed stride, 8-byte aligned).  Per-item head blocks (KMAC
 // keys) are absorbed first by a head-only launch of sponge_kernel<RW, false, 0> (SpongeParams::head_state); the tail,
