@@ -904,6 +904,7 @@ int symmetric_crypt_dev(bool encrypt, int d, size_t n, const uint8_t *keka, size
         fp.tag_stride = tag_len;
         fp.tag_len = (uint32_t)tag_len;
         fp.decrypt = encrypt ? 0 : 1;
+        fp.staged = (g_debug_flags.load() & 64) ? 1 : 0;  // A/B switch (debug bit 6)
         fp.n = n;
         // One wave per item (sponge_wide.h) while every wave still has most of a SIMD pair's LDS bandwidth to itself:
         // 1.3x per permutation at n = 128, break-even near one wave per SIMD (profiles/r02_wide_lane_probe.txt).

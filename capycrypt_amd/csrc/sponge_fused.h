@@ -40,10 +40,23 @@ struct FusedParams {
     uint32_t decrypt;
     const uint32_t *order;  // optional processing order, see SpongeParams::order
     uint32_t wide;          // launcher's choice: 1 = one wave per item (sponge_wide.h), 0 = four lanes per item (here)
+    uint32_t staged;        // A/B (debug bit 6): the round-1 form of this kernel, blocks staged through LDS
     uint64_t n;
 };
 
-template <int RW>
+// partner sponge's word: lanes (4q + 2, 4q + 3) <-> (4q, 4q + 1)
+__device__ __forceinline__ uint32_t quad_swap_pairs(uint32_t v)
+{
+    // quad_perm:[2,3,0,1] -> dpp_ctrl = 2 | 3<<2 | 0<<4 | 1<<6 = 0x4E
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);
+}
+
+// STAGED = false (default): every lane loads its own 32-bit half of every word of its item's block (the tag lane and
+// the keystream lane of a half load the same word in the same instruction, so the tag lane always sees the bytes as
+// they were before this step), the keystream lanes store the XORed half straight back, and on decrypt the tag lanes
+// take the keystream from their partner lanes with one DPP move per word.  No LDS and no barrier in the block loop.
+// STAGED = true: the round-1 form (wave-cooperative 8-byte transfers through LDS, four barriers per block), kept for A/B.
+template <int RW, bool STAGED = false>
 __global__ __launch_bounds__(64) void sponge_fused_crypt_kernel(const FusedParams fp)
 {
     constexpr uint32_t RB = RW * 8;
@@ -129,6 +142,52 @@ __global__ __launch_bounds__(64) void sponge_fused_crypt_kernel(const FusedParam
     // from here on the keystream sponge's state IS keystream block 0
 
     // ---- full blocks, one pass
+    uint32_t *stage32 = reinterpret_cast<uint32_t *>(s_stage);
+    if constexpr (!STAGED) {
+        const uint32_t max_full = wave_max_u32(nfull);
+        if (max_full) {
+            const uint8_t *last_word = batch_last_word(fp.msgs, fp.offsets, fp.n, fp.msg_stride, fp.uniform_len);
+            uint8_t *mine = (active ? const_cast<uint8_t *>(c.msg) : fp.msgs) + 4 * h;
+            uint32_t pf[RW];
+            auto own_load = [&](uint32_t t) {
+                const bool live = t < nfull;
+                const uint8_t *src = live ? mine + (uint64_t)t * RB : last_word;
+#pragma unroll
+                for (int w = 0; w < RW; w++)
+                    pf[w] = *reinterpret_cast<const __attribute__((address_space(1))) uint32_t *>(
+                        reinterpret_cast<uintptr_t>(live ? src + 8 * w : src));
+            };
+            own_load(0);
+            for (uint32_t t = 0; t < max_full; t++) {
+                const bool live = t < nfull;
+                uint32_t wv[RW];
+                if (fp.decrypt) {  // wave-uniform; the DPP move runs in every lane
+#pragma unroll
+                    for (int w = 0; w < RW; w++) wv[w] = pf[w] ^ quad_swap_pairs(a.a[w]);  // tag lanes: plaintext
+                } else {
+#pragma unroll
+                    for (int w = 0; w < RW; w++) wv[w] = pf[w];
+                }
+                if (live && role == 1) {
+                    uint8_t *dstp = mine + (uint64_t)t * RB;
+#pragma unroll
+                    for (int w = 0; w < RW; w++)
+                        *reinterpret_cast<__attribute__((address_space(1))) uint32_t *>(reinterpret_cast<uintptr_t>(dstp + 8 * w)) =
+                            pf[w] ^ a.a[w];
+                }
+                if (t + 1 < max_full) own_load(t + 1);
+                // tag sponge: absorb + permute; keystream sponge: permute while more keystream is needed
+                const bool perm = live && (role == 0 || (uint64_t)(t + 1) * RB < tgt_len);
+                if (perm) {
+                    if (role == 0) {
+#pragma unroll
+                        for (int w = 0; w < RW; w++) a.a[w] ^= wv[w];
+                    }
+                    keccakf1600_k2_unrolled(a, hmask);
+                }
+            }
+        }
+    } else {
     if (lane < NIT) {
         const uint64_t sl = (uint64_t)blockIdx.x * NIT + lane;
         const uint64_t it = sl < fp.n ? (fp.order ? (uint64_t)fp.order[sl] : sl) : fp.n;
@@ -151,7 +210,6 @@ __global__ __launch_bounds__(64) void sponge_fused_crypt_kernel(const FusedParam
     }
     __syncthreads();
     const uint32_t max_full = wave_max_u32(nfull);
-    uint32_t *stage32 = reinterpret_cast<uint32_t *>(s_stage);
     if (max_full) {
         uint8_t *dst[NLOAD];
         uint32_t lim[NLOAD];
@@ -215,6 +273,8 @@ __global__ __launch_bounds__(64) void sponge_fused_crypt_kernel(const FusedParam
                 keccakf1600_k2_unrolled(a, hmask);
             }
         }
+    }
+
     }
 
     // ---- tail: fewer than RB message bytes remain.  The keystream lanes read them (once), XOR, store, and hand the

@@ -18,6 +18,15 @@ hipError_t launch_sponge_fused(int rw, const FusedParams &fp, hipStream_t s)
         return hipGetLastError();
     }
     const dim3 grid((unsigned)((fp.n + 15) / 16)), block(64);
+    if (fp.staged) {
+        switch (rw) {
+        case 17: hipLaunchKernelGGL((sponge_fused_crypt_kernel<17, true>), grid, block, 0, s, fp); break;
+        case 19: hipLaunchKernelGGL((sponge_fused_crypt_kernel<19, true>), grid, block, 0, s, fp); break;
+        case 21: hipLaunchKernelGGL((sponge_fused_crypt_kernel<21, true>), grid, block, 0, s, fp); break;
+        default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     switch (rw) {
     case 17: hipLaunchKernelGGL(sponge_fused_crypt_kernel<17>, grid, block, 0, s, fp); break;
     case 19: hipLaunchKernelGGL(sponge_fused_crypt_kernel<19>, grid, block, 0, s, fp); break;

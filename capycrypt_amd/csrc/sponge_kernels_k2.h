@@ -192,49 +192,38 @@ __global__ __launch_bounds__(64) void sponge_kernel_k2(const SpongeParams p)
     for (uint32_t b = 0; b < hb_max; b++)
         if (active && b < hb) absorb_slow((uint64_t)b * RB);  // a pair is active or inactive as a whole
 
-    // ---------------- phase B: whole-wave coalesced loads, one block ahead, source pointers hoisted
-    if (h == 0) {
-        s_base[j] = (uint64_t)(uintptr_t)(c.msg ? c.msg : p.msgs);
-        s_nfull[j] = nfull;
-    }
+    // ---------------- phase B: each lane of a pair loads its own 32-bit half of every word of its sponge's block, the
+    // next block in flight under the rounds.  A pair's block lies in two or three 128-byte lines that stay in the CU's
+    // vector cache across its 17..21 loads (one wave per SIMD: 4 x 32 sponges per CU).  1.5-2.5 % faster than the
+    // wave-cooperative loads through LDS of round 1 (profiles/r02_direct_loads_ab.txt), 28 fewer VGPRs.
     const uint8_t *last_word = batch_last_word(p.msgs, p.offsets, p.n, p.msg_stride, p.uniform_len);
-    __syncthreads();
-    const uint32_t max_full = wave_max_u32(nfull);
-    if (max_full) {
-        const uint8_t *src[NLOAD];
-        uint32_t lim[NLOAD];
+    if (h == 0) s_base[j] = (uint64_t)(uintptr_t)(c.msg ? c.msg : p.msgs);  // MODE 1 reads it after its own barrier
+    {
+        const uint32_t max_full = wave_max_u32(nfull);
+        if (max_full) {
+            const uint8_t *mine = (c.msg ? c.msg : p.msgs) + 4 * h;
+            const uint8_t *safe = last_word;  // 8 readable bytes for lanes past their own last full block
+            auto own_load = [&](uint32_t t, uint32_t (&pf)[RW]) {
+                const uint8_t *q = t < nfull ? mine + (uint64_t)t * RB : safe;
 #pragma unroll
-        for (int k = 0; k < NLOAD; k++) {
-            const uint32_t i = k * 64 + lane;
-            const uint32_t m = i / RW, w = i - m * RW;
-            const bool in = m < NSP;
-            lim[k] = in ? s_nfull[in ? m : 0] : 0;
-            src[k] = in ? reinterpret_cast<const uint8_t *>(s_base[m]) + 8 * w : p.msgs;
-        }
-        uint64_t pf[NLOAD];
-        auto coop_load = [&](uint32_t t) {
+                for (int w = 0; w < RW; w++)
+                    pf[w] = *reinterpret_cast<const __attribute__((address_space(1))) uint32_t *>(
+                        reinterpret_cast<uintptr_t>(t < nfull ? q + 8 * w : q));
+            };
+            uint32_t pf[RW];
+            own_load(0, pf);
+            for (uint32_t t = 0; t < max_full; t++) {
+                if (t < nfull) {
 #pragma unroll
-            for (int k = 0; k < NLOAD; k++)
-                pf[k] = load_global_u64(ragged_src(t < lim[k], src[k], (uint64_t)t * RB, last_word));
-        };
-        coop_load(0);
-        const uint32_t *stage32 = reinterpret_cast<const uint32_t *>(s_stage);
-        for (uint32_t t = 0; t < max_full; t++) {
-#pragma unroll
-            for (int k = 0; k < NLOAD; k++) s_stage[k * 64 + lane] = pf[k];
-            __syncthreads();
-            uint32_t wv[RW];
-#pragma unroll
-            for (int w = 0; w < RW; w++) wv[w] = stage32[(j * RW + w) * 2 + h];
-            __syncthreads();
-            if (t + 1 < max_full) coop_load(t + 1);
-            if (t < nfull) {
-#pragma unroll
-                for (int w = 0; w < RW; w++) a.a[w] ^= wv[w];
-                if constexpr (BODY == 1)
-                    keccakf1600_k2_pipelined(a, hmask);
-                else
-                    keccakf1600_k2_unrolled(a, hmask);
+                    for (int w = 0; w < RW; w++) a.a[w] ^= pf[w];
+                }
+                if (t + 1 < max_full) own_load(t + 1, pf);
+                if (t < nfull) {
+                    if constexpr (BODY == 1)
+                        keccakf1600_k2_pipelined(a, hmask);
+                    else
+                        keccakf1600_k2_unrolled(a, hmask);
+                }
             }
         }
     }

@@ -90,7 +90,7 @@ for nmsg in (128, 512, 2048, 16384):
     perms = MIB5 // 136 + 3
     two_lane_bound = perms * 24 * 120 * 4.04 / 2.38e9
     wide_floor = perms * 24 * (3 * 64 + 22 * 4) / 2.38e9
-    kernel = "sponge_wide_crypt_kernel<17>" if nmsg <= 512 else "sponge_fused_crypt_kernel<17>"
+    kernel = "sponge_wide_crypt_kernel<17>" if nmsg <= 512 else "sponge_fused_crypt_kernel<17, false>"
     bound = wide_floor if nmsg <= 512 else two_lane_bound
     emit(config=3, what="sha3_encrypt / sha3_decrypt D512, %d x 5 MiB" % nmsg, enc_seconds=te, dec_seconds=td,
          enc_GiBps=nmsg * MIB5 / te / 2**30, dec_GiBps=nmsg * MIB5 / td / 2**30, roundtrip_ok=ok, kernel=kernel,
