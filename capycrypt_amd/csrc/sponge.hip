@@ -481,9 +481,13 @@ static int launch_sponge(int rw, const SpongeParams &p, hipStream_t s)
         const int rc = device_order(p.offsets, p.lens, p.n, s, &q.order);
         if (rc) return rc;
     }
-    const SpongeParams &p2 = q;
     hipError_t e;
     const size_t simds = device_simds();
+    // per-lane message loads in the one-lane kernels (sponge_kernels.h phase B); debug bit 6: A/B switch to the
+    // wave-cooperative loads through LDS of round 1
+    const bool direct_ok = !(q.debug_flags & 64);
+    if (direct_ok) q.debug_flags |= SPONGE_DIRECT_LOADS;
+    const SpongeParams &p2 = q;
     if (forced == 3 || (forced == 0 && g_mixed_enabled.load())) {
         const int m = try_launch_mixed(rw, p, forced == 3, s);
         if (m < 0) return m;

@@ -166,7 +166,36 @@ __global__ __launch_bounds__(64, WAVES) void sponge_kernel(const SpongeParams p)
             uint32_t voff[RW];
 #pragma unroll
             for (int k = 0; k < RW; k++) voff[k] = elem_offset(k);
-            if constexpr (!FULLCHIP) {
+            if (p.debug_flags & SPONGE_DIRECT_LOADS) {
+                // every lane loads the words of its own block, next block in flight under the rounds -- no LDS, no
+                // barrier.  The lines a wave's 64 blocks touch do not all stay in the CU's 32 KB vector cache at 2-4
+                // waves per SIMD, but L2 absorbs the re-fetches: +2-4 % uniform, +6-27 % ragged over the
+                // wave-cooperative loads through LDS (profiles/r02_direct_loads_ab.txt)
+                const uint8_t *mine = wave_base + (uint64_t)lane * p.msg_stride;
+                if constexpr (FULLCHIP) {
+                    // 128-VGPR budget: no registers held across the permutation, the other waves of the SIMD cover the loads
+                    for (uint32_t t = 0; t < nf; t++) {
+#pragma unroll
+                        for (int w = 0; w < RW; w++) xor_word(a, w, load_global_u64(mine + 8 * w));
+                        mine += RB;
+                        keccak_hot<FULLCHIP>(a);
+                    }
+                } else {
+                uint64_t pf[RW];
+#pragma unroll
+                for (int w = 0; w < RW; w++) pf[w] = load_global_u64(mine + 8 * w);
+                for (uint32_t t = 0; t < nf; t++) {
+#pragma unroll
+                    for (int w = 0; w < RW; w++) xor_word(a, w, pf[w]);
+                    if (t + 1 < nf) {
+                        mine += RB;
+#pragma unroll
+                        for (int w = 0; w < RW; w++) pf[w] = load_global_u64(mine + 8 * w);
+                    }
+                    keccak_hot<FULLCHIP>(a);
+                }
+                }
+            } else if constexpr (!FULLCHIP) {
                 uint64_t pf[RW];
 #pragma unroll
                 for (int k = 0; k < RW; k++) pf[k] = *reinterpret_cast<const uint64_t *>(wave_base + voff[k]);
@@ -206,7 +235,28 @@ __global__ __launch_bounds__(64, WAVES) void sponge_kernel(const SpongeParams p)
         __syncthreads();
         const uint32_t max_full = wave_max_u32(nfull);
         const uint8_t *last_word = batch_last_word(p.msgs, p.offsets, p.n, p.msg_stride, p.uniform_len);
-        if constexpr (!FULLCHIP) {
+        if (!FULLCHIP && (p.debug_flags & SPONGE_DIRECT_LOADS)) {  // ragged batches never take the issue-tuned instance
+            if (max_full) {
+                const uint8_t *mine = c.msg ? c.msg : p.msgs;
+                uint64_t pf[RW];
+                auto own_load = [&](uint32_t t) {
+                    const bool live = t < nfull;
+                    const uint8_t *src = live ? mine + (uint64_t)t * RB : last_word;
+#pragma unroll
+                    for (int w = 0; w < RW; w++) pf[w] = load_global_u64(live ? src + 8 * w : src);
+                };
+                own_load(0);
+                for (uint32_t t = 0; t < max_full; t++) {
+                    const bool live = t < nfull;
+                    if (live) {
+#pragma unroll
+                        for (int w = 0; w < RW; w++) xor_word(a, w, pf[w]);
+                    }
+                    if (t + 1 < max_full) own_load(t + 1);
+                    if (live) keccak_hot<FULLCHIP>(a);
+                }
+            }
+        } else if constexpr (!FULLCHIP) {
             if (max_full) {
                 // source pointer and block limit of every (slot, lane) pair, hoisted out of the block loop
                 const uint8_t *src[RW];
@@ -330,7 +380,35 @@ __global__ __launch_bounds__(64, WAVES) void sponge_kernel(const SpongeParams p)
     } else {
         // keystream XOR in place: msg[i] ^= squeeze(len); squeeze block = RW words (cSHAKE/KMAC only)
         uint32_t xfull = msg_aligned ? (uint32_t)(tgt_len / RB) : 0;
-        if (uniform) {
+        if (!FULLCHIP && (p.debug_flags & SPONGE_DIRECT_LOADS)) {
+            // every lane XORs its own message in place with 8-byte loads and stores, next block in flight.  Not for the
+            // issue-tuned instance: at 4 waves per SIMD the per-lane partial-line stores cost 18 % (429 -> 351 GiB/s at
+            // 262 144 x 64 KiB, profiles/r02_direct_loads_ab.txt) where the staged, coalesced stores do not.
+            if (uniform) xfull = (uint32_t)(p.uniform_len / RB);
+            uint8_t *mine = const_cast<uint8_t *>(c.msg ? c.msg : p.msgs);
+            const uint32_t max_x = wave_max_u32(xfull);
+            if (max_x) {
+                const uint8_t *last_word = batch_last_word(p.msgs, p.offsets, p.n, p.msg_stride, p.uniform_len);
+                uint64_t pf[RW];
+                auto own_load = [&](uint32_t t) {
+                    const bool live = t < xfull;
+                    const uint8_t *src = live ? mine + (uint64_t)t * RB : last_word;
+#pragma unroll
+                    for (int w = 0; w < RW; w++) pf[w] = load_global_u64(live ? src + 8 * w : src);
+                };
+                own_load(0);
+                for (uint32_t t = 0; t < max_x; t++) {
+                    const bool live = t < xfull;
+                    if (live) {
+                        uint8_t *bt = mine + (uint64_t)t * RB;
+#pragma unroll
+                        for (int w = 0; w < RW; w++) store_global_u64(bt + 8 * w, pf[w] ^ state_word(a, w));
+                    }
+                    if (t + 1 < max_x) own_load(t + 1);
+                    if (live && (uint64_t)(t + 1) * RB < tgt_len) keccak_hot<FULLCHIP>(a);
+                }
+            }
+        } else if (uniform) {
             const uint32_t nx = (uint32_t)(p.uniform_len / RB);
             xfull = nx;
             if (nx) {

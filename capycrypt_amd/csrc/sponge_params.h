@@ -5,6 +5,10 @@
 
 namespace capy {
 
+// set by the launcher (never by the caller) in SpongeParams::debug_flags: the one-lane kernels load message blocks per
+// lane instead of cooperatively through LDS (the default; cleared by debug bit 6 for A/B runs)
+constexpr uint32_t SPONGE_DIRECT_LOADS = 1u << 16;
+
 struct SpongeParams {
     uint64_t init_state[25];  // state after the batch-shared prefix (zeros for SHA3)
     // batch-shared prefix bytes that could NOT be folded into init_state (only when the prefix is
@@ -47,7 +51,7 @@ struct SpongeParams {
     // optional processing order (ragged batches): slot k of the grid works on item order[k].  The launcher sorts by
     // length so that the lanes of a wave finish together; outputs stay at the item's own index.
     const uint32_t *order;
-    uint32_t debug_flags;  // bit 0: do not use the wave-uniform addressing path (A/B measurements)
+    uint32_t debug_flags;  // bit 0: do not use the wave-uniform addressing path (A/B measurements); SPONGE_DIRECT_LOADS
     // resume (one-lane digest kernel only): the first resume_blocks blocks were absorbed by sponge_mixed_kernel,
     // whose states sit word-major in resume_state[25][resume_pad]; only the tail blocks and the squeeze remain
     const uint64_t *resume_state;

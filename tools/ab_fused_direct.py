@@ -33,7 +33,10 @@ def timed(fn):
     return e0.elapsed_time(e1) * 1e-3
 
 
-for nmsg, mlen in ((2048, MIB5), (16384, MIB5), (16384, 1 << 20)):
+shapes = ((2048, MIB5), (16384, MIB5), (16384, 1 << 20))
+if len(sys.argv) > 1:  # e.g. 32768x1048576,262144x65536 (two-pass path: keystream XOR kernel + tag kernel)
+    shapes = tuple(tuple(int(v) for v in x.split("x")) for x in sys.argv[1].split(","))
+for nmsg, mlen in shapes:
     msgs = rand(nmsg * mlen, 3)
     pws = rand(nmsg * 64, 31)
     zs = rand(nmsg * 512, 32)
