@@ -342,14 +342,15 @@ static size_t wide_max_items()
     return forced >= 0 ? (size_t)forced : device_simds() / 2;
 }
 
-// speed of the two-lane form relative to the one-lane form, per sponge, one wave per SIMD (40.4 vs 59.7 ms per MiB of
-// message = 1.48; the phase time is flat between 1.48 and 1.52, profiles/r01_mixed_schedule.txt); CAPY_MIXED_RATIO overrides
+// speed of the two-lane form relative to the one-lane form, per sponge, when both share the chip at one wave per SIMD.
+// Re-measured with the per-lane-load kernels for P = 2..6 phases (profiles/r02_mixed_ratio_sweep.txt): best at 1.46-1.47
+// for every P (+1.8 % over the 1.50 of round 1 at the headline batch); CAPY_MIXED_RATIO overrides
 static double mixed_ratio()
 {
     static const double r = [] {
         const char *e = getenv("CAPY_MIXED_RATIO");
         double v = e ? atof(e) : 0.0;
-        return (v >= 1.0 && v <= 2.0) ? v : 1.50;
+        return (v >= 1.0 && v <= 2.0) ? v : 1.47;
     }();
     return r;
 }
