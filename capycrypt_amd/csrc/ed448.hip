@@ -6,6 +6,7 @@
 #include <mutex>
 #include "common.h"
 #include "ed448_algo.h"
+#include "ed448_wave.h"
 #include "sponge_host.h"
 
 namespace capy {
@@ -17,6 +18,9 @@ namespace capy {
 // ------------------------------------------------------------------ kernels (one item per lane)
 #ifndef CAPY_ED448_WAVES
 #define CAPY_ED448_WAVES 2
+#endif
+#ifndef CAPY_ED448_WAVE_MAX_DEFAULT
+#define CAPY_ED448_WAVE_MAX_DEFAULT 8192
 #endif
 #ifdef CAPY_ED448_NUMVGPR
 __attribute__((amdgpu_num_vgpr(CAPY_ED448_NUMVGPR)))
@@ -222,10 +226,33 @@ static size_t pair_min_items()
 // in full per window (2049 rows), so fb_ct_kernel uses a second shared table with 4-bit windows (9 rows, 113 windows).
 static std::atomic<bool> g_hardened{false};
 
+// Small batches: one item per WAVE (ed448_wave.h) instead of one per lane -- 5.6x lower latency for the variable-base
+// and 2.9x for the fixed-base multiplication, worth it while the batch is too small to fill the chip's lanes: the
+// crossover is at ~10 000 items for variable base / double-scalar and ~5 000 for fixed base (profiles/r02_ed448_wave.txt),
+// hence a threshold of 8192 and half of it.  Off in hardened mode.  capy_ed448_set_wave_max() / CAPY_ED448_WAVE_MAX
+// override the threshold (0 = never).
+static std::atomic<long> g_wave_max{-1};
+static size_t wave_max_items()
+{
+    const long forced = g_wave_max.load();
+    if (forced >= 0) return (size_t)forced;
+    static const long env = [] {
+        const char *e = getenv("CAPY_ED448_WAVE_MAX");
+        return e ? atol(e) : -1L;
+    }();
+    return env >= 0 ? (size_t)env : (size_t)CAPY_ED448_WAVE_MAX_DEFAULT;
+}
+
 static int vb_launch(size_t n, const uint8_t *scalars, uint64_t scalar_stride, const uint8_t *points,
                      uint64_t point_stride, uint8_t *out, hipStream_t s)
 {
     if (!n) return CAPY_OK;
+    if (!g_hardened.load() && n <= wave_max_items()) {
+        hipLaunchKernelGGL(wave::vb_wave_kernel, dim3((unsigned)n), dim3(64), 0, s, (uint64_t)n, scalars, scalar_stride, points,
+                           point_stride, out);
+        CAPY_HIP(hipGetLastError());
+        return CAPY_OK;
+    }
     CAPY_WS(tab, uint32_t *, s, WS_TABLE, (n + 63) / 64 * 64 * VB_TABLE_DWORDS * 4);
     if (g_hardened.load()) {
         hipLaunchKernelGGL(vb_ct_kernel, grid64(n), dim3(64), 0, s, (uint64_t)n, scalars, scalar_stride, points, point_stride,
@@ -335,7 +362,9 @@ static int fb_launch(size_t n, const uint8_t *scalars, uint8_t *out, hipStream_t
     const uint32_t *gt = nullptr;
     int rc = ensure_gtab(&gt);
     if (rc) return rc;
-    if (n >= pair_min_items())
+    if (n <= wave_max_items() / 2)
+        hipLaunchKernelGGL(wave::fb_wave_kernel, dim3((unsigned)n), dim3(64), 0, s, (uint64_t)n, scalars, out, gt);
+    else if (n >= pair_min_items())
         hipLaunchKernelGGL(fb2_kernel, dim3((unsigned)((n + 127) / 128)), dim3(64), 0, s, (uint64_t)n, scalars, out, gt);
     else
         hipLaunchKernelGGL(fb_kernel, grid64(n), dim3(64), 0, s, (uint64_t)n, scalars, out, gt);
@@ -349,6 +378,11 @@ static int dsm_launch(size_t n, const uint8_t *a, const uint8_t *b, const uint8_
     const uint32_t *gt = nullptr;
     int rc = ensure_gtab(&gt);
     if (rc) return rc;
+    if (n <= wave_max_items()) {
+        hipLaunchKernelGGL(wave::dsm_wave_kernel, dim3((unsigned)n), dim3(64), 0, s, (uint64_t)n, a, b, points, out, gt);
+        CAPY_HIP(hipGetLastError());
+        return CAPY_OK;
+    }
     CAPY_WS(tab, uint32_t *, s, WS_TABLE, n * VB_TABLE_DWORDS * 4);
     hipLaunchKernelGGL(dsm_kernel, grid64(n), dim3(64), 0, s, (uint64_t)n, a, b, points, out, tab, gt);
     CAPY_HIP(hipGetLastError());
@@ -539,6 +573,12 @@ int capy_ed448_add_batch(size_t n, const uint8_t *p_xy, const uint8_t *q_xy, uin
                        o.as<uint8_t>());
     CAPY_HIP(hipGetLastError());
     return down(out_xy, o, n * 112);
+}
+
+int capy_ed448_set_wave_max(long max_items)
+{
+    g_wave_max.store(max_items < 0 ? -1 : max_items);
+    return CAPY_OK;
 }
 
 int capy_ed448_set_hardened(int on)

@@ -26,6 +26,17 @@ def O():
     return oracle
 
 
+@pytest.fixture(autouse=True, params=[-1, 0], ids=["wave-per-item-for-small-batches", "lane-per-item-only"])
+def ed448_kernel_family(request):
+    """Every test runs twice: with the default kernel choice (batches of up to a few thousand scalar multiplications take
+    the one-item-per-wave kernels of csrc/ed448_wave.h) and with those switched off (one item per lane at every size)."""
+    from capycrypt_amd import _lib
+
+    _lib.check(_lib.lib().capy_ed448_set_wave_max(request.param))
+    yield request.param
+    _lib.check(_lib.lib().capy_ed448_set_wave_max(-1))
+
+
 @pytest.fixture(scope="module")
 def vectors():
     with open(os.path.join(HERE, "golden", "ed448_vectors.json")) as f:
@@ -621,3 +632,43 @@ def test_many_forms_of_the_python_mirror(capy, O):
     ok = key_decrypt_many(ms, wrong)
     assert ok == [i not in (3, 9) for i in range(n)]
     assert all(bytes(ms[i].msg) == bodies[i] for i in range(n) if i not in (3, 9)) and bytes(ms[9].msg) == ct9
+
+
+def test_wave_kernels_equal_lane_kernels_on_edge_cases(capy, O, ed448_kernel_family):
+    """One item per wave (csrc/ed448_wave.h) against one item per lane, byte for byte: random and extreme scalars
+    (0, 1, 2^448 - 1, r, r - 1, single bits), distinct subgroup points, the identity, the point of order 2, and a
+    non-curve point (both kernel families run the same formulas, so even that must agree); variable base, fixed base and
+    [a]G + [b]P; a few results are also checked against the C oracle."""
+    import ctypes as C
+
+    from capycrypt_amd import _lib
+
+    if ed448_kernel_family != -1:
+        pytest.skip("sets the kernel family itself")
+    lib = _lib.lib()
+    rng = random.Random(448)
+    r = (1 << 446) - 0x8335dc163bb124b65129c96fde933d8d723a70aadc873d6d54a7bb0d
+    ks = [0, 1, 2, (1 << 448) - 1, r, r - 1, r + 1, 1 << 447, 1 << 224, (1 << 224) - 1, 0x0F0F << 430]
+    ks += [rng.getrandbits(448) for _ in range(40)]
+    n = len(ks)
+    kb = [k.to_bytes(56, "big") for k in ks]
+    ts = [rng.getrandbits(446).to_bytes(56, "big") for _ in range(n)]
+    pts = capy.ops.ed448_basemul_batch(ts)
+    ident = (0).to_bytes(56, "little") + (1).to_bytes(56, "little")
+    p = (1 << 448) - (1 << 224) - 1
+    order2 = (0).to_bytes(56, "little") + (p - 1).to_bytes(56, "little")
+    pts[3], pts[4], pts[5] = ident, order2, (5).to_bytes(56, "little") + (7).to_bytes(56, "little")
+    results = []
+    for wmax in (0, 1 << 20):
+        _lib.check(lib.capy_ed448_set_wave_max(wmax))
+        vb = capy.ops.ed448_scalarmul_batch(kb, pts)
+        fb = capy.ops.ed448_basemul_batch(kb)
+        out = (C.c_uint8 * (n * 112))()
+        _lib.check(lib.capy_ed448_double_scalarmul_batch(n, b"".join(kb[::-1]), b"".join(kb), b"".join(pts), out))
+        results.append((vb, fb, bytes(out)))
+    assert results[0][0] == results[1][0]
+    assert results[0][1] == results[1][1]
+    assert results[0][2] == results[1][2]
+    for i in (0, 1, 3, 6, 11, n - 1):
+        assert results[1][0][i] == O.ed448_scalarmul(kb[i], pts[i]), i
+        assert results[1][1][i] == O.ed448_basemul(kb[i]), i
