@@ -226,8 +226,8 @@ static size_t pair_min_items()
 // in full per window (2049 rows), so fb_ct_kernel uses a second shared table with 4-bit windows (9 rows, 113 windows).
 static std::atomic<bool> g_hardened{false};
 
-// Small batches: one item per WAVE (ed448_wave.h) instead of one per lane -- 5.6x lower latency for the variable-base
-// and 2.9x for the fixed-base multiplication, worth it while the batch is too small to fill the chip's lanes: the
+// Small batches: one item per WAVE (ed448_wave.h) instead of one per lane -- 7x lower latency for the variable-base
+// and 3.6x for the fixed-base multiplication, worth it while the batch is too small to fill the chip's lanes: the
 // crossover is at ~10 000 items for variable base / double-scalar and ~5 000 for fixed base (profiles/r02_ed448_wave.txt),
 // hence a threshold of 8192 and half of it.  Off in hardened mode.  capy_ed448_set_wave_max() / CAPY_ED448_WAVE_MAX
 // override the threshold (0 = never).

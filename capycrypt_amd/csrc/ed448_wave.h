@@ -8,7 +8,7 @@
 // a level of the addition / doubling formulas side by side.
 //
 //   field multiplication (rv_mul): a_i is broadcast inside each row (ds_swizzle), b * x^i mod p (x = 2^28,
-//   x^16 = x^8 + 1) is kept rotating through the row (two DPP moves and an add per step), every lane accumulates one
+//   x^16 = x^8 + 1) is kept rotating through the row (two fused DPP operations per step), every lane accumulates one
 //   64-bit column: 16 v_mad_u64_u32 per lane, ~100 instructions, 240 ns at one wave per SIMD against 554 ns for the
 //   in-lane form -- and four of them at once (tools/probe_ed448_sliced.hip checks it against fe_mul bit for bit).
 //   doubling = 2 passes, addition = 3 passes, rows are moved with ds_bpermute.
@@ -29,7 +29,7 @@ typedef uint32_t RV;  // one limb per lane: lane = 16 * row + limb; four field e
 
 struct WC {            // per-lane constants
     uint32_t l4;       // 4 * limb index (byte address of my limb inside a row for ds_bpermute)
-    uint32_t m8, m89;  // all-ones in limb lane 8 / lanes 8 and 9
+    uint32_t m8, m89, m8b;  // all-ones in limb lane 8 / lanes 8 and 9 / lanes 8..11
     uint32_t r0, r1, r2, r3;  // all-ones in row 0 / 1 / 2 / 3
     uint32_t twop, fourp;     // my limb of 2p and 4p
     uint32_t one;             // my limb of the field element 1
@@ -42,6 +42,7 @@ __device__ __forceinline__ WC wc_init()
     c.l4 = l * 4;
     c.m8 = l == 8 ? ~0u : 0u;
     c.m89 = (l == 8 || l == 9) ? ~0u : 0u;
+    c.m8b = (l >= 8 && l <= 11) ? ~0u : 0u;
     c.r0 = row == 0 ? ~0u : 0u;
     c.r1 = row == 1 ? ~0u : 0u;
     c.r2 = row == 2 ? ~0u : 0u;
@@ -50,7 +51,7 @@ __device__ __forceinline__ WC wc_init()
     c.fourp = 2 * c.twop;
     c.one = l == 0 ? 1u : 0u;
     // keep the masks as AND operands (the compiler would otherwise re-derive the conditions and use v_cndmask)
-    asm volatile("" : "+v"(c.m8), "+v"(c.m89), "+v"(c.r0), "+v"(c.r1), "+v"(c.r2), "+v"(c.r3));
+    asm volatile("" : "+v"(c.m8), "+v"(c.m89), "+v"(c.m8b), "+v"(c.r0), "+v"(c.r1), "+v"(c.r2), "+v"(c.r3));
     return c;
 }
 
@@ -83,9 +84,10 @@ __device__ __forceinline__ RV rv_neg_nr(const WC &c, RV a) { return c.twop - a; 
 __device__ __forceinline__ RV rv_sub(const WC &c, RV a, RV b) { return rv_weak(c, a + c.twop - b); }
 __device__ __forceinline__ RV rv_sub4(const WC &c, RV a, RV b) { return rv_weak(c, a + c.fourp - b); }
 
-// Row-wise a * b mod p.  Exact while 32 * max_limb(a) * max_limb(b) < 2^64 (sixteen terms per column, the limbs of
-// b * x^i grow to at most twice those of b) -- looser than fe_mul's 38 La Lb, so every operand bound of the point
-// formulas in ed448_dev.h carries over.  Output limbs <= 2^28 + 6.
+// Row-wise a * b mod p.  The same polynomial product folded with the same x^16 = x^8 + 1 as fe_mul, so a column
+// collects the same products with the same multiplicities: exact while 38 * max_limb(a) * max_limb(b) < 2^64, and every
+// operand bound audited for the point formulas of ed448_dev.h carries over (the limbs of b * x^i are sums of at most
+// three limbs of b: < 2^32).  Output limbs <= 2^28 + 8.
 __device__ __forceinline__ RV rv_mul(const WC &c, RV a, RV b)
 {
     uint32_t ai[16];
@@ -105,10 +107,15 @@ __device__ __forceinline__ RV rv_mul(const WC &c, RV a, RV b)
     ai[13] = limb_bcast<13>(a);
     ai[14] = limb_bcast<14>(a);
     ai[15] = limb_bcast<15>(a);
+    // B[i] = b * x^i mod p in four interleaved chains (steps of x^4), so that the DPP moves of one chain cover the
+    // latency of the others:  * x: limb 15 -> limbs 0 and 8;  * x^2: limbs 14, 15 -> 0, 1 and 8, 9;  * x^4: 12..15 -> 0..3 and 8..11
     uint32_t B[16];
     B[0] = b;
+    B[1] = row_ror<1>(b) + (row_ror<9>(b) & c.m8);
+    B[2] = row_ror<2>(b) + (row_ror<10>(b) & c.m89);
+    B[3] = row_ror<1>(B[2]) + (row_ror<9>(B[2]) & c.m8);
 #pragma unroll
-    for (int i = 1; i < 16; i++) B[i] = row_ror<1>(B[i - 1]) + (row_ror<9>(B[i - 1]) & c.m8);  // * x: limb 15 -> limbs 0 and 8
+    for (int i = 4; i < 16; i++) B[i] = row_ror<4>(B[i - 4]) + (row_ror<12>(B[i - 4]) & c.m8b);
     uint64_t acc = 0;
 #pragma unroll
     for (int i = 0; i < 16; i++) acc += (uint64_t)ai[i] * B[i];

@@ -170,7 +170,7 @@ int capy_ed448_set_hardened(int on);
 
 /* Tuning / A-B switch (process-wide): batches of up to max_items scalar multiplications take the one-item-per-wave
  * kernels (csrc/ed448_wave.h: a field element spread over 16 lanes, the four coordinates of a point in the four rows of
- * a wave; 5.6x / 2.9x lower latency than one item per lane for variable / fixed base, less throughput; fixed-base
+ * a wave; 7x / 3.6x lower latency than one item per lane for variable / fixed base, less throughput; fixed-base
  * batches switch at half the value).  0 = never, negative = the built-in default (8192).
  * Results are bit-identical either way.  Has no effect in hardened mode, which always uses the batched kernels. */
 int capy_ed448_set_wave_max(long max_items);
