@@ -125,18 +125,31 @@ pubs_h = (C.c_uint8 * (n * 112))()
 h_h = (C.c_uint8 * (n * 56))()
 z_h = (C.c_uint8 * (n * 56))()
 st_h = (C.c_int32 * n)()
-_lib.check(lib.capy_keypair_batch(512, n, pws_h, 64, None, pubs_h))  # warm (fixed-base table build)
-t0 = time.perf_counter()
-_lib.check(lib.capy_keypair_batch(512, n, pws_h, 64, None, pubs_h))
-tk = time.perf_counter() - t0
-t0 = time.perf_counter()
-_lib.check(lib.capy_schnorr_sign_batch(512, n, pws_h, 64, None, msgs_h, offs_h, h_h, z_h))
-ts = time.perf_counter() - t0
-t0 = time.perf_counter()
-_lib.check(lib.capy_schnorr_verify_batch(512, n, pubs_h, msgs_h, offs_h, h_h, z_h, st_h))
-tv = time.perf_counter() - t0
+
+
+def first_and_steady(fn):
+    """seconds of the first call of the process (scratch pools, side stream, fixed-base table, host pages not yet
+    pinned) and of the best of three further calls"""
+    t0 = time.perf_counter()
+    _lib.check(fn())
+    first = time.perf_counter() - t0
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        _lib.check(fn())
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    return first, best
+
+
+tk0, tk = first_and_steady(lambda: lib.capy_keypair_batch(512, n, pws_h, 64, None, pubs_h))
+ts0, ts = first_and_steady(lambda: lib.capy_schnorr_sign_batch(512, n, pws_h, 64, None, msgs_h, offs_h, h_h, z_h))
+tv0, tv = first_and_steady(lambda: lib.capy_schnorr_verify_batch(512, n, pubs_h, msgs_h, offs_h, h_h, z_h, st_h))
 emit(config=5, what="Schnorr D512, 2^16 x 1 KiB messages, host-buffer C ABI (PCIe inclusive)",
-     keypair_per_s=n / tk, sign_per_s=n / ts, verify_per_s=n / tv, all_verified=not any(st_h))
+     keypair_per_s=n / tk, sign_per_s=n / ts, verify_per_s=n / tv, all_verified=not any(st_h),
+     first_call_per_s={"keypair": n / tk0, "sign": n / ts0, "verify": n / tv0},
+     note="steady state = best of three calls after the first; the first call of a process also builds the fixed-base "
+          "table, allocates the scratch pools and pins the host pages")
 
 # ---- PCIe-inclusive SHA3-256 rate through the host-pointer entry point: 65536 x 64 KiB = 4 GiB of pageable host
 # memory (the kernel itself takes ~4 ms at this shape, so this measures the staging path).  Cold = first call on a
