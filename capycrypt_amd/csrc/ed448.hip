@@ -450,9 +450,18 @@ struct LateMsgs {
         return CAPY_OK;
     }
 };
+struct SideStreams {  // one per host thread and device, destroyed with the thread
+    hipStream_t s[64] = {nullptr};
+    ~SideStreams()
+    {
+        for (hipStream_t x : s)
+            if (x) (void)hipStreamDestroy(x);
+    }
+};
 static hipStream_t side_stream()
 {
-    thread_local hipStream_t streams[64] = {nullptr};
+    thread_local SideStreams holder;
+    hipStream_t *streams = holder.s;
     static const bool off = [] {  // CAPY_HOST_OVERLAP=0: everything on the default stream (A/B: copy and kernels serialise)
         const char *e = getenv("CAPY_HOST_OVERLAP");
         return e && e[0] == '0';
