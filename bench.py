@@ -326,6 +326,28 @@ def main():
                 eel = float(t.item())
             ed = {"pairs_per_gpu": n, "scalar_mults_per_s": world * n * reps / eel,
                   "kernel_ms": e0.elapsed_time(e1) / reps}
+            # latency of a small batch (what a one-message-at-a-time caller of the reference's API pays): 64 variable-base
+            # multiplications per call, one item per wave (csrc/ed448_wave.h, the default up to 8192 items) against one
+            # item per lane; the outputs must be identical
+            if rank == 0:
+                small = {}
+                outs = []
+                for name, wmax in (("wave_per_item_ms", -1), ("lane_per_item_ms", 0)):
+                    _lib.check(lib.capy_ed448_set_wave_max(wmax))
+                    o = torch.zeros(64 * 112, dtype=torch.uint8, device=dev)
+                    _lib.check(lib.capy_ed448_scalarmul_batch_dev(64, sc.data_ptr(), pts.data_ptr(), o.data_ptr(), sp))
+                    torch.cuda.synchronize()
+                    s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    s0.record(stream)
+                    for _ in range(5):
+                        _lib.check(lib.capy_ed448_scalarmul_batch_dev(64, sc.data_ptr(), pts.data_ptr(), o.data_ptr(), sp))
+                    s1.record(stream)
+                    torch.cuda.synchronize()
+                    small[name] = s0.elapsed_time(s1) / 5
+                    outs.append(o)
+                _lib.check(lib.capy_ed448_set_wave_max(-1))
+                assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], out[:64 * 112]), "kernel families disagree"
+                ed["small_batch"] = dict(items=64, **small)
             # the first outputs are kept for the parity spot-check, which runs in the cpu_baseline leg (the only
             # place this file touches oracle/)
             ed_sample = (sc[:56 * 4].cpu().numpy().tobytes(), pts[:112 * 4].cpu().numpy().tobytes(),
