@@ -436,6 +436,14 @@ static int try_launch_mixed(int rw, const SpongeParams &p, bool forced, hipStrea
 }
 
 // which kernel launch_sponge() picks: 1 one-lane latency-tuned, 2 two-lane, 3 rotating schedule, 4 one-lane issue-tuned
+// messages of up to this many rate blocks (suffix included) take sponge_short.h when the batch fills the chip
+// (CAPY_SHORT_MAX_BLOCKS overrides; profiles/r02_short_message_kernel.txt)
+static const uint32_t SHORT_MAX_BYTES_PER_RATE = [] {
+    const char *e = getenv("CAPY_SHORT_MAX_BLOCKS");
+    const long v = e ? atol(e) : 4;
+    return (uint32_t)((v >= 0 && v <= 4096) ? v : 4);
+}();
+
 static int sponge_plan(int rw, const SpongeParams &p, int *phases)
 {
     const int forced = g_lanes_per_sponge.load();
@@ -444,6 +452,9 @@ static int sponge_plan(int rw, const SpongeParams &p, int *phases)
     MixedPlan m;
     const unsigned dbg = g_debug_flags.load();
     if (forced == 0 && !(dbg & 16) && !p.offsets && p.n <= 2 * wide_max_items() && p.uniform_len >= 64 * 1024) return 6;
+    if (forced == 0 && !(dbg & 128) && !p.offsets && p.n > 128 * simds && p.head_len == 0 && p.pre_len == 0 &&
+        p.uniform_len + p.suffix_len <= SHORT_MAX_BYTES_PER_RATE * (uint32_t)rw * 8 && ((p.msg_stride | (uintptr_t)p.msgs) & 7) == 0)
+        return 7;
     if ((forced == 3 || (forced == 0 && g_mixed_enabled.load())) && mixed_plan(rw, p, forced == 3, m)) {
         *phases = (int)m.P;
         return 3;
@@ -517,6 +528,23 @@ static int launch_sponge(int rw, const SpongeParams &p, hipStream_t s)
             if (e == hipErrorInvalidValue) return fail(CAPY_ERR_ARG, "internal: no kernel instance for this rate / mode");
             CAPY_HIP(e);
             return launch_sponge(rw, tail, s);
+        }
+    }
+    // Many short, equally long, key-less messages (SHA3 / SHAKE / cSHAKE digests of up to one squeeze block): the framing
+    // is wave-uniform, sponge_short.h decides it with scalar code.  Debug bit 7: never (A/B and tests).
+    {
+        const uint32_t rb = (uint32_t)rw * 8;
+        const bool short_ok = forced == 0 && !(q.debug_flags & 128) && p.out_mode == 0 && p.absorb_body && p.pre_len == 0 &&
+                              p.head_len == 0 && !p.key_offsets && !p.offsets && !p.mask && !p2.order && !p.resume_state &&
+                              !p.head_state && p.stride_bytes == rb && p.n > 128 * simds &&
+                              p.uniform_len + p.suffix_len <= SHORT_MAX_BYTES_PER_RATE * rb && p.msg_stride >= p.uniform_len &&
+                              (((uintptr_t)p.msgs | p.msg_stride) & 7) == 0 && p.out_len <= 8 * p.sq_words &&
+                              (((uintptr_t)p.out | p.out_stride) & 7) == 0;
+        if (short_ok) {
+            e = launch_sponge_short(rw, p2, s);
+            if (e == hipErrorInvalidValue) return fail(CAPY_ERR_ARG, "internal: no kernel instance for this rate");
+            CAPY_HIP(e);
+            return CAPY_OK;
         }
     }
     // Very small digest batches of long messages: one sponge per 25 lanes (sponge_wide.h), 1.3x the two-lane kernel per
@@ -1467,6 +1495,7 @@ int capy_sha3_launch_plan(int d, size_t n, uint64_t uniform_len, uint64_t msg_st
     p.uniform_len = uniform_len;
     p.msg_stride = msg_stride;
     p.absorb_body = 1;
+    p.suffix_len = 1;  // the SHA3 domain-separation byte
     p.stride_bytes = f.stride;
     p.n = n;
     *kind = sponge_plan(f.rw, p, phases);

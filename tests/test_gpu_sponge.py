@@ -797,3 +797,60 @@ def test_small_ragged_batches_of_long_messages(capy, O, sponge_lanes):
         for i in range(0, n, 13):
             assert got5[i] == O.sha3(msgs[i], 512), lens[i]
             assert gotk[i] == O.kmac_xof(keys[i], msgs[i], 448, b"T", 512), (len(keys[i]), lens[i])
+
+
+@pytest.mark.parametrize("d", [224, 256, 384, 512])
+def test_short_message_kernel_matches_generic_kernel(capy, O, sponge_lanes, d):
+    """Uniform batches of more than 128 items per SIMD whose messages are at most four rate blocks long take
+    sponge_short.h (wave-uniform framing decided by scalar code).  Every digest must equal the generic kernel's
+    (debug bit 7) at the lengths where the framing changes shape -- empty, one byte, word boundaries, r - 1, r, r + 1
+    around every block boundary, the reference's 135 (mod 136) suffix rule -- and the oracle's for sampled items;
+    cSHAKE with a one-block output goes the same way."""
+    import ctypes as C
+
+    import torch
+
+    from capycrypt_amd import _lib
+
+    if sponge_lanes != 1:
+        pytest.skip("sets the kernel choice itself")
+    lib = _lib.lib()
+    r = (1600 - 2 * d) // 8
+    n = 140000
+    lengths = sorted({0, 1, 7, 8, 9, 63, 64, 135, 136, 137, r - 8, r - 1, r, r + 1, 2 * r - 1, 2 * r, 2 * r + 7, 271, 3 * r - 2,
+                      3 * r, 4 * r - 2})
+    for L in lengths:
+        stride = max(8, (L + 7) // 8 * 8)
+        msgs = _dev_rand(n * stride, 100 + L)
+        outs = []
+        for lanes in (0, 128 << 8):
+            _lib.check(lib.capy_set_sponge_lanes(lanes))
+            kind, phases = C.c_int(0), C.c_int(0)
+            _lib.check(lib.capy_sha3_launch_plan(d, n, L, stride, C.byref(kind), C.byref(phases)))
+            assert (kind.value == 7) == (lanes == 0 and L + 1 <= 4 * r), (L, lanes, kind.value)
+            dig = torch.zeros(n * (d // 8), dtype=torch.uint8, device="cuda")
+            _lib.check(lib.capy_sha3_batch_dev(d, n, msgs.data_ptr(), None, L, stride, dig.data_ptr(), None))
+            torch.cuda.synchronize()
+            outs.append(dig)
+        assert torch.equal(outs[0], outs[1]), (d, L)
+        hd = bytes(outs[0].cpu().numpy())
+        for i in (0, 63, 64, n - 1):
+            m = bytes(msgs[i * stride:i * stride + L].cpu().numpy())
+            assert hd[i * (d // 8):(i + 1) * (d // 8)] == O.sha3(m, d), (d, L, i)
+    # cSHAKE (prefix folded into the initial state, suffix 04), output of one rate block at most
+    L, stride = 100, 104
+    msgs = _dev_rand(n * stride, 7)
+    host = bytes(msgs[:4 * stride].cpu().numpy())
+    lbits = 256
+    outs = []
+    for lanes in (0, 128 << 8):
+        _lib.check(lib.capy_set_sponge_lanes(lanes))
+        out = torch.zeros(n * (lbits // 8), dtype=torch.uint8, device="cuda")
+        _lib.check(lib.capy_cshake_batch_dev(d, n, msgs.data_ptr(), None, L, stride, lbits, b"FN", 2, b"custom", 6,
+                                             out.data_ptr(), lbits // 8, None))
+        torch.cuda.synchronize()
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+    ho = bytes(outs[0].cpu().numpy())
+    for i in range(4):
+        assert ho[i * 32:(i + 1) * 32] == O.cshake(host[i * stride:i * stride + L], lbits, b"FN", b"custom", d), (d, i)
