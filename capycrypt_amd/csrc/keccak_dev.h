@@ -158,6 +158,92 @@ __device__ __host__ constexpr uint64_t keccak_rc64(int r)
     return RC[r];
 }
 
+// ---- the round for TWO OR MORE WAVES PER SIMD (profiles/r03_valu_issue_bisect.txt) -------------------------------------
+// Measured on MI355X with one instrument (rocprofv3 --pmc + in-kernel clocks): a SIMD issues a wave64 VALU instruction
+// of the SIMPLE class (v_bitop3_b32, v_xor/and/or/not, v_add/sub_u32, v_lshrrev_b32, v_mov_b32, f32 add/mul/fma) in
+// 2 cycles, so two waves that each issue every 4 cycles share it at full rate -- but every other opcode
+// (v_alignbit_b32, v_lshlrev_b32, DPP moves, every 3-operand integer op but bitop3, all multiplies, all 64-bit ops,
+// carry-out adds) holds the SIMD for 4 cycles, and the arbiter gives the OLDER wave every issue window: a younger
+// wave advances through simple instructions only and stops at its first 4-cycle instruction until the older wave is
+// done.  The keccak round is 122 simple + 58 v_alignbit_b32, so a second wave added nothing (4.0 cycles per
+// instruction at 1, 2, 4, 7 waves per SIMD).  Raising the wave's priority around its 4-cycle blocks lets the younger
+// wave take those windows too: the two waves then overlap their simple blocks two instructions per window and run
+// their rotation blocks one after the other -- (58 + 58 + 122) windows for two rounds instead of 360; measured on a
+// synthetic stream of this shape 2.5 cycles per instruction at two waves per SIMD (1.45x), 2.3 at four.
+// The compiler must not move instructions between the blocks (sched_barrier), and a lone wave pays ~8 % for the four
+// s_setprio, so the launchers take this form only when every SIMD holds at least two waves.
+#ifndef CAPY_PAIRED_PRIO
+#define CAPY_PAIRED_PRIO true  // false: the same blocked round without s_setprio (A/B builds only)
+#endif
+template <bool PRIO>
+__device__ __forceinline__ void keccak_round_blocked(KState &a, uint32_t rc_lo, uint32_t rc_hi)
+{
+    uint32_t cl[5], ch[5], rl[5], rh[5];
+#pragma unroll
+    for (int x = 0; x < 5; x++) {
+        cl[x] = xor3(xor3(a.lo[x], a.lo[x + 5], a.lo[x + 10]), a.lo[x + 15], a.lo[x + 20]);
+        ch[x] = xor3(xor3(a.hi[x], a.hi[x + 5], a.hi[x + 10]), a.hi[x + 15], a.hi[x + 20]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int x = 0; x < 5; x++) rol64c<1>(cl[x], ch[x], rl[x], rh[x]);
+    if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    KState e, b;
+#pragma unroll
+    for (int i = 0; i < 25; i++) {
+        e.lo[i] = xor3(a.lo[i], cl[(i % 5 + 4) % 5], rl[(i % 5 + 1) % 5]);
+        e.hi[i] = xor3(a.hi[i], ch[(i % 5 + 4) % 5], rh[(i % 5 + 1) % 5]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
+    rho_pi_all(e, b, std::make_integer_sequence<int, 25>{});
+    if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int y = 0; y < 5; y++)
+#pragma unroll
+        for (int x = 0; x < 5; x++) {
+            a.lo[x + 5 * y] = chi3(b.lo[x + 5 * y], b.lo[(x + 1) % 5 + 5 * y], b.lo[(x + 2) % 5 + 5 * y]);
+            a.hi[x + 5 * y] = chi3(b.hi[x + 5 * y], b.hi[(x + 1) % 5 + 5 * y], b.hi[(x + 2) % 5 + 5 * y]);
+        }
+    a.lo[0] ^= rc_lo;
+    a.hi[0] ^= rc_hi;
+}
+
+// Fully unrolled, literal round constants (an SGPR operand would turn the iota XOR into a 4-cycle instruction inside a
+// simple block): the form for exactly two waves per SIMD, where nothing but the partner wave hides a scalar load.
+template <bool PRIO, int... Rs>
+__device__ __forceinline__ void keccakf1600_paired_unrolled_impl(KState &a, std::integer_sequence<int, Rs...>)
+{
+    (keccak_round_blocked<PRIO>(a, (uint32_t)keccak_rc64(Rs), (uint32_t)(keccak_rc64(Rs) >> 32)), ...);
+}
+template <bool PRIO>
+__device__ __forceinline__ void keccakf1600_paired_unrolled(KState &a)
+{
+    keccakf1600_paired_unrolled_impl<PRIO>(a, std::make_integer_sequence<int, 24>{});
+}
+
+// Rolled two-round body on the blocked round, constants one trip ahead (the many-waves form of keccakf1600_pipelined).
+template <bool PRIO>
+__device__ __forceinline__ void keccakf1600_paired(KState &a)
+{
+    uint32_t c0 = KECCAK_RC32[0], c1 = KECCAK_RC32[1], c2 = KECCAK_RC32[2], c3 = KECCAK_RC32[3];
+#pragma unroll 1
+    for (int r = 0; r < 24; r += 2) {
+        const int nx = (r + 2 < 24) ? r + 2 : 0;
+        const uint32_t n0 = KECCAK_RC32[2 * nx], n1 = KECCAK_RC32[2 * nx + 1], n2 = KECCAK_RC32[2 * nx + 2],
+                       n3 = KECCAK_RC32[2 * nx + 3];
+        keccak_round_blocked<PRIO>(a, c0, c1);
+        keccak_round_blocked<PRIO>(a, c2, c3);
+        c0 = n0;
+        c1 = n1;
+        c2 = n2;
+        c3 = n3;
+    }
+}
+
 template <int... Rs>
 __device__ __forceinline__ void keccakf1600_unrolled_impl(KState &a, std::integer_sequence<int, Rs...>)
 {

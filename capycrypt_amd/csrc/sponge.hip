@@ -563,6 +563,9 @@ static int launch_sponge(int rw, const SpongeParams &p, hipStream_t s)
     // messages of 0..64 KiB: 16.0 vs 13.6 ms; equal lengths given through offsets: 9.7 vs 8.1 ms)
     else if (p.n > 128 * simds && !(q.debug_flags & 2) && !p2.offsets && !p2.order)  // debug bit 1: A/B switch
         e = launch_sponge_k1_full(rw, (int)p.out_mode, p2, s);
+    // more than one wave on some SIMD: the paired form of the latency-tuned instance (debug bit 8: A/B switch)
+    else if (p.n > 64 * simds && !(q.debug_flags & 256))
+        e = launch_sponge_k1_lat_paired(rw, (int)p.out_mode, p2, s);
     else
         e = launch_sponge_k1_lat(rw, (int)p.out_mode, p2, s);
     if (e == hipErrorInvalidValue) return fail(CAPY_ERR_ARG, "internal: no kernel instance for this rate / mode");
@@ -863,8 +866,10 @@ __global__ __launch_bounds__(64) void keccak_probe_kernel(uint64_t n_states, uin
             keccakf1600_unrolled(a);
         else if (VARIANT == 1)
             keccakf1600(a);
-        else
+        else if (VARIANT == 2)
             keccakf1600_pipelined(a);
+        else
+            keccakf1600_paired<true>(a);
     }
     uint32_t x = 0, y = 0;
 #pragma unroll
@@ -1476,7 +1481,8 @@ int capy_release_workspace(void)
 
 int capy_set_sponge_lanes(int lanes)
 {
-    g_debug_flags.store(((unsigned)lanes >> 8) & 0xff);  // undocumented A/B switches in the high bits
+    // undocumented A/B switches in the high bits; bit 18 of the argument = debug bit 8 (no paired latency-tuned instance)
+    g_debug_flags.store((((unsigned)lanes >> 8) & 0xff) | ((((unsigned)lanes >> 18) & 1) << 8));
     g_fused_enabled.store((((unsigned)lanes >> 16) & 1) == 0);  // bit 16: disable the fused encrypt kernel
     g_mixed_enabled.store((((unsigned)lanes >> 17) & 1) == 0);  // bit 17: disable the mixed one/two-lane schedule
     lanes &= 0xff;
@@ -1515,15 +1521,18 @@ int capy_fill_random_dev(uint8_t *dst, uint64_t nbytes, uint64_t seed, void *str
 int capy_keccak_valu_probe_dev(uint64_t n_states, uint32_t iters, uint64_t *checksum_dev, void *stream)
 {
     if (!n_states) return CAPY_OK;
-    // top two bits of iters select the loop form (0 unrolled = default, 1 rolled, 2 rolled + constant prefetch)
+    // top two bits of iters select the loop form (0 unrolled = default, 1 rolled, 2 rolled + constant prefetch,
+    // 3 the blocked round with raised priority around its rotation blocks: the many-waves form of the kernels)
     const uint32_t variant = iters >> 30, it = iters & 0x3fffffffu;
     const dim3 grid((unsigned)((n_states + 63) / 64));
     if (variant == 0)
         hipLaunchKernelGGL(keccak_probe_kernel<0>, grid, dim3(64), 0, (hipStream_t)stream, n_states, it, checksum_dev);
     else if (variant == 1)
         hipLaunchKernelGGL(keccak_probe_kernel<1>, grid, dim3(64), 0, (hipStream_t)stream, n_states, it, checksum_dev);
-    else
+    else if (variant == 2)
         hipLaunchKernelGGL(keccak_probe_kernel<2>, grid, dim3(64), 0, (hipStream_t)stream, n_states, it, checksum_dev);
+    else
+        hipLaunchKernelGGL(keccak_probe_kernel<3>, grid, dim3(64), 0, (hipStream_t)stream, n_states, it, checksum_dev);
     CAPY_HIP(hipGetLastError());
     return CAPY_OK;
 }

@@ -32,20 +32,26 @@ namespace capy {
 // Measured on MI355X (profiles/r01_keccak_loop_forms.txt): a lone wave hides nothing, so with <= 1 wave per SIMD
 // the fully unrolled permutation with literal round constants wins (905 vs 734..825 GB/s-equivalent at 768
 // waves); with many waves per SIMD the rolled form with constants fetched one trip ahead wins (10.7 vs 9.1 G
-// permutations/s at 16k waves).
-template <bool FULLCHIP>
+// permutations/s at 16k waves).  Since r03 the many-waves form is the BLOCKED round with raised priority around its
+// rotation blocks (keccak_dev.h: keccak_round_blocked): two waves of a SIMD then share it at 2 cycles per simple
+// instruction, 13.9 instead of 9.9 G permutations/s (profiles/r03_valu_issue_bisect.txt).
+// PAIRED (latency-tuned instance only): the launch puts two waves on a SIMD (64 < items per SIMD <= 128, ragged
+// batches of any size): the unrolled permutation on the blocked round.
+template <bool FULLCHIP, bool PAIRED = false>
 __device__ __forceinline__ void keccak_hot(KState &a)
 {
     if constexpr (FULLCHIP)
-        keccakf1600_pipelined(a);
+        keccakf1600_paired<CAPY_PAIRED_PRIO>(a);
+    else if constexpr (PAIRED)
+        keccakf1600_paired_unrolled<CAPY_PAIRED_PRIO>(a);
     else
         keccakf1600_unrolled(a);
 }
-template <bool FULLCHIP>
+template <bool FULLCHIP, bool PAIRED = false>
 __device__ __forceinline__ void keccak_cold(KState &a)
 {
-    if constexpr (FULLCHIP)
-        keccakf1600_pipelined(a);
+    if constexpr (FULLCHIP || PAIRED)
+        keccakf1600_paired<CAPY_PAIRED_PRIO>(a);
     else
         keccakf1600(a);
 }
@@ -58,14 +64,21 @@ __device__ __forceinline__ void xor_word(KState &a, int w, uint64_t v)
 __device__ __forceinline__ uint64_t state_word(const KState &a, int w) { return ((uint64_t)a.hi[w] << 32) | a.lo[w]; }
 
 // register budget: the latency-tuned instance must still fit two waves per SIMD (it serves up to 128 items per SIMD);
-// the issue-tuned instance is held to 128 VGPRs for four.
+// the issue-tuned instance is held to 168 VGPRs for three.
+// r03: three waves (168 VGPRs) since the blocked round pairs the waves of a SIMD: +1.4 / +4.8 / +7 % over four waves at
+// 128 VGPRs on 2^18 x 512 KiB / 2^20 x 4 KiB / 2^21 x 1 KiB, config 2 +4 % (profiles/r03_chipfull.txt)
 #ifndef CAPY_FULLCHIP_WAVES
-#define CAPY_FULLCHIP_WAVES 4
+#define CAPY_FULLCHIP_WAVES 3
 #endif
-// WAVES = waves per SIMD the register budget is sized for (2: latency-tuned, 256 VGPRs; 4: issue-tuned, 128 VGPRs).
+// 1: the issue-tuned instance also keeps the next block in registers under the permutation (A/B, r03: spills at four
+// waves (0.70x), -3 % at three)
+#ifndef CAPY_FULLCHIP_PREFETCH
+#define CAPY_FULLCHIP_PREFETCH 0
+#endif
+// WAVES = waves per SIMD the register budget is sized for (2: latency-tuned, 256 VGPRs; 3: issue-tuned, 168 VGPRs).
 // A 3-wave copy of the issue-tuned instance for ragged batches was tried and dropped: the latency-tuned instance is
 // faster there (see launch_sponge in sponge.hip).
-template <int RW, bool FULLCHIP, int MODE, int WAVES = (FULLCHIP ? CAPY_FULLCHIP_WAVES : 2)>
+template <int RW, bool FULLCHIP, int MODE, int WAVES = (FULLCHIP ? CAPY_FULLCHIP_WAVES : 2), bool PAIRED = false>
 __global__ __launch_bounds__(64, WAVES) void sponge_kernel(const SpongeParams p)
 {
     constexpr uint32_t RB = RW * 8;
@@ -138,7 +151,7 @@ __global__ __launch_bounds__(64, WAVES) void sponge_kernel(const SpongeParams p)
         if (active && b < hb) {
 #pragma unroll
             for (int w = 0; w < RW; w++) xor_word(a, w, stream_word(p, c, (uint64_t)b * RB + 8 * w));
-            keccak_cold<FULLCHIP>(a);
+            keccak_cold<FULLCHIP, PAIRED>(a);
         }
     }
 
@@ -172,13 +185,13 @@ __global__ __launch_bounds__(64, WAVES) void sponge_kernel(const SpongeParams p)
                 // waves per SIMD, but L2 absorbs the re-fetches: +2-4 % uniform, +6-27 % ragged over the
                 // wave-cooperative loads through LDS (profiles/r02_direct_loads_ab.txt)
                 const uint8_t *mine = wave_base + (uint64_t)lane * p.msg_stride;
-                if constexpr (FULLCHIP) {
+                if constexpr (FULLCHIP && !CAPY_FULLCHIP_PREFETCH) {
                     // 128-VGPR budget: no registers held across the permutation, the other waves of the SIMD cover the loads
                     for (uint32_t t = 0; t < nf; t++) {
 #pragma unroll
                         for (int w = 0; w < RW; w++) xor_word(a, w, load_global_u64(mine + 8 * w));
                         mine += RB;
-                        keccak_hot<FULLCHIP>(a);
+                        keccak_hot<FULLCHIP, PAIRED>(a);
                     }
                 } else {
                 uint64_t pf[RW];
@@ -192,7 +205,7 @@ __global__ __launch_bounds__(64, WAVES) void sponge_kernel(const SpongeParams p)
 #pragma unroll
                         for (int w = 0; w < RW; w++) pf[w] = load_global_u64(mine + 8 * w);
                     }
-                    keccak_hot<FULLCHIP>(a);
+                    keccak_hot<FULLCHIP, PAIRED>(a);
                 }
                 }
             } else if constexpr (!FULLCHIP) {
@@ -214,7 +227,7 @@ __global__ __launch_bounds__(64, WAVES) void sponge_kernel(const SpongeParams p)
                     }
 #pragma unroll
                     for (int w = 0; w < RW; w++) xor_word(a, w, wv[w]);
-                    keccak_hot<FULLCHIP>(a);
+                    keccak_hot<FULLCHIP, PAIRED>(a);
                 }
             } else {
                 for (uint32_t t = 0; t < nf; t++) {
@@ -225,7 +238,7 @@ __global__ __launch_bounds__(64, WAVES) void sponge_kernel(const SpongeParams p)
 #pragma unroll
                     for (int w = 0; w < RW; w++) xor_word(a, w, s_stage[lane * RW + w]);
                     __syncthreads();
-                    keccak_hot<FULLCHIP>(a);
+                    keccak_hot<FULLCHIP, PAIRED>(a);
                 }
             }
         }
@@ -253,7 +266,7 @@ __global__ __launch_bounds__(64, WAVES) void sponge_kernel(const SpongeParams p)
                         for (int w = 0; w < RW; w++) xor_word(a, w, pf[w]);
                     }
                     if (t + 1 < max_full) own_load(t + 1);
-                    if (live) keccak_hot<FULLCHIP>(a);
+                    if (live) keccak_hot<FULLCHIP, PAIRED>(a);
                 }
             }
         } else if constexpr (!FULLCHIP) {
@@ -287,7 +300,7 @@ __global__ __launch_bounds__(64, WAVES) void sponge_kernel(const SpongeParams p)
                     if (t < nfull) {
 #pragma unroll
                         for (int w = 0; w < RW; w++) xor_word(a, w, wv[w]);
-                        keccak_hot<FULLCHIP>(a);
+                        keccak_hot<FULLCHIP, PAIRED>(a);
                     }
                 }
             }
@@ -306,7 +319,7 @@ __global__ __launch_bounds__(64, WAVES) void sponge_kernel(const SpongeParams p)
                     for (int w = 0; w < RW; w++) xor_word(a, w, s_stage[lane * RW + w]);
                 }
                 __syncthreads();
-                if (t < nfull) keccak_hot<FULLCHIP>(a);
+                if (t < nfull) keccak_hot<FULLCHIP, PAIRED>(a);
             }
         }
     }
@@ -321,7 +334,7 @@ __global__ __launch_bounds__(64, WAVES) void sponge_kernel(const SpongeParams p)
                 const uint64_t base = (uint64_t)(first + j) * RB;
 #pragma unroll
                 for (int w = 0; w < RW; w++) xor_word(a, w, stream_word(p, c, base + 8 * w));
-                keccak_cold<FULLCHIP>(a);
+                keccak_cold<FULLCHIP, PAIRED>(a);
             }
         }
     }
@@ -355,7 +368,7 @@ __global__ __launch_bounds__(64, WAVES) void sponge_kernel(const SpongeParams p)
                 for (int k = 0; k < RW; k++) *reinterpret_cast<uint64_t *>(bt + ooff[k]) = s_stage[k * 64 + lane];
                 __syncthreads();
                 produced += RB;
-                if (produced < p.out_len) keccak_hot<FULLCHIP>(a);
+                if (produced < p.out_len) keccak_hot<FULLCHIP, PAIRED>(a);
             }
         }
         while (produced < p.out_len) {
@@ -375,7 +388,7 @@ __global__ __launch_bounds__(64, WAVES) void sponge_kernel(const SpongeParams p)
             }
             // the reference permutes once more after the last block (sponge.rs:30); that state is
             // never observable, so the permutation is skipped here.
-            if (produced < p.out_len) keccak_hot<FULLCHIP>(a);
+            if (produced < p.out_len) keccak_hot<FULLCHIP, PAIRED>(a);
         }
     } else {
         // keystream XOR in place: msg[i] ^= squeeze(len); squeeze block = RW words (cSHAKE/KMAC only)
@@ -405,7 +418,7 @@ __global__ __launch_bounds__(64, WAVES) void sponge_kernel(const SpongeParams p)
                         for (int w = 0; w < RW; w++) store_global_u64(bt + 8 * w, pf[w] ^ state_word(a, w));
                     }
                     if (t + 1 < max_x) own_load(t + 1);
-                    if (live && (uint64_t)(t + 1) * RB < tgt_len) keccak_hot<FULLCHIP>(a);
+                    if (live && (uint64_t)(t + 1) * RB < tgt_len) keccak_hot<FULLCHIP, PAIRED>(a);
                 }
             }
         } else if (uniform) {
@@ -427,7 +440,7 @@ __global__ __launch_bounds__(64, WAVES) void sponge_kernel(const SpongeParams p)
 #pragma unroll
                     for (int k = 0; k < RW; k++) *reinterpret_cast<uint64_t *>(bt + voff[k]) = s_stage[k * 64 + lane];
                     __syncthreads();
-                    if ((uint64_t)(t + 1) * RB < tgt_len) keccak_hot<FULLCHIP>(a);
+                    if ((uint64_t)(t + 1) * RB < tgt_len) keccak_hot<FULLCHIP, PAIRED>(a);
                 }
             }
         } else {
@@ -459,7 +472,7 @@ __global__ __launch_bounds__(64, WAVES) void sponge_kernel(const SpongeParams p)
                         store_global_u64(reinterpret_cast<uint8_t *>(s_base[m]) + (uint64_t)t * RB + 8 * w, s_stage[i]);
                 }
                 __syncthreads();
-                if (t < xfull && (uint64_t)(t + 1) * RB < tgt_len) keccak_hot<FULLCHIP>(a);
+                if (t < xfull && (uint64_t)(t + 1) * RB < tgt_len) keccak_hot<FULLCHIP, PAIRED>(a);
             }
         }
         // leftover bytes (unaligned messages: everything) byte-granular
@@ -477,7 +490,7 @@ __global__ __launch_bounds__(64, WAVES) void sponge_kernel(const SpongeParams p)
                         if (pos + 8 * w + b < tgt_len) m[pos + 8 * w + b] ^= (uint8_t)(v >> (8 * b));
                 }
                 pos += RB;
-                if (pos < tgt_len) keccak_cold<FULLCHIP>(a);
+                if (pos < tgt_len) keccak_cold<FULLCHIP, PAIRED>(a);
             }
         }
     }

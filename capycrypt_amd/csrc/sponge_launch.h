@@ -7,6 +7,8 @@
 namespace capy {
 // one lane per sponge, latency-tuned instance (launches that cannot fill the chip)
 hipError_t launch_sponge_k1_lat(int rw, int mode, const SpongeParams &p, hipStream_t s);
+// the same for launches with two waves per SIMD (blocked round, raised priority around the rotation blocks)
+hipError_t launch_sponge_k1_lat_paired(int rw, int mode, const SpongeParams &p, hipStream_t s);
 // one lane per sponge, issue-tuned instance (many waves per SIMD)
 hipError_t launch_sponge_k1_full(int rw, int mode, const SpongeParams &p, hipStream_t s);
 // two lanes per sponge (small batches of long messages)

@@ -63,7 +63,7 @@ __global__ __launch_bounds__(64, 4) void sponge_short_kernel(const SpongeParams 
         const uint64_t base = (uint64_t)b * RB;
 #pragma unroll
         for (int w = 0; w < RW; w++) xor_word(a, w, short_word(msg, base + 8 * w, len, sfx, p.suffix_len, pad80, padded));
-        keccakf1600_pipelined(a);
+        keccakf1600_paired<CAPY_PAIRED_PRIO>(a);
     }
     // one squeeze block at most: out_len <= 8 * sq_words bytes, rows 8-byte aligned (checked by the launcher)
     if (active) {
