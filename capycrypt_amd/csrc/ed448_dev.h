@@ -200,74 +200,15 @@ inline void fe_check_sqr(const Fe &a)
 // 1: Karatsuba multiplication / squaring (default: +5 % variable base, +10 % fixed base on MI355X, because the Ed448
 // kernels are power-limited and a 32x32->64 multiply-add costs more energy than the additions that replace it);
 // 0: the plain 256 / 136-MAD forms (same instruction count within 10 %).
+// r03, tried and dropped (profiles/r03_ed448_forms.txt): the -AA columns accumulated as (-a0[i]) * b0[j] by
+// v_mad_i64_i32 instead of 15 64-bit subtractions (each a v_sub_co / v_subb_co pair plus the s_nop their vcc hazard
+// costs on gfx950).  It needs 36 (multiplication) / 20 (squaring) more multiply-adds and 8-16 negations: 5497 VALU in the
+// doubling loop of vb2_kernel against 5266 + 97 s_nop here, and the optimiser only emits the signed multiply-add when
+// the operands' value ranges are hidden from it (otherwise four instructions each: 23.5 instead of 26.6 M/s).
 #ifndef CAPY_ED448_KARATSUBA
 #define CAPY_ED448_KARATSUBA 1
 #endif
-// Form of the squaring (r03): 0 plain (136 MADs), 1 Karatsuba with 64-bit subtractions of the a0^2 columns (108 MADs,
-// 15 subtractions = 30 carry-pair instructions + the s_nop the v_sub_co -> v_subb_co hazard costs on gfx950),
-// 2 Karatsuba with the a0^2 products ALSO accumulated negatively by v_mad_i64_i32 on negated limbs (128 MADs, no
-// subtraction, 23 instead of 38 column accumulators).  Same switch for the multiplication: CAPY_ED448_MUL_FORM.
-// Measured (profiles/r03_ed448_forms.txt, 2^18 variable-base multiplications): form 1 / 1 (default) 26.6 M/s; plain
-// squaring with Karatsuba multiplication 26.6; form 2 squaring 23.5; form 2 both 21.6; plain squaring with form 2
-// multiplication 24.6 -- fewer instructions but MORE multiplies lose: the kernels are energy-bound (v_mad_u64_u32 on
-// random limbs pulls the clock to 2.04-2.13 GHz at any occupancy, profiles/r03_valu_issue_bisect.txt), so what
-// counts is the number of 32 x 32 multiplies, not the number of issue slots.
-#ifndef CAPY_ED448_SQR_FORM
-#define CAPY_ED448_SQR_FORM CAPY_ED448_KARATSUBA
-#endif
-#ifndef CAPY_ED448_MUL_FORM
-#define CAPY_ED448_MUL_FORM CAPY_ED448_KARATSUBA
-#endif
-// acc += (int64) n * (int64) y on signed 32-bit operands: one v_mad_i64_i32
-CAPY_HD inline void mad_s(uint64_t &acc, uint32_t n, uint32_t y)
-{
-    acc += (uint64_t)((int64_t)(int32_t)n * (int64_t)(int32_t)y);
-}
-#if CAPY_ED448_MUL_FORM == 2
-// Karatsuba without subtractions:  lo[k] = AA[k] + BB[k] + CC[k+8] - AA[k+8]   hi[k] = BB[k+8] + CC[k] + CC[k+8] - AA[k]
-// with every -AA term accumulated as (-a0[i]) * b0[j] by the signed multiply-add.  Limbs are < 2^31 (the Karatsuba
-// operand bound), so a0, b0 and -a0 are exact signed 32-bit values; all sums are mod 2^64 as in the other forms.
-// 100 + 64 + 64 = 228 MADs + 14 additions, 23 column accumulators.
-CAPY_HD CAPY_NOINLINE inline Fe fe_mul(const Fe a, const Fe b)
-{
-    CAPY_FE_CHECK_MUL(a, b);
-    uint32_t as[8], bs[8], na[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        as[j] = a.l[j] + a.l[8 + j];
-        bs[j] = b.l[j] + b.l[8 + j];
-        na[j] = 0u - a.l[j];
-    }
-    uint64_t lo[8], hi[8], cch[7];
-#pragma unroll
-    for (int k = 0; k < 8; k++) lo[k] = hi[k] = 0;
-#pragma unroll
-    for (int k = 0; k < 7; k++) cch[k] = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++)
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const int k = i + j;
-            const uint64_t bb = (uint64_t)a.l[8 + i] * b.l[8 + j], cc = (uint64_t)as[i] * bs[j];
-            if (k < 8) {
-                lo[k] += (uint64_t)a.l[i] * b.l[j];
-                mad_s(hi[k], na[i], b.l[j]);
-                lo[k] += bb;
-                hi[k] += cc;
-            } else {
-                mad_s(lo[k - 8], na[i], b.l[j]);
-                hi[k - 8] += bb;
-                cch[k - 8] += cc;
-            }
-        }
-#pragma unroll
-    for (int k = 0; k < 7; k++) {
-        lo[k] += cch[k];
-        hi[k] += cch[k];
-    }
-    return fe_from_columns(lo, hi);
-}
-#elif CAPY_ED448_MUL_FORM == 1
+#if CAPY_ED448_KARATSUBA
 // Karatsuba over the Goldilocks split: AA = a0 b0, BB = a1 b1, CC = (a0 + a1)(b0 + b1);
 //   lo[k] = AA[k] + BB[k] + CC[k+8] - AA[k+8]      hi[k] = BB[k+8] + CC[k] + CC[k+8] - AA[k]
 // 192 MADs instead of 256, for 16 limb sums, 30 64-bit subtractions and 14 additions: about the same instruction count,
@@ -363,53 +304,7 @@ CAPY_HD CAPY_NOINLINE inline Fe fe_mul(const Fe a, const Fe b)
 
 #endif
 
-#if CAPY_ED448_SQR_FORM == 2
-// r = a^2 mod p, subtraction-free Karatsuba as in fe_mul (form 2): 56 + 36 + 36 = 128 MADs + 14 additions.  The squaring
-// operand bound (limbs < 2^30) keeps 2 a0[i] and -2 a0[i] exact signed 32-bit values.
-CAPY_HD CAPY_NOINLINE inline Fe fe_sqr(const Fe a)
-{
-    CAPY_FE_CHECK_SQR(a);
-    uint32_t as[8], d0[8], d1[8], ds[8], n0[8], nd0[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        as[j] = a.l[j] + a.l[8 + j];  // < 2^31 under the operand bound
-        d0[j] = 2 * a.l[j];
-        d1[j] = 2 * a.l[8 + j];
-        ds[j] = 2 * as[j];
-        n0[j] = 0u - a.l[j];
-        nd0[j] = 0u - d0[j];
-    }
-    uint64_t lo[8], hi[8], cch[7];
-#pragma unroll
-    for (int k = 0; k < 8; k++) lo[k] = hi[k] = 0;
-#pragma unroll
-    for (int k = 0; k < 7; k++) cch[k] = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++)
-#pragma unroll
-        for (int j = i; j < 8; j++) {
-            const int k = i + j;
-            const uint64_t bb = (uint64_t)(i < j ? d1[i] : a.l[8 + i]) * a.l[8 + j];
-            const uint64_t cc = (uint64_t)(i < j ? ds[i] : as[i]) * as[j];
-            if (k < 8) {
-                lo[k] += (uint64_t)(i < j ? d0[i] : a.l[i]) * a.l[j];
-                mad_s(hi[k], i < j ? nd0[i] : n0[i], a.l[j]);
-                lo[k] += bb;
-                hi[k] += cc;
-            } else {
-                mad_s(lo[k - 8], i < j ? nd0[i] : n0[i], a.l[j]);
-                hi[k - 8] += bb;
-                cch[k - 8] += cc;
-            }
-        }
-#pragma unroll
-    for (int k = 0; k < 7; k++) {
-        lo[k] += cch[k];
-        hi[k] += cch[k];
-    }
-    return fe_from_columns(lo, hi);
-}
-#elif CAPY_ED448_SQR_FORM == 1
+#if CAPY_ED448_KARATSUBA
 // r = a^2 mod p, Karatsuba as in fe_mul with AA = a0^2, BB = a1^2, CC = (a0 + a1)^2: 3 x 36 = 108 MADs instead of 136.
 CAPY_HD CAPY_NOINLINE inline Fe fe_sqr(const Fe a)
 {
