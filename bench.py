@@ -36,21 +36,18 @@ VALU_CEIL_GBS = 10.68e9 * 136.0 / 1e9
 VALU_ARCH_CEIL_GBS = 1024 * 2.4e9 / 2 / 4320 * 64 * 136.0 / 1e9
 
 
-DEVICE_HEADERS = ("keccak_dev.h", "sponge_params.h", "sponge_kernels.h", "sponge_kernels_k2.h", "sponge_mixed.h",
-                  "sponge_fused.h", "sponge_wide.h", "ed448_dev.h", "ed448_algo.h")
-
-
 def kernel_source_digest():
-    """sha256 over the headers that hold the DEVICE code of the measured kernels (the sponge kernels and the whole
-    Ed448 arithmetic live in headers; the .hip files add launchers and thin __global__ wrappers): a PMC summary in
-    profiles/ is only used for the kernels it was taken on.  Host-side launch logic is covered by the kernel-name /
-    batch / stride match."""
+    """sha256 over EVERY device source of the library (capycrypt_amd/csrc/*.h and *.hip: the sponge kernels and the whole
+    Ed448 arithmetic live in headers, the .hip files hold launchers and __global__ wrappers): a PMC summary in profiles/
+    is only used for the build it was taken on."""
+    import glob
     import hashlib
 
     h = hashlib.sha256()
-    for name in DEVICE_HEADERS:
-        with open(os.path.join(ROOT, "capycrypt_amd", "csrc", name), "rb") as fh:
-            h.update(name.encode() + b"\0" + fh.read())
+    src = os.path.join(ROOT, "capycrypt_amd", "csrc")
+    for path in sorted(glob.glob(os.path.join(src, "*.h")) + glob.glob(os.path.join(src, "*.hip"))):
+        with open(path, "rb") as fh:
+            h.update(os.path.basename(path).encode() + b"\0" + fh.read())
     return h.hexdigest()[:16]
 
 
@@ -103,6 +100,8 @@ def cpu_baseline(seconds):
     from oracle import oracle as O
 
     lib = O.lib()
+    # the reference's own form of the permutation: in place, four rounds per trip (keccakf.rs:56-422 -> oracle/keccak_inplace.c)
+    O.select_keccak(True)
     rng = random.Random(0xCA9C0001)
     msg = rng.randbytes(MSG_BYTES)
     buf = (C.c_uint8 * MSG_BYTES).from_buffer_copy(msg)
@@ -118,12 +117,11 @@ def cpu_baseline(seconds):
     import hashlib
 
     assert bytes(out) == hashlib.sha3_256(msg).digest()
-    # also the same port over independent messages on the host cores this job may use (the reference
-    # itself is single-threaded on this path; ctypes drops the GIL during the call).  Capped at the box's per-GPU
-    # CPU share.
+    # also the same port over independent messages on ALL host cores this job may use (the reference
+    # itself is single-threaded on this path; ctypes drops the GIL during the call)
     import threading
 
-    nthr = max(1, min(16, len(os.sched_getaffinity(0))))
+    nthr = max(1, len(os.sched_getaffinity(0)))
     counts = [0] * nthr
     span = min(5.0, seconds)
 
@@ -148,11 +146,13 @@ def cpu_baseline(seconds):
         hashlib.sha3_256(msg).digest()
         nlib += 1
     el_lib = time.perf_counter() - t2
+    O.select_keccak(False)
     return {
         "value": n * MSG_BYTES / 2**30 / el,
         "unit": "GiB/s",
         "cores": 1,
         "kind": "port",
+        "what": "C port of the reference's sponge on its in-place four-rounds-per-trip keccak-f (keccakf.rs:56-422), gcc -O3",
         "sample": "%d x 5 MiB SHA3-256 on 1 host thread (%.1f s); host has %d cpus (%s)" % (n, el, os.cpu_count(),
                                                                                             _cpu_model()),
         "multi_thread": {"value": sum(counts) * MSG_BYTES / 2**30 / el_mt, "unit": "GiB/s", "cores": nthr,

@@ -24,11 +24,15 @@ int fail(int code, const std::string &msg);
 struct DevBuf {
     void *p = nullptr;
     size_t bytes = 0;
+    bool secret = false;  // holds key material (passwords, secret scalars, derived keys): zeroed before it is freed
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
     ~DevBuf()
     {
+        // the host-buffer entry points enqueue on the default stream, so the memset runs after their kernels;
+        // hipFree synchronises anyway
+        if (p && secret) (void)hipMemsetAsync(p, 0, bytes, nullptr);
         if (p) (void)hipFree(p);
     }
     hipError_t alloc(size_t n)
@@ -52,6 +56,27 @@ enum WsSlot { WS_PRE = 0, WS_ZPW, WS_ZOFF, WS_KEKA, WS_TAG2, WS_A, WS_B, WS_C, W
 void *workspace(hipStream_t stream, WsSlot slot, size_t bytes);  // nullptr on allocation failure
 void workspace_release();                                           // free this thread's scratch (synchronises)
 void workspace_scrub(hipStream_t stream, WsSlot slot, size_t bytes);  // zero a slot's first bytes, stream-ordered
+// Scrubs the named slots when the enclosing function returns -- on EVERY path, also the early error returns (a failed
+// launch must not leave z || pw, ke || ka, a secret scalar or an ECDH point behind in scratch that later calls reuse).
+struct WsScrubGuard {
+    hipStream_t stream;
+    struct Item {
+        WsSlot slot;
+        size_t bytes;
+    } items[4];
+    int count = 0;
+    explicit WsScrubGuard(hipStream_t s) : stream(s) {}
+    WsScrubGuard(const WsScrubGuard &) = delete;
+    WsScrubGuard &operator=(const WsScrubGuard &) = delete;
+    void add(WsSlot slot, size_t bytes)
+    {
+        if (count < 4) items[count++] = {slot, bytes};
+    }
+    ~WsScrubGuard()
+    {
+        for (int i = 0; i < count; i++) workspace_scrub(stream, items[i].slot, items[i].bytes);
+    }
+};
 
 // Messages of a host batch on the device.  If every message already starts on an 8-byte boundary the
 // packed buffer is copied as is; otherwise it is re-laid out so that every message starts on a

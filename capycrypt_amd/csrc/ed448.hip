@@ -410,8 +410,11 @@ static int derive_s_dev(int d, size_t n, const KeyView &pw, uint8_t *s_be, hipSt
 // Signable::sign, src/ecc/signable.rs:40-57
 static int sign_dev(int d, size_t n, const KeyView &pw, const MsgView &m, uint8_t *h, uint8_t *z, hipStream_t st)
 {
+    WsScrubGuard scrub(st);  // on every return path
     CAPY_WS(s_be, uint8_t *, st, WS_A, n * 56);
+    scrub.add(WS_A, n * 56);  // the secret scalar s
     CAPY_WS(k_be, uint8_t *, st, WS_B, n * 56);
+    scrub.add(WS_B, n * 56);  // the nonce k
     CAPY_WS(U, uint8_t *, st, WS_C, n * 112);
     int rc = derive_s_dev(d, n, pw, s_be, st);
     if (rc) return rc;
@@ -427,8 +430,6 @@ static int sign_dev(int d, size_t n, const KeyView &pw, const MsgView &m, uint8_
     if (rc) return rc;
     hipLaunchKernelGGL(sc_sign_z_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, (uint64_t)n, k_be, h, s_be, z);
     CAPY_HIP(hipGetLastError());
-    workspace_scrub(st, WS_A, n * 56);  // s
-    workspace_scrub(st, WS_B, n * 56);  // k
     return CAPY_OK;
 }
 
@@ -502,9 +503,13 @@ static int pk_keys_dev(int d, size_t n, const uint8_t *W, uint8_t *keka, hipStre
 static int key_encrypt_dev(int d, size_t n, const uint8_t *pubs, const uint8_t *k_rand, const MsgView &m_in, uint8_t *z_xy,
                            uint8_t *tags, hipStream_t st, LateMsgs *late = nullptr)
 {
+    WsScrubGuard scrub(st);  // on every return path
     CAPY_WS(k_be, uint8_t *, st, WS_B, n * 56);
+    scrub.add(WS_B, n * 56);  // the ephemeral scalar k
     CAPY_WS(W, uint8_t *, st, WS_C, n * 112);
+    scrub.add(WS_C, n * 112);  // the shared point W
     CAPY_WS(keka, uint8_t *, st, WS_D, n * 112);
+    scrub.add(WS_D, n * 112);  // ke || ka
     int rc = sc_mul4_launch(n, k_rand, k_be, st);
     if (rc) return rc;
     rc = vb_launch(n, k_be, 56, pubs, 112, W, st);  // W = k*V
@@ -516,20 +521,20 @@ static int key_encrypt_dev(int d, size_t n, const uint8_t *pubs, const uint8_t *
     MsgView m = m_in;
     if (late && (rc = late->upload(m))) return rc;
     // t = kmac_xof(ka, m, 448, "PKA") over the plaintext (:43), then m ^= kmac_xof(ke, "", |m|, "PKE") (:45-46)
-    rc = symmetric_crypt_dev(true, d, n, keka, 56, 112, m, tags, 56, "PKE", "PKA", nullptr, st);
-    workspace_scrub(st, WS_B, n * 56);   // the ephemeral scalar k
-    workspace_scrub(st, WS_C, n * 112);  // the shared point W
-    workspace_scrub(st, WS_D, n * 112);  // ke || ka
-    return rc;
+    return symmetric_crypt_dev(true, d, n, keka, 56, 112, m, tags, 56, "PKE", "PKA", nullptr, st);
 }
 
 // KeyEncryptable::key_decrypt, src/ecc/encryptable.rs:72-94
 static int key_decrypt_dev(int d, size_t n, const KeyView &pw, const uint8_t *z_xy, const MsgView &m_in,
                            const uint8_t *tags, int32_t *status, hipStream_t st, LateMsgs *late = nullptr)
 {
+    WsScrubGuard scrub(st);  // on every return path
     CAPY_WS(s_be, uint8_t *, st, WS_A, n * 56);
+    scrub.add(WS_A, n * 56);  // the secret scalar s
     CAPY_WS(W, uint8_t *, st, WS_C, n * 112);
+    scrub.add(WS_C, n * 112);  // the shared point W
     CAPY_WS(keka, uint8_t *, st, WS_D, n * 112);
+    scrub.add(WS_D, n * 112);  // ke || ka
     int rc = derive_s_dev(d, n, pw, s_be, st);
     if (rc) return rc;
     rc = vb_launch(n, s_be, 56, z_xy, 112, W, st);  // W = s*Z
@@ -539,11 +544,7 @@ static int key_decrypt_dev(int d, size_t n, const KeyView &pw, const uint8_t *z_
     MsgView m = m_in;
     if (late && (rc = late->upload(m))) return rc;
     // candidate plaintext, tag check, restore the ciphertext where the tag failed (:82-93)
-    rc = symmetric_crypt_dev(false, d, n, keka, 56, 112, m, const_cast<uint8_t *>(tags), 56, "PKE", "PKA", status, st);
-    workspace_scrub(st, WS_A, n * 56);   // s
-    workspace_scrub(st, WS_C, n * 112);  // W
-    workspace_scrub(st, WS_D, n * 112);  // ke || ka
-    return rc;
+    return symmetric_crypt_dev(false, d, n, keka, 56, 112, m, const_cast<uint8_t *>(tags), 56, "PKE", "PKA", status, st);
 }
 
 static int up(DevBuf &b, const void *src, size_t bytes)
@@ -644,26 +645,31 @@ int capy_ed448_get_generator(uint8_t *xy)
     return CAPY_OK;
 }
 
+// [4]P = (0, 1): the identity and the points of order 2 and 4 -- useless (and dangerous) as a generator
+static bool pt_order_divides_4(const uint8_t *xy)
+{
+    const Pt q = pt_dbl<true>(pt_dbl<true>(pt_from_affine_bytes(xy)));
+    return fe_is_zero(q.X) && fe_is_zero(fe_sub(q.Y, q.Z));
+}
+
 int capy_ed448_set_generator(const uint8_t *xy)
 {
     if (xy && !pt_validate_bytes(xy)) return fail(CAPY_ERR_ARG, "generator is not a canonical point of the curve");
+    if (xy && pt_order_divides_4(xy)) return fail(CAPY_ERR_ARG, "generator has order 1, 2 or 4");
     std::lock_guard<std::mutex> lk(g_gtab_mu);
     const uint8_t *want = xy ? xy : G_XY;
     if (memcmp(current_generator(), want, 112) == 0) return CAPY_OK;
-    // drop every device's table (built lazily again from the new point); wait for work that may still read it
-    int cur = 0;
-    const bool have_dev = hipGetDevice(&cur) == hipSuccess;
+    // Every device's table is rebuilt lazily from the new point.  The old tables are RETIRED, not freed: a concurrent
+    // call that took the table pointer before this one (ensure_gtab releases the mutex before it launches) may still
+    // have kernels in flight on it.  A retired table (15 MB) stays allocated until the process ends; the generator is
+    // meant to be set once, at start-up.
+    static std::vector<uint32_t *> retired;
     for (int dev = 0; dev < 64; dev++) {
-        if (!g_gtab[dev] && !g_gtab_ct[dev]) continue;
-        if (hipSetDevice(dev) == hipSuccess) {
-            (void)hipDeviceSynchronize();
-            if (g_gtab[dev]) (void)hipFree(g_gtab[dev]);
-            if (g_gtab_ct[dev]) (void)hipFree(g_gtab_ct[dev]);
-        }
+        if (g_gtab[dev]) retired.push_back(g_gtab[dev]);
+        if (g_gtab_ct[dev]) retired.push_back(g_gtab_ct[dev]);
         g_gtab[dev] = nullptr;
         g_gtab_ct[dev] = nullptr;
     }
-    if (have_dev) (void)hipSetDevice(cur);
     memcpy(g_gen_xy, want, 112);
     return CAPY_OK;
 }
@@ -721,10 +727,11 @@ int capy_keypair_batch_dev(int d, size_t n, const uint8_t *pws, size_t pw_len, c
     CAPY_REQUIRE(pub_xy, "pub_xy");
     CAPY_REQUIRE(keys_ok(pws, pw_len, pw_offsets), "pws");
     hipStream_t st = (hipStream_t)stream;
+    WsScrubGuard scrub(st);  // on every return path
     CAPY_WS(s_be, uint8_t *, st, WS_A, n * 56);
+    scrub.add(WS_A, n * 56);  // the secret scalar s
     TRY(derive_s_dev(d, n, dev_keys(pws, pw_len, pw_offsets), s_be, st));
     TRY(fb_launch(n, s_be, pub_xy, st));
-    workspace_scrub(st, WS_A, n * 56);  // the secret scalar s
     return CAPY_OK;
 }
 
@@ -789,6 +796,7 @@ int capy_keypair_batch(int d, size_t n, const uint8_t *pws, size_t pw_len, const
     PackedKeys pw;
     TRY(pw.upload(n, pws, pw_len, pw_offsets));
     DevBuf s, o;
+    s.secret = true;  // the secret scalars: zeroed before the buffer is freed
     CAPY_HIP(s.alloc(n * 56));
     CAPY_HIP(o.alloc(n * 112));
     TRY(derive_s_dev(d, n, pw.view, s.as<uint8_t>(), nullptr));

@@ -438,11 +438,31 @@ static int try_launch_mixed(int rw, const SpongeParams &p, bool forced, hipStrea
 // which kernel launch_sponge() picks: 1 one-lane latency-tuned, 2 two-lane, 3 rotating schedule, 4 one-lane issue-tuned
 // messages of up to this many rate blocks (suffix included) take sponge_short.h when the batch fills the chip
 // (CAPY_SHORT_MAX_BLOCKS overrides; profiles/r02_short_message_kernel.txt)
-static const uint32_t SHORT_MAX_BYTES_PER_RATE = [] {
+static const uint32_t SHORT_MAX_BLOCKS = [] {
     const char *e = getenv("CAPY_SHORT_MAX_BLOCKS");
     const long v = e ? atol(e) : 4;
     return (uint32_t)((v >= 0 && v <= 4096) ? v : 4);
 }();
+
+// The conditions under which launch_sponge() takes the short-message kernel (sponge_short.h) / the wave-per-item digest
+// kernel (sponge_wide.h) -- shared with sponge_plan(), so that capy_sha3_launch_plan reports the kernel that really runs.
+// p.order must already hold the device-side processing order if one is used.
+static bool short_kernel_ok(int rw, const SpongeParams &p, int forced, unsigned dbg, size_t simds)
+{
+    const uint32_t rb = (uint32_t)rw * 8;
+    return forced == 0 && !(dbg & 128) && p.out_mode == 0 && p.absorb_body && p.pre_len == 0 && p.head_len == 0 &&
+           !p.key_offsets && !p.offsets && !p.mask && !p.order && !p.resume_state && !p.head_state && p.stride_bytes == rb &&
+           p.n > 128 * simds && p.uniform_len + p.suffix_len <= SHORT_MAX_BLOCKS * rb && p.msg_stride >= p.uniform_len &&
+           (((uintptr_t)p.msgs | p.msg_stride) & 7) == 0 && p.out_len <= 8 * p.sq_words &&
+           (((uintptr_t)p.out | p.out_stride) & 7) == 0;
+}
+static bool wide_digest_ok(int rw, const SpongeParams &p, int forced, unsigned dbg)
+{
+    const bool shape_ok = p.out_mode == 0 && p.pre_len == 0 && p.stride_bytes == (uint32_t)rw * 8 && !p.resume_state && !p.head_state;
+    const uint64_t max_len = p.offsets ? ~0ULL : p.uniform_len;  // lengths of a ragged device batch are not known here
+    return shape_ok && (((dbg & 32) && p.n <= 4096) ||
+                        (forced == 0 && !(dbg & 16) && p.n <= 2 * wide_max_items() && p.absorb_body && max_len >= 64 * 1024));
+}
 
 static int sponge_plan(int rw, const SpongeParams &p, int *phases)
 {
@@ -451,10 +471,8 @@ static int sponge_plan(int rw, const SpongeParams &p, int *phases)
     *phases = 1;
     MixedPlan m;
     const unsigned dbg = g_debug_flags.load();
-    if (forced == 0 && !(dbg & 16) && !p.offsets && p.n <= 2 * wide_max_items() && p.uniform_len >= 64 * 1024) return 6;
-    if (forced == 0 && !(dbg & 128) && !p.offsets && p.n > 128 * simds && p.head_len == 0 && p.pre_len == 0 &&
-        p.uniform_len + p.suffix_len <= SHORT_MAX_BYTES_PER_RATE * (uint32_t)rw * 8 && ((p.msg_stride | (uintptr_t)p.msgs) & 7) == 0)
-        return 7;
+    if (wide_digest_ok(rw, p, forced, dbg)) return 6;
+    if (short_kernel_ok(rw, p, forced, dbg, simds)) return 7;
     if ((forced == 3 || (forced == 0 && g_mixed_enabled.load())) && mixed_plan(rw, p, forced == 3, m)) {
         *phases = (int)m.P;
         return 3;
@@ -533,14 +551,7 @@ static int launch_sponge(int rw, const SpongeParams &p, hipStream_t s)
     // Many short, equally long, key-less messages (SHA3 / SHAKE / cSHAKE digests of up to one squeeze block): the framing
     // is wave-uniform, sponge_short.h decides it with scalar code.  Debug bit 7: never (A/B and tests).
     {
-        const uint32_t rb = (uint32_t)rw * 8;
-        const bool short_ok = forced == 0 && !(q.debug_flags & 128) && p.out_mode == 0 && p.absorb_body && p.pre_len == 0 &&
-                              p.head_len == 0 && !p.key_offsets && !p.offsets && !p.mask && !p2.order && !p.resume_state &&
-                              !p.head_state && p.stride_bytes == rb && p.n > 128 * simds &&
-                              p.uniform_len + p.suffix_len <= SHORT_MAX_BYTES_PER_RATE * rb && p.msg_stride >= p.uniform_len &&
-                              (((uintptr_t)p.msgs | p.msg_stride) & 7) == 0 && p.out_len <= 8 * p.sq_words &&
-                              (((uintptr_t)p.out | p.out_stride) & 7) == 0;
-        if (short_ok) {
+        if (short_kernel_ok(rw, p2, forced, q.debug_flags, simds)) {
             e = launch_sponge_short(rw, p2, s);
             if (e == hipErrorInvalidValue) return fail(CAPY_ERR_ARG, "internal: no kernel instance for this rate");
             CAPY_HIP(e);
@@ -550,11 +561,7 @@ static int launch_sponge(int rw, const SpongeParams &p, hipStream_t s)
     // Very small digest batches of long messages: one sponge per 25 lanes (sponge_wide.h), 1.3x the two-lane kernel per
     // permutation while every wave has most of a SIMD pair's LDS bandwidth to itself (n / 2 waves <= SIMDs / 2).
     // Debug bit 4 / 5: never / always.
-    const bool wide_ok = p.out_mode == 0 && p.pre_len == 0 && p.stride_bytes == (uint32_t)rw * 8 && !p.resume_state &&
-                         !p.head_state;
-    const uint64_t max_len = p.offsets ? ~0ULL : p.uniform_len;  // lengths of a ragged device batch are not known here
-    if (wide_ok && (((q.debug_flags & 32) && p.n <= 4096) || (forced == 0 && !(q.debug_flags & 16) && p.n <= 2 * wide_max_items() &&
-                                             p.absorb_body && max_len >= 64 * 1024)))
+    if (wide_digest_ok(rw, p2, forced, q.debug_flags))
         e = launch_sponge_wide_digest(rw, p2, s);
     else if (forced == 2 || ((forced == 0 || forced == 3) && p.n <= 32 * simds))
         e = launch_sponge_k2(rw, (int)p.out_mode, p2, s);
@@ -982,7 +989,10 @@ static int sha3_crypt_dev(bool encrypt, int d, size_t n, const KeyView &pw, uint
     if (!valid_d(d)) return fail(CAPY_ERR_UNSUPPORTED_SECPARAM, "unsupported security parameter");
     if (n == 0) return CAPY_OK;
     // z || pw per item (:33-34), then ke||ka = kmac_xof(z||pw, "", 1024, "S") (:36-37)
+    WsScrubGuard scrub(s);  // z || pw and ke || ka are zeroed on the stream however this function returns
     CAPY_WS(keka, uint8_t *, s, WS_KEKA, n * 128);
+    scrub.add(WS_KEKA, n * 128);
+    scrub.add(WS_ZPW, n * 512 + (pw.key_offsets ? pws_bytes : n * pw.key_len));
     MsgView none;
     int rc;
     if (pw.key_offsets) {
@@ -1006,10 +1016,7 @@ static int sha3_crypt_dev(bool encrypt, int d, size_t n, const KeyView &pw, uint
         rc = kmac_launch(d, n, fixed_keys(zpw, zk, zk), none, true, (const uint8_t *)"S", 1, 0, keka, 128, 128, nullptr, s);
     }
     if (rc) return rc;
-    rc = symmetric_crypt_dev(encrypt, d, n, keka, 64, 128, m, tags, 64, ke_custom, ka_custom, status, s);
-    workspace_scrub(s, WS_ZPW, n * 512 + (pw.key_offsets ? pws_bytes : n * pw.key_len));
-    workspace_scrub(s, WS_KEKA, n * 128);
-    return rc;
+    return symmetric_crypt_dev(encrypt, d, n, keka, 64, 128, m, tags, 64, ke_custom, ka_custom, status, s);
 }
 
 // ------------------------------------------------------------------ bulk host <-> device copies
@@ -1111,6 +1118,7 @@ int PackedBatch::download(size_t n, uint8_t *host_msgs, const uint64_t *host_off
 
 int PackedKeys::upload(size_t n, const uint8_t *keys, size_t key_len, const uint64_t *offsets)
 {
+    data.secret = true;  // KMAC keys / passwords: zeroed before the buffer is freed
     if (!offsets) {
         if (key_len > CAPY_MAX_KEY_LEN) return fail(CAPY_ERR_ARG, "key too long");
         total = (uint64_t)n * key_len;
@@ -1503,6 +1511,9 @@ int capy_sha3_launch_plan(int d, size_t n, uint64_t uniform_len, uint64_t msg_st
     p.absorb_body = 1;
     p.suffix_len = 1;  // the SHA3 domain-separation byte
     p.stride_bytes = f.stride;
+    p.sq_words = f.sq_words;  // as sha3_launch() sets them: the kernel-choice predicates read these
+    p.out_len = (uint32_t)(d / 8);
+    p.out_stride = (uint64_t)(d / 8);
     p.n = n;
     *kind = sponge_plan(f.rw, p, phases);
     return CAPY_OK;

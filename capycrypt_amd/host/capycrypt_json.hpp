@@ -60,6 +60,25 @@ class Parser {
         if (peek() != c) throw ParseError(std::string("expected '") + c + "'");
         i++;
     }
+    // exactly four hex digits of a \u escape (std::stoul would accept "+1f " and throw its own exception types)
+    unsigned hex4()
+    {
+        if (i + 4 > s.size()) throw ParseError("bad \\u escape");
+        unsigned v = 0;
+        for (int k = 0; k < 4; k++) {
+            const char c = s[i++];
+            v <<= 4;
+            if (c >= '0' && c <= '9')
+                v |= (unsigned)(c - '0');
+            else if (c >= 'a' && c <= 'f')
+                v |= (unsigned)(c - 'a' + 10);
+            else if (c >= 'A' && c <= 'F')
+                v |= (unsigned)(c - 'A' + 10);
+            else
+                throw ParseError("bad \\u escape");
+        }
+        return v;
+    }
     std::string string_()
     {
         expect('"');
@@ -78,16 +97,28 @@ class Parser {
                 case 'b': out += '\b'; break;
                 case 'f': out += '\f'; break;
                 case 'u': {
-                    if (i + 4 > s.size()) throw ParseError("bad \\u escape");
-                    unsigned cp = (unsigned)std::stoul(s.substr(i, 4), nullptr, 16);
-                    i += 4;
+                    unsigned cp = hex4();
+                    if (cp >= 0xD800 && cp <= 0xDBFF) {  // high surrogate: must be followed by \uDC00..\uDFFF
+                        if (i + 2 > s.size() || s[i] != '\\' || s[i + 1] != 'u') throw ParseError("lone surrogate in \\u escape");
+                        i += 2;
+                        const unsigned lo = hex4();
+                        if (lo < 0xDC00 || lo > 0xDFFF) throw ParseError("lone surrogate in \\u escape");
+                        cp = 0x10000 + ((cp - 0xD800) << 10) + (lo - 0xDC00);
+                    } else if (cp >= 0xDC00 && cp <= 0xDFFF) {
+                        throw ParseError("lone surrogate in \\u escape");
+                    }
                     if (cp < 0x80) {
                         out += (char)cp;
                     } else if (cp < 0x800) {
                         out += (char)(0xC0 | (cp >> 6));
                         out += (char)(0x80 | (cp & 0x3F));
-                    } else {
+                    } else if (cp < 0x10000) {
                         out += (char)(0xE0 | (cp >> 12));
+                        out += (char)(0x80 | ((cp >> 6) & 0x3F));
+                        out += (char)(0x80 | (cp & 0x3F));
+                    } else {
+                        out += (char)(0xF0 | (cp >> 18));
+                        out += (char)(0x80 | ((cp >> 12) & 0x3F));
                         out += (char)(0x80 | ((cp >> 6) & 0x3F));
                         out += (char)(0x80 | (cp & 0x3F));
                     }
@@ -104,8 +135,11 @@ class Parser {
 
   public:
     explicit Parser(const std::string &text) : s(text) {}
-    Ptr value()
+    // Message / KeyPair files nest three levels deep; the reader is recursive, so untrusted input gets a depth limit
+    static constexpr int MAX_DEPTH = 64;
+    Ptr value(int depth = 0)
     {
+        if (depth > MAX_DEPTH) throw ParseError("nesting too deep");
         auto v = std::make_shared<Value>();
         char c = peek();
         if (c == '{') {
@@ -118,7 +152,7 @@ class Parser {
             while (true) {
                 std::string k = (ws(), string_());
                 expect(':');
-                v->members.emplace_back(k, value());
+                v->members.emplace_back(k, value(depth + 1));
                 if (peek() == ',') {
                     i++;
                     continue;
@@ -134,7 +168,7 @@ class Parser {
                 return v;
             }
             while (true) {
-                v->items.push_back(value());
+                v->items.push_back(value(depth + 1));
                 if (peek() == ',') {
                     i++;
                     continue;

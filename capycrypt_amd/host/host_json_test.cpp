@@ -68,6 +68,23 @@ int main(int argc, char **argv)
         EXPECT(false);
     } catch (const json::ParseError &) {
     }
+    // untrusted input: nesting depth is capped, \u escapes need four hex digits, surrogate pairs combine, lone ones fail
+    {
+        std::string deep(100000, '[');
+        try {
+            json::Parser(deep).document();
+            EXPECT(false);
+        } catch (const json::ParseError &) {
+        }
+        for (const char *bad : {"\"\\u12g4\"", "\"\\u+1f4\"", "\"\\ud83d\"", "\"\\ude00\"", "\"\\ud83d\\u0041\"", "\"\\u12\""}) {
+            try {
+                json::Parser(bad).document();
+                EXPECT(false);
+            } catch (const json::ParseError &) {
+            }
+        }
+        EXPECT(json::Parser("\"\\ud83d\\ude00 \\u00e9\"").document()->text == "\xF0\x9F\x98\x80 \xC3\xA9");
+    }
     // KeyPair: to_string_pretty, fields owner, pub_key, priv_key, date_created (src/ecc/keypair.rs:11-22)
     KeyPair k;
     k.owner = "test \"key\"";

@@ -143,9 +143,10 @@ int capy_ed448_scalarmul_batch(size_t n, const uint8_t *scalars_be, const uint8_
 int capy_ed448_scalarmul_batch_dev(size_t n, const uint8_t *scalars_be, const uint8_t *points_xy,
                                    uint8_t *out_xy, void *stream);
 /* The point `ExtendedPoint::generator()` stands for.  Default: the RFC 8032 Ed448 base point -- an ASSUMPTION about the
- * absent curve crate; capy_ed448_set_generator(xy) replaces it (xy must pass the validation below;
- * NULL restores the default) for every later fixed-base multiplication, key pair, signature and ECDHIES call of the
- * process; the per-device fixed-base tables are rebuilt on next use.  Call it while no Ed448 work is in flight. */
+ * absent curve crate; capy_ed448_set_generator(xy) replaces it (xy must pass the validation below
+ * and must not be the identity or a point of order 2 or 4; NULL restores the default) for every later fixed-base
+ * multiplication, key pair, signature and ECDHIES call of the process; the per-device fixed-base tables are rebuilt on
+ * next use.  Calls already in flight finish on the old tables (retired, not freed); meant to be called once at start-up. */
 int capy_ed448_set_generator(const uint8_t *xy);
 int capy_ed448_get_generator(uint8_t *xy);
 /* out_i = [scalar_i] G — `ExtendedPoint::generator() * Scalar`

@@ -12,7 +12,7 @@ _SO = os.path.join(_HERE, "libcapyoracle.so")
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("oracle_sponge.c", "oracle_ed448.c", "capy_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("oracle_sponge.c", "keccak_inplace.c", "oracle_ed448.c", "capy_oracle.h")]
     if force or not os.path.exists(_SO) or any(
         os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs
     ):
@@ -38,10 +38,16 @@ def _buf(b):
     return (C.c_uint8 * max(1, len(b))).from_buffer_copy(bytes(b) if len(b) else b"\0")
 
 
-def keccakf1600(state):
+def keccakf1600(state, inplace=False):
+    """keccak-f[1600]; inplace=True: the reference's in-place four-rounds-per-trip form (keccak_inplace.c)."""
     arr = (C.c_uint64 * 25)(*state)
-    lib().oracle_keccakf1600(arr)
+    (lib().oracle_keccakf1600_inplace if inplace else lib().oracle_keccakf1600)(arr)
     return list(arr)
+
+
+def select_keccak(inplace):
+    """Which form of the permutation the sponge functions run on (see oracle_sponge.c: oracle_select_keccak)."""
+    lib().oracle_select_keccak(1 if inplace else 0)
 
 
 def left_encode(v):

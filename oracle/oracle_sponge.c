@@ -49,6 +49,13 @@ void oracle_keccakf1600(uint64_t a[25])
     }
 }
 
+/* The sponge below runs on either form of the permutation: 0 = the textbook round above (default: what every parity test
+ * checks against), 1 = the in-place four-rounds-per-trip form of keccakf.rs:56-422 (keccak_inplace.c; bench.py's
+ * cpu_baseline times that one, because it is the code the reference actually runs).  Both are checked equal in
+ * tests/test_oracle_sponge.py.  Not thread-safe to switch while other threads hash. */
+static void (*keccak_impl)(uint64_t *) = oracle_keccakf1600;
+void oracle_select_keccak(int inplace) { keccak_impl = inplace ? oracle_keccakf1600_inplace : oracle_keccakf1600; }
+
 /* ------------------------------------------------------------------ growable byte buffer */
 typedef struct {
     uint8_t *p;
@@ -159,7 +166,7 @@ static void bytes_to_state(const uint8_t *in, size_t len, size_t r, uint64_t s[2
             s[w] ^= lane;
             off += 8;
         }
-        oracle_keccakf1600(s);
+        keccak_impl(s);
     }
 }
 
@@ -188,7 +195,7 @@ static void sponge_squeeze(uint64_t s[25], size_t bit_length, size_t rate_bits, 
                 have++;
             }
         produced_bits = have * 8;
-        oracle_keccakf1600(s);
+        keccak_impl(s);
     }
 }
 

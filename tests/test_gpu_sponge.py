@@ -107,6 +107,20 @@ def test_kmac_xof_matches_oracle(capy, O, d):
         assert got == [O.kmac_xof(k, m, lbits, s, d) for k, m in zip(keys, msgs)], (klen, lbits)
 
 
+def test_kmac_for_the_aes_module_callers(capy, O):
+    """SURVEY 8(f) rank 3, literally: the two kmac_xof calls of /root/reference/src/aes/encryptable.rs:38,42 (and
+    :140,145 on the decrypt side) -- key derivation kmac_xof(iv || key, "", 512, "AES", D256) for 16-byte IVs with
+    128/192/256-bit AES keys, then the tag kmac_xof(ka, msg, 512, "AES", D256) over the message -- as one batch each."""
+    rng = random.Random(0xAE5)
+    for keylen in (16, 24, 32):
+        ivkeys = [rng.randbytes(16 + keylen) for _ in LENS]
+        keka = capy.ops.kmac_xof_batch(ivkeys, [b""] * len(LENS), 512, b"AES", 256)
+        assert keka == [O.kmac_xof(k, b"", 512, b"AES", 256) for k in ivkeys]
+        kas = [kk[keylen:] for kk in keka]  # ka = the bytes behind ke (encryptable.rs:40)
+        msgs = [rng.randbytes(n) for n in LENS]
+        assert capy.ops.kmac_xof_batch(kas, msgs, 512, b"AES", 256) == [O.kmac_xof(k, m, 512, b"AES", 256) for k, m in zip(kas, msgs)]
+
+
 @pytest.mark.parametrize("d", [224, 256, 384, 512])
 def test_cshake_matches_oracle(capy, O, d):
     rng = random.Random(200 + d)

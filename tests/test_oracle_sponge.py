@@ -101,6 +101,27 @@ def test_keccakf_zero_state():
     assert st[0] == 0xF1258F7940E1DDE7 and st[24] == 0xEAF1FF7B5CECA249  # XKCP KeccakF-1600-IntermediateValues
 
 
+def test_inplace_keccak_equals_textbook_round():
+    """oracle/keccak_inplace.c (the in-place four-rounds-per-trip form of /root/reference/src/sha3/keccakf.rs:56-422, what
+    bench.py's cpu_baseline times) against the textbook permutation, and the sponge built on either."""
+    import hashlib
+    import random
+
+    rng = random.Random(0x1600)
+    assert O.keccakf1600([0] * 25, inplace=True)[0] == 0xF1258F7940E1DDE7
+    for _ in range(200):
+        st = [rng.getrandbits(64) for _ in range(25)]
+        assert O.keccakf1600(st, inplace=True) == O.keccakf1600(st)
+    O.select_keccak(True)
+    try:
+        for n in (0, 1, 135, 136, 137, 5000):
+            m = rng.randbytes(n)
+            assert O.sha3(m, 256) == hashlib.sha3_256(m).digest()
+            assert O.sha3(m, 512, quirks=0) == hashlib.sha3_512(m).digest()
+    finally:
+        O.select_keccak(False)
+
+
 def _openssl_kmac():
     import json
     import os
