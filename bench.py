@@ -381,7 +381,7 @@ def main():
                 traffic = e["hbm_read_bytes_corrected_x2"] + e.get("hbm_write_bytes", 0.0)
             # the variable-base kernel this run launches: two items per lane from 262 144 pairs (ed448.hip: pair_min_items)
             want = "capy::vb2_kernel" if a.ed448_pairs >= 262144 else "capy::vb_kernel"
-            if k.startswith(want) and "valu_insts_per_wave" in e:
+            if want in k and "valu_insts_per_wave" in e:
                 ed_pmc = (k, e)
 
     # measured VALU ceiling of this box, live: nothing but permutations, 16 waves per SIMD, rolled form with the round

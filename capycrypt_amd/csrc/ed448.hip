@@ -118,6 +118,7 @@ __global__ __launch_bounds__(64, CAPY_ED448_WAVES) void vb2_kernel(uint64_t n, c
     }
 }
 
+template <bool CT>  // CT: gtab is the hardened table
 __global__ __launch_bounds__(64, CAPY_ED448_WAVES) void fb2_kernel(uint64_t n, const uint8_t *scalars_be, uint8_t *out_xy,
                                                  const uint32_t *gtab)
 {
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(64, CAPY_ED448_WAVES) void fb2_kernel(uint64_t n, c
 #pragma unroll 1
     for (int j = 0; j < 2; j++) {
         const uint64_t i = (j == 1 && base + 64 < n) ? base + 64 : base;
-        r = fb_scalarmul(scalars_be + i * 56, gtab);
+        r = CT ? fb_scalarmul_ct(scalars_be + i * 56, gtab) : fb_scalarmul(scalars_be + i * 56, gtab);
         if (j == 0) park_xyz(parked, r);
     }
     const Pt r0 = unpark_xyz(parked);
@@ -221,16 +222,25 @@ static size_t pair_min_items()
     return v;
 }
 
-// Hardened mode (capy_ed448_set_hardened): table reads that do not depend on the scalar.  Variable base: vb_ct_kernel
-// reads all 17 rows of the (lane-interleaved) per-item table per window.  Fixed base: the 12-bit table cannot be read
-// in full per window (2049 rows), so fb_ct_kernel uses a second shared table with 4-bit windows (9 rows, 113 windows).
-static std::atomic<bool> g_hardened{false};
+// Constant-address table lookups (capy_ed448_set_hardened): table reads that do not depend on the scalar.  Variable
+// base: vb_scalarmul_ct reads every row of the (lane-interleaved) per-item table per window.  Fixed base: the 12-bit table
+// cannot be read in full per window (2049 entries), so fb_scalarmul_ct uses a second shared table with 5-bit windows (17
+// entries per row, 90 windows).  Mode bits: 1 = the multiplications by SECRET scalars inside the protocol calls
+// (KeyPair::new, sign, key_encrypt's ephemeral k, key_decrypt) -- ON BY DEFAULT since r03, as the reference's curve
+// crate advertises fixed-time lookups; 2 = also the raw capy_ed448_scalarmul / basemul calls, whose scalars the library
+// cannot classify.  Verification and the table builds work on public data and always take the indexed kernels.
+static std::atomic<int> g_hardened{1};
+static bool harden(bool secret)
+{
+    const int m = g_hardened.load();
+    return (m & 2) || (secret && (m & 1));
+}
 
 // Small batches: one item per WAVE (ed448_wave.h) instead of one per lane -- 7x lower latency for the variable-base
 // and 3.6x for the fixed-base multiplication, worth it while the batch is too small to fill the chip's lanes: the
 // crossover is at ~10 000 items for variable base / double-scalar and ~5 000 for fixed base (profiles/r02_ed448_wave.txt),
-// hence a threshold of 8192 and half of it.  Off in hardened mode.  capy_ed448_set_wave_max() / CAPY_ED448_WAVE_MAX
-// override the threshold (0 = never).
+// hence a threshold of 8192 and half of it; the same thresholds serve the constant-address forms (wave::*<true>).
+// capy_ed448_set_wave_max() / CAPY_ED448_WAVE_MAX override the threshold (0 = never).
 static std::atomic<long> g_wave_max{-1};
 static size_t wave_max_items()
 {
@@ -243,23 +253,35 @@ static size_t wave_max_items()
     return env >= 0 ? (size_t)env : (size_t)CAPY_ED448_WAVE_MAX_DEFAULT;
 }
 
+// secret: the scalars are key material (see harden())
 static int vb_launch(size_t n, const uint8_t *scalars, uint64_t scalar_stride, const uint8_t *points,
-                     uint64_t point_stride, uint8_t *out, hipStream_t s)
+                     uint64_t point_stride, uint8_t *out, hipStream_t s, bool secret)
 {
     if (!n) return CAPY_OK;
-    if (!g_hardened.load() && n <= wave_max_items()) {
-        hipLaunchKernelGGL(wave::vb_wave_kernel, dim3((unsigned)n), dim3(64), 0, s, (uint64_t)n, scalars, scalar_stride, points,
-                           point_stride, out);
+    const bool ct = harden(secret);
+    if (n <= wave_max_items()) {
+        if (ct)
+            hipLaunchKernelGGL(wave::vb_wave_kernel<true>, dim3((unsigned)n), dim3(64), 0, s, (uint64_t)n, scalars, scalar_stride,
+                               points, point_stride, out);
+        else
+            hipLaunchKernelGGL(wave::vb_wave_kernel<false>, dim3((unsigned)n), dim3(64), 0, s, (uint64_t)n, scalars, scalar_stride,
+                               points, point_stride, out);
         CAPY_HIP(hipGetLastError());
         return CAPY_OK;
     }
+    // whole waves: the constant-address table of a wave is interleaved across its 64 lanes
     CAPY_WS(tab, uint32_t *, s, WS_TABLE, (n + 63) / 64 * 64 * VB_TABLE_DWORDS * 4);
-    if (g_hardened.load()) {
+    const dim3 pair_grid((unsigned)((n + 127) / 128));
+    if (ct) {
+        // one item per lane at every size: two items per lane with a shared inversion (vb2_kernel<true>) took 20.7 ms for
+        // 2^18 items against 12.9 ms here (profiles/r03_ed448_hardened.txt) -- at two waves per SIMD the 17-row scans
+        // of the wave-interleaved table have nothing to hide behind
+
         hipLaunchKernelGGL(vb_ct_kernel, grid64(n), dim3(64), 0, s, (uint64_t)n, scalars, scalar_stride, points, point_stride,
                            out, tab);
     } else if (n >= pair_min_items()) {
-        hipLaunchKernelGGL(vb2_kernel, dim3((unsigned)((n + 127) / 128)), dim3(64), 0, s, (uint64_t)n, scalars, scalar_stride,
-                           points, point_stride, out, tab);
+        hipLaunchKernelGGL(vb2_kernel, pair_grid, dim3(64), 0, s, (uint64_t)n, scalars, scalar_stride, points, point_stride,
+                           out, tab);
     } else {
         hipLaunchKernelGGL(vb_kernel, grid64(n), dim3(64), 0, s, (uint64_t)n, scalars, scalar_stride, points, point_stride,
                            out, tab);
@@ -348,26 +370,30 @@ static int ensure_gtab(const uint32_t **out, bool hardened_table = false)
     return CAPY_OK;
 }
 
-static int fb_launch(size_t n, const uint8_t *scalars, uint8_t *out, hipStream_t s)
+static int fb_launch(size_t n, const uint8_t *scalars, uint8_t *out, hipStream_t s, bool secret)
 {
     if (!n) return CAPY_OK;
-    if (g_hardened.load()) {  // every row of a 4-bit-window table is read per window: no address depends on the scalar
-        const uint32_t *gct = nullptr;
-        int rc = ensure_gtab(&gct, true);
-        if (rc) return rc;
-        hipLaunchKernelGGL(fb_ct_kernel, grid64(n), dim3(64), 0, s, (uint64_t)n, scalars, out, gct);
-        CAPY_HIP(hipGetLastError());
-        return CAPY_OK;
-    }
+    const bool ct = harden(secret);
     const uint32_t *gt = nullptr;
-    int rc = ensure_gtab(&gt);
+    // ct: every entry of the window's row of the 5-bit table is read per window: no address depends on the scalar
+    int rc = ensure_gtab(&gt, ct);
     if (rc) return rc;
-    if (n <= wave_max_items() / 2)
-        hipLaunchKernelGGL(wave::fb_wave_kernel, dim3((unsigned)n), dim3(64), 0, s, (uint64_t)n, scalars, out, gt);
-    else if (n >= pair_min_items())
-        hipLaunchKernelGGL(fb2_kernel, dim3((unsigned)((n + 127) / 128)), dim3(64), 0, s, (uint64_t)n, scalars, out, gt);
-    else
+    const dim3 pair_grid((unsigned)((n + 127) / 128));
+    if (n <= wave_max_items() / 2) {
+        if (ct)
+            hipLaunchKernelGGL(wave::fb_wave_kernel<true>, dim3((unsigned)n), dim3(64), 0, s, (uint64_t)n, scalars, out, gt);
+        else
+            hipLaunchKernelGGL(wave::fb_wave_kernel<false>, dim3((unsigned)n), dim3(64), 0, s, (uint64_t)n, scalars, out, gt);
+    } else if (n >= pair_min_items()) {
+        if (ct)
+            hipLaunchKernelGGL(fb2_kernel<true>, pair_grid, dim3(64), 0, s, (uint64_t)n, scalars, out, gt);
+        else
+            hipLaunchKernelGGL(fb2_kernel<false>, pair_grid, dim3(64), 0, s, (uint64_t)n, scalars, out, gt);
+    } else if (ct) {
+        hipLaunchKernelGGL(fb_ct_kernel, grid64(n), dim3(64), 0, s, (uint64_t)n, scalars, out, gt);
+    } else {
         hipLaunchKernelGGL(fb_kernel, grid64(n), dim3(64), 0, s, (uint64_t)n, scalars, out, gt);
+    }
     CAPY_HIP(hipGetLastError());
     return CAPY_OK;
 }
@@ -423,7 +449,7 @@ static int sign_dev(int d, size_t n, const KeyView &pw, const MsgView &m, uint8_
     if (rc) return rc;
     rc = sc_mul4_launch(n, k_be, k_be, st);
     if (rc) return rc;
-    rc = fb_launch(n, k_be, U, st);  // U = k*G, affine
+    rc = fb_launch(n, k_be, U, st, true);  // U = k*G, affine; k is the secret nonce
     if (rc) return rc;
     // h = KMAC(U.x bytes, msg, 448, "T")
     rc = kmac_launch(d, n, fixed_keys(U, 56, 112), m, true, (const uint8_t *)"T", 1, 0, h, 56, 56, nullptr, st);
@@ -512,9 +538,9 @@ static int key_encrypt_dev(int d, size_t n, const uint8_t *pubs, const uint8_t *
     scrub.add(WS_D, n * 112);  // ke || ka
     int rc = sc_mul4_launch(n, k_rand, k_be, st);
     if (rc) return rc;
-    rc = vb_launch(n, k_be, 56, pubs, 112, W, st);  // W = k*V
+    rc = vb_launch(n, k_be, 56, pubs, 112, W, st, true);  // W = k*V; k is the ephemeral secret
     if (rc) return rc;
-    rc = fb_launch(n, k_be, z_xy, st);  // Z = k*G
+    rc = fb_launch(n, k_be, z_xy, st, true);  // Z = k*G
     if (rc) return rc;
     rc = pk_keys_dev(d, n, W, keka, st);
     if (rc) return rc;
@@ -537,7 +563,7 @@ static int key_decrypt_dev(int d, size_t n, const KeyView &pw, const uint8_t *z_
     scrub.add(WS_D, n * 112);  // ke || ka
     int rc = derive_s_dev(d, n, pw, s_be, st);
     if (rc) return rc;
-    rc = vb_launch(n, s_be, 56, z_xy, 112, W, st);  // W = s*Z
+    rc = vb_launch(n, s_be, 56, z_xy, 112, W, st, true);  // W = s*Z; s is the private scalar
     if (rc) return rc;
     rc = pk_keys_dev(d, n, W, keka, st);
     if (rc) return rc;
@@ -576,7 +602,7 @@ int capy_ed448_scalarmul_batch_dev(size_t n, const uint8_t *scalars_be, const ui
                                    void *stream)
 {
     if (n) CAPY_REQUIRE(scalars_be && points_xy && out_xy, "scalars / points / out");
-    return vb_launch(n, scalars_be, 56, points_xy, 112, out_xy, (hipStream_t)stream);
+    return vb_launch(n, scalars_be, 56, points_xy, 112, out_xy, (hipStream_t)stream, false);
 }
 
 int capy_ed448_scalarmul_batch(size_t n, const uint8_t *scalars_be, const uint8_t *points_xy, uint8_t *out_xy)
@@ -588,14 +614,14 @@ int capy_ed448_scalarmul_batch(size_t n, const uint8_t *scalars_be, const uint8_
     TRY(up(s, scalars_be, n * 56));
     TRY(up(p, points_xy, n * 112));
     CAPY_HIP(o.alloc(n * 112));
-    TRY(vb_launch(n, s.as<uint8_t>(), 56, p.as<uint8_t>(), 112, o.as<uint8_t>(), nullptr));
+    TRY(vb_launch(n, s.as<uint8_t>(), 56, p.as<uint8_t>(), 112, o.as<uint8_t>(), nullptr, false));
     return down(out_xy, o, n * 112);
 }
 
 int capy_ed448_basemul_batch_dev(size_t n, const uint8_t *scalars_be, uint8_t *out_xy, void *stream)
 {
     if (n) CAPY_REQUIRE(scalars_be && out_xy, "scalars / out");
-    return fb_launch(n, scalars_be, out_xy, (hipStream_t)stream);
+    return fb_launch(n, scalars_be, out_xy, (hipStream_t)stream, false);
 }
 
 int capy_ed448_basemul_batch(size_t n, const uint8_t *scalars_be, uint8_t *out_xy)
@@ -606,7 +632,7 @@ int capy_ed448_basemul_batch(size_t n, const uint8_t *scalars_be, uint8_t *out_x
     DevBuf s, o;
     TRY(up(s, scalars_be, n * 56));
     CAPY_HIP(o.alloc(n * 112));
-    TRY(fb_launch(n, s.as<uint8_t>(), o.as<uint8_t>(), nullptr));
+    TRY(fb_launch(n, s.as<uint8_t>(), o.as<uint8_t>(), nullptr, false));
     return down(out_xy, o, n * 112);
 }
 
@@ -631,9 +657,10 @@ int capy_ed448_set_wave_max(long max_items)
     return CAPY_OK;
 }
 
-int capy_ed448_set_hardened(int on)
+int capy_ed448_set_hardened(int mode)
 {
-    g_hardened.store(on != 0);
+    if (mode < 0 || mode > 3) return fail(CAPY_ERR_ARG, "mode must be 0 (off), 1 (secret scalars of the protocol calls, default), 2 or 3");
+    g_hardened.store(mode);
     return CAPY_OK;
 }
 
@@ -731,7 +758,7 @@ int capy_keypair_batch_dev(int d, size_t n, const uint8_t *pws, size_t pw_len, c
     CAPY_WS(s_be, uint8_t *, st, WS_A, n * 56);
     scrub.add(WS_A, n * 56);  // the secret scalar s
     TRY(derive_s_dev(d, n, dev_keys(pws, pw_len, pw_offsets), s_be, st));
-    TRY(fb_launch(n, s_be, pub_xy, st));
+    TRY(fb_launch(n, s_be, pub_xy, st, true));  // the private scalar
     return CAPY_OK;
 }
 
@@ -800,7 +827,7 @@ int capy_keypair_batch(int d, size_t n, const uint8_t *pws, size_t pw_len, const
     CAPY_HIP(s.alloc(n * 56));
     CAPY_HIP(o.alloc(n * 112));
     TRY(derive_s_dev(d, n, pw.view, s.as<uint8_t>(), nullptr));
-    TRY(fb_launch(n, s.as<uint8_t>(), o.as<uint8_t>(), nullptr));
+    TRY(fb_launch(n, s.as<uint8_t>(), o.as<uint8_t>(), nullptr, true));  // the private scalar
     return down(pub_xy, o, n * 112);
 }
 

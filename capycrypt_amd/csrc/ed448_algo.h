@@ -93,6 +93,31 @@ constexpr int CT_WBITS = CAPY_ED448_CT_WBITS;
 using CtWin = Win<CT_WBITS>;
 static_assert(CtWin::ENTRIES <= TAB_ENTRIES, "the hardened table lives in the same scratch as the indexed one");
 
+// m with its value hidden from the optimiser: a select written as `hit ? v : x` is turned into a BRANCH around the
+// loads (control flow and addresses would then depend on the secret digit); an opaque mask keeps it arithmetic
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const __attribute__((address_space(4))) uint32_t *CtConstPtr;
+#else
+typedef const uint32_t *CtConstPtr;
+#endif
+// acc | (v & m) in one instruction (v_bitop3_b32, truth table 0xEA; the compiler emits v_and_b32 + v_or_b32 for the C form)
+CAPY_HD inline uint32_t ct_take(uint32_t acc, uint32_t v, uint32_t m)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_bitop3_b32(v, m, acc, 0xEA);
+#else
+    return acc | (v & m);
+#endif
+}
+CAPY_HD inline uint32_t ct_mask(bool hit)
+{
+    uint32_t m = 0u - (uint32_t)hit;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(m));
+#endif
+    return m;
+}
+
 struct CtTable {
     uint32_t *base;   // the wave's table: CtWin::ENTRIES * 64 dwords per lane, interleaved
     uint32_t lane;    // my lane within the wave (0 on the host)
@@ -126,16 +151,16 @@ CAPY_HD inline Pt vb_add_digit_ct(const Pt &acc, const CtTable &t, int digit)
     Fe sel[4] = {fe_zero(), fe_zero(), fe_zero(), fe_zero()};  // X, Y, Z, dT
 #pragma unroll 1
     for (uint32_t j = 0; j < (uint32_t)CtWin::ENTRIES; j++) {
-        const uint32_t m = 0u - (uint32_t)(j == idx);
+        const uint32_t m = ct_mask(j == idx);
 #pragma unroll
         for (int f = 0; f < 4; f++) {
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const uint4 v = *reinterpret_cast<const uint4 *>(t.base + ((size_t)(j * 16 + f * 4 + q) * t.nlanes + t.lane) * 4);
-                sel[f].l[4 * q] |= v.x & m;
-                sel[f].l[4 * q + 1] |= v.y & m;
-                sel[f].l[4 * q + 2] |= v.z & m;
-                sel[f].l[4 * q + 3] |= v.w & m;
+                sel[f].l[4 * q] = ct_take(sel[f].l[4 * q], v.x, m);
+                sel[f].l[4 * q + 1] = ct_take(sel[f].l[4 * q + 1], v.y, m);
+                sel[f].l[4 * q + 2] = ct_take(sel[f].l[4 * q + 2], v.z, m);
+                sel[f].l[4 * q + 3] = ct_take(sel[f].l[4 * q + 3], v.w, m);
             }
         }
     }
@@ -194,30 +219,37 @@ CAPY_HD inline Pt fb_add_digit(const Pt &acc, const uint32_t *gtab, int row, int
     return pt_add_affine_cached(acc, x2, y2, td2);
 }
 
-// Hardened fixed base: a second shared table with FBCT_WBITS-bit signed windows -- few enough rows (9) to read ALL of
-// them per window and keep the wanted one by masking.  The rows are the same for every lane of a wave, so the scan is
-// uniform-address traffic out of the L2; one mixed addition per window (113 of them).
-constexpr int FBCT_WBITS = 4;
+// Hardened fixed base: a second shared table with FBCT_WBITS-bit signed windows -- few enough entries per row to read ALL
+// of them per window and keep the wanted one.  The entries are the same for every lane of a wave, so they arrive by
+// scalar loads (no vector memory traffic, no VGPRs) and each costs one v_bitop3_b32 per limb: 17 x 48 = 816 VALU per
+// window at 5 bits, against ~2650 for the mixed addition that follows.  Windows x (addition + scan) is flat between 5 and
+// 6 bits (90 x 3466 vs 75 x 4234) and worse at 4 (113 x 3082) and 7 (64 x 5770); r02 ran 4 bits with vector loads and
+// AND/OR masking (2 VALU per limb and entry): 3.0x the indexed kernel, now profiles/r03_ed448_hardened.txt.
+#ifndef CAPY_ED448_FBCT_WBITS
+#define CAPY_ED448_FBCT_WBITS 5
+#endif
+constexpr int FBCT_WBITS = CAPY_ED448_FBCT_WBITS;
 using FbCtWin = Win<FBCT_WBITS>;
 constexpr int FBCT_ROWS = FbCtWin::NWIN + 1;
 constexpr int FBCT_ENTRIES = FbCtWin::ENTRIES;
 constexpr int FBCT_TABLE_DWORDS = FBCT_ROWS * FBCT_ENTRIES * FB_ENTRY_DWORDS;
 
-CAPY_HD inline Pt fb_add_digit_ct(const Pt &acc, const uint32_t *gtab, int row, int digit)
+CAPY_HD inline Pt fb_add_digit_ct(const Pt &acc, const uint32_t *__restrict__ gtab, int row, int digit)
 {
     const bool neg = digit < 0;
     const uint32_t idx = (uint32_t)(neg ? -digit : digit);
     Fe x2 = fe_zero(), y2 = fe_zero(), td2 = fe_zero();
 #pragma unroll 1
     for (uint32_t j = 0; j < (uint32_t)FBCT_ENTRIES; j++) {
-        const uint32_t m = 0u - (uint32_t)(j == idx);
-        const uint32_t *e = gtab + ((size_t)row * FBCT_ENTRIES + j) * FB_ENTRY_DWORDS;
-        const Fe x = load_fe(e), y = load_fe(e + 16), t = load_fe(e + 32);
+        const uint32_t m = ct_mask(j == idx);
+        // wave-uniform address; read through the constant address space so that the entry arrives by scalar loads
+        // (s_load_dwordx16 into SGPRs: the table is never written while a kernel that uses it runs)
+        const CtConstPtr e = (CtConstPtr)(gtab + ((size_t)row * FBCT_ENTRIES + j) * FB_ENTRY_DWORDS);
 #pragma unroll
         for (int i = 0; i < 16; i++) {
-            x2.l[i] |= x.l[i] & m;
-            y2.l[i] |= y.l[i] & m;
-            td2.l[i] |= t.l[i] & m;
+            x2.l[i] = ct_take(x2.l[i], e[i], m);
+            y2.l[i] = ct_take(y2.l[i], e[16 + i], m);
+            td2.l[i] = ct_take(td2.l[i], e[32 + i], m);
         }
     }
     x2 = fe_select(neg, x2, fe_neg_nr(x2));

@@ -15,8 +15,11 @@
 //
 // The algorithm is the one of ed448_algo.h step for step (same signed 5-bit windows, same table, same formulas, same
 // fixed-base table), so the outputs are the same field values and hence the same bytes.  Every lane of the wave follows
-// the same control flow; the scalar's digits are wave-uniform.  Not used when capy_ed448_set_hardened(1) is in force
-// (the table row is chosen by a secret digit here as in the indexed batched kernels).
+// the same control flow; the scalar's digits are wave-uniform.  CT = true (r03) is the constant-address form for secret
+// scalars: every row of the LDS table (variable base) / every entry of the window's row of the 5-bit hardened table
+// (fixed base) is read and the wanted one kept by a wave-uniform mask, the sign is applied by masks too -- 17 extra LDS
+// reads per window for the variable base (free next to ~1000 instructions of point arithmetic), 90 instead of 39
+// additions for the fixed base (1.4x, the inversion dominates either way).
 //
 // Device-only (DPP / swizzle builtins); covered by GPU tests that compare it with the batched kernels.
 #pragma once
@@ -258,14 +261,30 @@ __device__ __forceinline__ void wv_build_table(const WC &c, VbTable &t, RV P)
         if (j + 1 < TAB_ENTRIES) acc = wv_add(c, acc, Pc);
     }
 }
+// -(x, y) by masks, no select on the (secret) sign
+__device__ __forceinline__ RV wv_cond_neg_ct(const WC &c, RV Q, bool neg)
+{
+    const uint32_t nm = ct_mask(neg) & (c.r0 | c.r3);  // rows 0 and 3 of a negative digit
+    return (Q & ~nm) | (rv_neg_nr(c, Q) & nm);
+}
+template <bool CT>
 __device__ __forceinline__ RV wv_add_digit(const WC &c, RV acc, const VbTable &t, int digit)
 {
     const bool neg = digit < 0;
     const int idx = neg ? -digit : digit;
-    const RV Q = t.e[idx][threadIdx.x & 63];
-    return wv_add(c, acc, wv_cond_neg(c, Q, neg));
+    const uint32_t lane = threadIdx.x & 63;
+    if constexpr (CT) {
+        RV Q = 0;
+#pragma unroll
+        for (int j = 0; j < TAB_ENTRIES; j++) Q = ct_take(Q, t.e[j][lane], ct_mask(j == idx));
+        return wv_add(c, acc, wv_cond_neg_ct(c, Q, neg));
+    } else {
+        const RV Q = t.e[idx][lane];
+        return wv_add(c, acc, wv_cond_neg(c, Q, neg));
+    }
 }
 // vb_scalarmul
+template <bool CT>
 __device__ __forceinline__ RV wv_scalarmul(const WC &c, const uint8_t *k_be, RV P, VbTable &t)
 {
     wv_build_table(c, t, P);
@@ -274,41 +293,53 @@ __device__ __forceinline__ RV wv_scalarmul(const WC &c, const uint8_t *k_be, RV 
     sc_from_be(k, k_be);
     const uint32_t top = sc_recode_signed<WBITS>(w, k);
     sc_msb_align<WBITS>(w);
-    RV acc = wv_add_digit(c, rv_identity(c), t, (int)top);
+    RV acc = wv_add_digit<CT>(c, rv_identity(c), t, (int)top);
 #pragma unroll 1
     for (int i = 0; i < NWIN; i++) {
 #pragma unroll 1
         for (int j = 0; j < WBITS; j++) acc = wv_dbl(c, acc);
-        acc = wv_add_digit(c, acc, t, sc_next_digit_msb<WBITS>(w));
+        acc = wv_add_digit<CT>(c, acc, t, sc_next_digit_msb<WBITS>(w));
     }
     return acc;
 }
 
-// ---- fixed base: the shared affine table of ed448_algo.h (x, y, d x y per entry, 16 limbs each)
+// ---- fixed base: the shared affine tables of ed448_algo.h (x, y, d x y per entry, 16 limbs each): the 12-bit table
+// indexed by the digit, or (CT) the 5-bit hardened table with every entry of the window's row read
+template <bool CT>
 __device__ __forceinline__ RV wv_fb_add_digit(const WC &c, RV acc, const uint32_t *gtab, int row, int digit)
 {
     const bool neg = digit < 0;
     const int idx = neg ? -digit : digit;
-    const uint32_t *e = gtab + ((size_t)row * FB_TAB_ENTRIES + idx) * FB_ENTRY_DWORDS;
     const uint32_t lane = threadIdx.x & 63, l = lane & 15, r = lane >> 4;
     // rows 0, 1, 3 read x, y, d x y; row 2 is Z2 = 1
-    const uint32_t off = (r == 3 ? 32u : r * 16u) + l;
-    const uint32_t v = e[r == 2 ? l : off];
+    const uint32_t off = r == 2 ? l : (r == 3 ? 32u : r * 16u) + l;
+    uint32_t v;
+    if constexpr (CT) {
+        const uint32_t *e = gtab + (size_t)row * FBCT_ENTRIES * FB_ENTRY_DWORDS + off;
+        v = 0;
+#pragma unroll
+        for (int j = 0; j < FBCT_ENTRIES; j++) v = ct_take(v, e[j * FB_ENTRY_DWORDS], ct_mask(j == idx));
+    } else {
+        v = gtab[((size_t)row * FB_TAB_ENTRIES + idx) * FB_ENTRY_DWORDS + off];
+    }
     const RV Q = (v & ~c.r2) | (c.one & c.r2);
-    return wv_add(c, acc, wv_cond_neg(c, Q, neg));
+    return wv_add(c, acc, CT ? wv_cond_neg_ct(c, Q, neg) : wv_cond_neg(c, Q, neg));
 }
+template <bool CT>
 __device__ __forceinline__ RV wv_fb_accumulate(const WC &c, RV acc, const uint8_t *k_be, const uint32_t *gtab)
 {
+    constexpr int W = CT ? FBCT_WBITS : FB_WBITS;
     uint32_t k[14], w[15];
     sc_from_be(k, k_be);
-    const uint32_t top = sc_recode_signed<FB_WBITS>(w, k);
-    acc = wv_fb_add_digit(c, acc, gtab, FbWin::NWIN, (int)top);
+    const uint32_t top = sc_recode_signed<W>(w, k);
+    acc = wv_fb_add_digit<CT>(c, acc, gtab, Win<W>::NWIN, (int)top);
 #pragma unroll 1
-    for (int i = 0; i < FbWin::NWIN; i++) acc = wv_fb_add_digit(c, acc, gtab, i, sc_next_digit_lsb<FB_WBITS>(w));
+    for (int i = 0; i < Win<W>::NWIN; i++) acc = wv_fb_add_digit<CT>(c, acc, gtab, i, sc_next_digit_lsb<W>(w));
     return acc;
 }
 
 // ---- kernels: grid = n waves
+template <bool CT>
 __global__ __launch_bounds__(64) void vb_wave_kernel(uint64_t n, const uint8_t *scalars_be, uint64_t scalar_stride,
                                                      const uint8_t *points_xy, uint64_t point_stride, uint8_t *out_xy)
 {
@@ -317,16 +348,17 @@ __global__ __launch_bounds__(64) void vb_wave_kernel(uint64_t n, const uint8_t *
     const uint64_t i = blockIdx.x;
     const WC c = wc_init();
     const RV P = wv_from_affine_bytes(c, points_xy + i * point_stride);
-    const RV r = wv_scalarmul(c, scalars_be + i * scalar_stride, P, tab);
+    const RV r = wv_scalarmul<CT>(c, scalars_be + i * scalar_stride, P, tab);
     wv_to_affine_bytes(c, out_xy + i * 112, r, stage);
 }
 
+template <bool CT>  // CT: gtab is the hardened table (FBCT_WBITS-bit windows)
 __global__ __launch_bounds__(64) void fb_wave_kernel(uint64_t n, const uint8_t *scalars_be, uint8_t *out_xy, const uint32_t *gtab)
 {
     __shared__ uint32_t stage[32];
     const uint64_t i = blockIdx.x;
     const WC c = wc_init();
-    const RV r = wv_fb_accumulate(c, rv_identity(c), scalars_be + i * 56, gtab);
+    const RV r = wv_fb_accumulate<CT>(c, rv_identity(c), scalars_be + i * 56, gtab);
     wv_to_affine_bytes(c, out_xy + i * 112, r, stage);
 }
 
@@ -339,8 +371,8 @@ __global__ __launch_bounds__(64) void dsm_wave_kernel(uint64_t n, const uint8_t 
     const uint64_t i = blockIdx.x;
     const WC c = wc_init();
     const RV P = wv_from_affine_bytes(c, points_xy + i * 112);
-    RV r = wv_scalarmul(c, b_be + i * 56, P, tab);
-    r = wv_fb_accumulate(c, r, a_be + i * 56, gtab);
+    RV r = wv_scalarmul<false>(c, b_be + i * 56, P, tab);  // verification: public scalars
+    r = wv_fb_accumulate<false>(c, r, a_be + i * 56, gtab);
     wv_to_affine_bytes(c, out_xy + i * 112, r, stage);
 }
 

@@ -183,9 +183,14 @@ def ed448_validate_batch(points_xy):
     return [status[i] == 0 for i in range(n)]
 
 
-def ed448_set_hardened(on):
-    """Constant-address table lookups for every scalar multiplication (include/capyhip.h: capy_ed448_set_hardened)."""
-    L.check(L.lib().capy_ed448_set_hardened(1 if on else 0))
+def ed448_set_hardened(mode):
+    """Constant-address table lookups (include/capyhip.h: capy_ed448_set_hardened): 0 off, 1 secret scalars of the
+    protocol calls (the default), 3 every scalar multiplication incl. the raw calls; True means 3, False 0."""
+    if mode is True:
+        mode = 3
+    elif mode is False:
+        mode = 0
+    L.check(L.lib().capy_ed448_set_hardened(int(mode)))
 
 
 def ed448_set_generator(xy=None):

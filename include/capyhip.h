@@ -159,15 +159,23 @@ int capy_ed448_add_batch(size_t n, const uint8_t *p_xy, const uint8_t *q_xy, uin
 int capy_ed448_double_scalarmul_batch(size_t n, const uint8_t *a_be, const uint8_t *b_be,
                                       const uint8_t *points_xy, uint8_t *out_xy);
 
-/* Side-channel hardening (process-wide, default off).  By default the window tables of the scalar multiplications are
- * indexed by digits of the scalar: control flow is uniform but the ADDRESS stream depends on the secret (a
- * cache-timing channel on a GPU shared with untrusted tenants; the reference's curve crate advertises fixed-time
- * lookups).  With capy_ed448_set_hardened(1) every scalar multiplication of every entry point -- variable base, fixed
- * base, key pairs, signatures, ECDHIES -- reads its whole 17-row window table per window and keeps the wanted row by
- * masking (fixed base: a second shared table with 4-bit windows, all 9 rows read per window): no address and no branch
- * depends on a scalar.  Results are bit-identical; the cost is measured in profiles/r02_ed448_hardened.txt.
- * (Signable::verify handles public values only and keeps the fast path.) */
-int capy_ed448_set_hardened(int on);
+/* Side-channel hardening: constant-address table lookups (process-wide).  An indexed window table makes the ADDRESS
+ * stream of a scalar multiplication depend on the scalar's digits (control flow is uniform either way): a cache-timing
+ * channel on a GPU shared with untrusted tenants; the reference's curve crate advertises fixed-time lookups
+ * (tests/integration_tests.rs:131-134).  In the constant-address form every row of the window table is read per window
+ * and the wanted one kept by masking (variable base: the 17-row per-item table, 4-bit windows in the batched kernels;
+ * fixed base: a second shared table with 5-bit windows, 17 entries read per window by scalar loads); the sign is applied
+ * by masks; no address and no branch depends on a scalar.  Results are bit-identical with the indexed kernels.
+ *   mode 1 (DEFAULT since r03): the multiplications by SECRET scalars inside the protocol calls -- capy_keypair_*,
+ *          capy_schnorr_sign_* (the nonce k), capy_key_encrypt_* (the ephemeral k, both multiplications),
+ *          capy_key_decrypt_* (the private scalar) -- at every batch size (the one-item-per-wave kernels have
+ *          constant-address forms too).  Verification and the raw capy_ed448_scalarmul / basemul calls, whose scalars
+ *          the library takes to be public, keep the indexed kernels.
+ *   mode 3: also the raw scalarmul / basemul calls (for callers that pass secrets through them).
+ *   mode 0: indexed kernels everywhere (benchmarks; single-tenant devices).   mode 2: raw calls only.
+ * Cost (profiles/r03_ed448_hardened.txt): variable base 1.3x, fixed base 2.3x (90 additions instead of 39: a table that
+ * must be read in full cannot have 12-bit windows), sign / key pair accordingly. */
+int capy_ed448_set_hardened(int mode);
 
 /* Tuning / A-B switch (process-wide): batches of up to max_items scalar multiplications take the one-item-per-wave
  * kernels (csrc/ed448_wave.h: a field element spread over 16 lanes, the four coordinates of a point in the four rows of

@@ -575,9 +575,11 @@ def test_generator_can_be_replaced(capy, O):
 
 
 def test_hardened_mode_is_bit_identical(capy, O):
-    """capy_ed448_set_hardened(1): every scalar multiplication reads its whole window table per window (no address
-    depends on a scalar); fixed-base multiplications become variable-base multiplications of the generator.  Every
-    result must equal the default mode's and the oracle's: raw operations, key pairs, signatures, ECDHIES."""
+    """capy_ed448_set_hardened: mode 1 (the default) runs the multiplications by secret scalars inside the protocol calls
+    on the constant-address kernels (every row of the window table read per window, no address depends on a scalar),
+    mode 3 the raw multiplications as well, mode 0 none.  Every result must be the same in all three and equal the
+    oracle's: raw operations, key pairs, signatures, ECDHIES -- with the one-item-per-wave kernels and without (the
+    autouse fixture), i.e. through wave::*<true> and vb_ct / fb_ct (fb2_kernel<true>: test_hardened_pair_kernels_match)."""
     rng = random.Random(0xC7)
     n = 130
     ks = [rng.randbytes(56) for _ in range(n)]
@@ -595,16 +597,62 @@ def test_hardened_mode_is_bit_identical(capy, O):
         r["dec"] = capy.ops.key_decrypt_batch(pws, z, c, t, 512)
         return r
 
-    plain = run()
     try:
-        capy.ops.ed448_set_hardened(True)
+        capy.ops.ed448_set_hardened(0)
+        plain = run()
+        capy.ops.ed448_set_hardened(1)
+        default = run()
+        capy.ops.ed448_set_hardened(3)
         hard = run()
     finally:
-        capy.ops.ed448_set_hardened(False)
+        capy.ops.ed448_set_hardened(1)
     for k in plain:
         assert hard[k] == plain[k], k
+        assert default[k] == plain[k], k
     assert plain["vb"] == [O.ed448_scalarmul(k, p) for k, p in zip(ks, pts)]
     assert plain["fb"] == [O.ed448_basemul(k) for k in ks] and all(plain["ver"]) and all(plain["dec"][1])
+
+
+def test_hardened_pair_kernels_match(capy, O, ed448_kernel_family):
+    """The kernels of batches from 262 144 items: two items per lane sharing one inversion (vb2_kernel, fb2_kernel<false>)
+    against their constant-address counterparts (vb_ct_kernel, fb2_kernel<true>).  CAPY_ED448_PAIR cannot be switched at
+    run time, so a batch of the real threshold size (with a ragged last wave) runs once in mode 0 and once in mode 3 and
+    must agree item by item; a sample is checked against the oracle."""
+    import ctypes as C
+
+    from capycrypt_amd import _lib
+
+    if ed448_kernel_family != -1:
+        pytest.skip("batch size is far above the wave-kernel threshold either way")
+    import torch
+
+    lib = _lib.lib()
+    n = (1 << 18) + 70  # ragged last wave of 128
+    dev = torch.device("cuda", 0)
+    sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    sc = torch.empty(n * 56, dtype=torch.uint8, device=dev)
+    tsc = torch.empty(n * 56, dtype=torch.uint8, device=dev)
+    _lib.check(lib.capy_fill_random_dev(sc.data_ptr(), n * 56, 71, sp))
+    _lib.check(lib.capy_fill_random_dev(tsc.data_ptr(), n * 56, 72, sp))
+    pts = torch.empty(n * 112, dtype=torch.uint8, device=dev)
+    outs = {}
+    try:
+        for mode in (0, 3):
+            capy.ops.ed448_set_hardened(mode)
+            if mode == 0:
+                _lib.check(lib.capy_ed448_basemul_batch_dev(n, tsc.data_ptr(), pts.data_ptr(), sp))
+            vb = torch.empty(n * 112, dtype=torch.uint8, device=dev)
+            fb = torch.empty(n * 112, dtype=torch.uint8, device=dev)
+            _lib.check(lib.capy_ed448_scalarmul_batch_dev(n, sc.data_ptr(), pts.data_ptr(), vb.data_ptr(), sp))
+            _lib.check(lib.capy_ed448_basemul_batch_dev(n, sc.data_ptr(), fb.data_ptr(), sp))
+            torch.cuda.synchronize()
+            outs[mode] = (vb, fb)
+    finally:
+        capy.ops.ed448_set_hardened(1)
+    assert torch.equal(outs[0][0], outs[3][0]) and torch.equal(outs[0][1], outs[3][1])
+    sch, pth, vbh = bytes(sc.cpu().numpy()), bytes(pts.cpu().numpy()), bytes(outs[3][0].cpu().numpy())
+    for i in (0, 63, 64, 127, 128, n - 71, n - 1):
+        assert vbh[112 * i:112 * i + 112] == O.ed448_scalarmul(sch[56 * i:56 * i + 56], pth[112 * i:112 * i + 112]), i
 
 
 def test_many_forms_of_the_python_mirror(capy, O):
@@ -659,16 +707,24 @@ def test_wave_kernels_equal_lane_kernels_on_edge_cases(capy, O, ed448_kernel_fam
     order2 = (0).to_bytes(56, "little") + (p - 1).to_bytes(56, "little")
     pts[3], pts[4], pts[5] = ident, order2, (5).to_bytes(56, "little") + (7).to_bytes(56, "little")
     results = []
-    for wmax in (0, 1 << 20):
-        _lib.check(lib.capy_ed448_set_wave_max(wmax))
-        vb = capy.ops.ed448_scalarmul_batch(kb, pts)
-        fb = capy.ops.ed448_basemul_batch(kb)
-        out = (C.c_uint8 * (n * 112))()
-        _lib.check(lib.capy_ed448_double_scalarmul_batch(n, b"".join(kb[::-1]), b"".join(kb), b"".join(pts), out))
-        results.append((vb, fb, bytes(out)))
-    assert results[0][0] == results[1][0]
-    assert results[0][1] == results[1][1]
-    assert results[0][2] == results[1][2]
+    try:
+        for wmax, mode in ((0, 0), (1 << 20, 0), (0, 3), (1 << 20, 3)):  # lane / wave kernels, indexed / constant-address
+            _lib.check(lib.capy_ed448_set_wave_max(wmax))
+            capy.ops.ed448_set_hardened(mode)
+            vb = capy.ops.ed448_scalarmul_batch(kb, pts)
+            fb = capy.ops.ed448_basemul_batch(kb)
+            out = (C.c_uint8 * (n * 112))()
+            _lib.check(lib.capy_ed448_double_scalarmul_batch(n, b"".join(kb[::-1]), b"".join(kb), b"".join(pts), out))
+            results.append((vb, fb, bytes(out)))
+    finally:
+        capy.ops.ed448_set_hardened(1)
+    for idx, other in enumerate(results[1:]):
+        # the constant-address lane kernel uses 4-bit windows: a different operation sequence, which must agree on the
+        # curve only -- the non-curve point (item 5) is compared between the two indexed families alone
+        keep = [i for i in range(n) if idx == 0 or i != 5]
+        assert [results[0][0][i] for i in keep] == [other[0][i] for i in keep]
+        assert results[0][1] == other[1]
+        assert [results[0][2][112 * i:112 * i + 112] for i in keep] == [other[2][112 * i:112 * i + 112] for i in keep]
     for i in (0, 1, 3, 6, 11, n - 1):
         assert results[1][0][i] == O.ed448_scalarmul(kb[i], pts[i]), i
         assert results[1][1][i] == O.ed448_basemul(kb[i]), i

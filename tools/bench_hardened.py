@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Cost of capy_ed448_set_hardened(1): variable-base / fixed-base multiplication, key pair, sign at 2^16 and 2^18 items,
-default vs hardened.  Run on the GPU box: python tools/bench_hardened.py > gpurun_out/r02_ed448_hardened.txt"""
+"""Cost of the constant-address table lookups (capy_ed448_set_hardened): variable-base / fixed-base multiplication, key
+pair, sign from one item to 2^18, mode 0 (indexed) vs mode 3 (constant-address everywhere; mode 1, the default, covers
+key pair and sign).  Run on the GPU box: python tools/bench_hardened.py > gpurun_out/r03_ed448_hardened.txt"""
 import ctypes as C
 import os
 import sys
@@ -34,8 +35,8 @@ def timed(fn, reps=3):
     return e0.elapsed_time(e1) / reps
 
 
-print("# ms per call, default | hardened | ratio   (1 KiB messages for sign)")
-for n in (1 << 16, 1 << 18):
+print("# ms per call, indexed (mode 0) | constant-address (mode 3) | ratio   (1 KiB messages for sign)")
+for n in (1, 64, 2048, 1 << 14, 1 << 16, 1 << 18):
     sc, tsc = rand(n * 56, 1), rand(n * 56, 2)
     pts = torch.empty(n * 112, dtype=torch.uint8, device=dev)
     out = torch.empty(n * 112, dtype=torch.uint8, device=dev)
@@ -53,8 +54,8 @@ for n in (1 << 16, 1 << 18):
         _lib.check(lib.capy_ed448_set_hardened(0))
         a = timed(fn)
         ref = (out.clone(), h.clone(), z.clone())
-        _lib.check(lib.capy_ed448_set_hardened(1))
+        _lib.check(lib.capy_ed448_set_hardened(3))
         b = timed(fn)
         same = torch.equal(ref[0], out) and torch.equal(ref[1], h) and torch.equal(ref[2], z)
-        _lib.check(lib.capy_ed448_set_hardened(0))
+        _lib.check(lib.capy_ed448_set_hardened(1))
         print("n=%7d %-14s %9.3f | %9.3f | %5.2fx  %s" % (n, name, a, b, b / a, "identical" if same else "MISMATCH"), flush=True)
