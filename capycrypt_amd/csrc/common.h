@@ -20,25 +20,31 @@ int fail(int code, const std::string &msg);
             return capy::fail(CAPY_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));           \
     } while (0)
 
-// RAII device allocation for the host-pointer entry points.
+// RAII device allocation for the host-pointer entry points, served from a per-thread cache of blocks (sponge.hip:
+// devbuf_take / devbuf_give) so that repeated calls neither allocate nor free (= synchronise).
+void *devbuf_take(size_t bytes, size_t *cap);  // nullptr on allocation failure
+void devbuf_give(void *p, size_t cap);
 struct DevBuf {
     void *p = nullptr;
-    size_t bytes = 0;
-    bool secret = false;  // holds key material (passwords, secret scalars, derived keys): zeroed before it is freed
+    size_t bytes = 0;  // requested size
+    size_t cap = 0;    // size of the block behind it
+    bool secret = false;  // holds key material (passwords, secret scalars, derived keys): zeroed before it is reused
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
     ~DevBuf()
     {
-        // the host-buffer entry points enqueue on the default stream, so the memset runs after their kernels;
-        // hipFree synchronises anyway
-        if (p && secret) (void)hipMemsetAsync(p, 0, bytes, nullptr);
-        if (p) (void)hipFree(p);
+        if (!p) return;
+        // the host-buffer entry points enqueue on the default stream, so the memset runs after their kernels and
+        // before any later user of the block
+        if (secret) (void)hipMemsetAsync(p, 0, bytes, nullptr);
+        devbuf_give(p, cap);
     }
     hipError_t alloc(size_t n)
     {
         bytes = n ? n : 8;
-        return hipMalloc(&p, bytes);
+        p = devbuf_take(bytes, &cap);
+        return p ? hipSuccess : hipErrorOutOfMemory;
     }
     template <class T>
     T *as() const

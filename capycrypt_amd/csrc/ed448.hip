@@ -852,6 +852,13 @@ int capy_schnorr_sign_batch(int d, size_t n, const uint8_t *pws, size_t pw_len, 
     return down(z_be, dz, n * 56);
 }
 
+// Declared after the DevBufs of a host-buffer entry point that launches on the side stream: whatever path the function
+// leaves by, the side stream has drained before the buffers go back to the per-thread cache (common.h: DevBuf).
+struct SideStreamDrain {
+    hipStream_t s;
+    ~SideStreamDrain() { (void)hipStreamSynchronize(s); }
+};
+
 int capy_schnorr_verify_batch(int d, size_t n, const uint8_t *pub_xy, const uint8_t *msgs, const uint64_t *offsets,
                               const uint8_t *h, const uint8_t *z_be, int32_t *status)
 {
@@ -868,6 +875,7 @@ int capy_schnorr_verify_batch(int d, size_t n, const uint8_t *pub_xy, const uint
     TRY(up(dz, z_be, n * 56));
     CAPY_HIP(st.alloc(n * 4));
     hipStream_t side = side_stream();
+    SideStreamDrain drain{side};
     TRY(verify_dev(d, n, pk.as<uint8_t>(), MsgView(), dh.as<uint8_t>(), dz.as<uint8_t>(), st.as<int32_t>(), side, &late));
     CAPY_HIP(hipStreamSynchronize(side));
     return down(status, st, n * 4);
@@ -889,6 +897,7 @@ int capy_key_encrypt_batch(int d, size_t n, const uint8_t *pub_xy, const uint8_t
     CAPY_HIP(dz.alloc(n * 112));
     CAPY_HIP(dt.alloc(n * 56));
     hipStream_t side = side_stream();
+    SideStreamDrain drain{side};
     TRY(key_encrypt_dev(d, n, pk.as<uint8_t>(), kr.as<uint8_t>(), MsgView(), dz.as<uint8_t>(), dt.as<uint8_t>(), side, &late));
     CAPY_HIP(hipStreamSynchronize(side));
     TRY(b.download(n, msgs, offsets));
@@ -914,6 +923,7 @@ int capy_key_decrypt_batch(int d, size_t n, const uint8_t *pws, size_t pw_len, c
     TRY(up(dt, tags, n * 56));
     CAPY_HIP(st.alloc(n * 4));
     hipStream_t side = side_stream();
+    SideStreamDrain drain{side};
     TRY(key_decrypt_dev(d, n, pw.view, dz.as<uint8_t>(), MsgView(), dt.as<uint8_t>(), st.as<int32_t>(), side, &late));
     CAPY_HIP(hipStreamSynchronize(side));
     TRY(b.download(n, msgs, offsets));

@@ -4,8 +4,12 @@
 #include <string.h>
 #include <algorithm>
 #include <atomic>
+#include <ctype.h>
+#include <condition_variable>
+#include <memory>
 #include <mutex>
 #include <thread>
+#include <sched.h>
 #include "common.h"
 #include "sponge_launch.h"
 #include "sponge_fused.h"
@@ -58,42 +62,170 @@ static std::vector<size_t> shard_bounds(size_t n, size_t world, const uint64_t *
     return b;
 }
 
+// ---- persistent workers (r03).  One long-lived host thread per position of the device list: it selects its device
+// once, pins itself to the CPUs the device is attached to (/sys/bus/pci/devices/<bdf>/local_cpulist -- SURVEY 8(e) names
+// NUMA placement of the staging as the scaling risk), and keeps its thread-local scratch pools and device-buffer cache
+// (workspace(), DevBuf) from call to call.  r02 spawned fresh std::threads per call: every sharded call re-allocated
+// its pools and freed them (a device synchronisation each) at thread exit.  Sharded calls from several host threads
+// take turns (one pool).
+namespace {
+// "0-15,128-143" -> CPU set; empty on any parse problem
+static bool parse_cpulist(const char *text, cpu_set_t *set)
+{
+    CPU_ZERO(set);
+    int any = 0;
+    const char *q = text;
+    while (*q) {
+        char *end = nullptr;
+        long a = strtol(q, &end, 10);
+        if (end == q) break;
+        long b = a;
+        q = end;
+        if (*q == '-') {
+            b = strtol(q + 1, &end, 10);
+            if (end == q + 1) return false;
+            q = end;
+        }
+        for (long c = a; c <= b && c < CPU_SETSIZE; c++) {
+            CPU_SET((int)c, set);
+            any++;
+        }
+        while (*q == ',' || *q == '\n' || *q == ' ') q++;
+    }
+    return any > 0;
+}
+static void pin_to_device_cpus(int device)
+{
+    if (getenv("CAPY_NO_WORKER_AFFINITY")) return;
+    char bdf[64] = {0};
+    if (hipDeviceGetPCIBusId(bdf, sizeof bdf, device) != hipSuccess) {
+        (void)hipGetLastError();
+        return;
+    }
+    for (char *c = bdf; *c; c++) *c = (char)tolower(*c);
+    const std::string path = std::string("/sys/bus/pci/devices/") + bdf + "/local_cpulist";
+    FILE *f = fopen(path.c_str(), "r");
+    if (!f) return;
+    char line[4096] = {0};
+    const bool ok = fgets(line, sizeof line, f) != nullptr;
+    fclose(f);
+    cpu_set_t want, have, both;
+    if (!ok || !parse_cpulist(line, &want) || sched_getaffinity(0, sizeof have, &have) != 0) return;
+    CPU_AND(&both, &want, &have);  // never leave the CPUs this process may use (containers)
+    if (CPU_COUNT(&both) > 0) (void)sched_setaffinity(0, sizeof both, &both);
+}
+
+struct Worker {
+    int device = 0;
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::function<void()> job;
+    bool has_job = false, done = false, quit = false;
+    void loop()
+    {
+        g_in_shard = true;  // a worker never shards again: its body is the single-device form of the entry point
+        const bool dev_ok = hipSetDevice(device) == hipSuccess;
+        if (!dev_ok) (void)hipGetLastError();
+        pin_to_device_cpus(device);
+        std::unique_lock<std::mutex> lk(mu);
+        while (true) {
+            cv.wait(lk, [&] { return has_job || quit; });
+            if (quit) break;
+            lk.unlock();
+            job();
+            lk.lock();
+            has_job = false;
+            done = true;
+            cv.notify_all();
+        }
+        lk.unlock();
+        workspace_release();  // on this thread: its scratch pools and buffer cache
+    }
+    void submit(std::function<void()> f)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        job = std::move(f);
+        has_job = true;
+        done = false;
+        cv.notify_all();
+    }
+    void wait()
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return done; });
+    }
+    void stop()
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            quit = true;
+            cv.notify_all();
+        }
+        if (th.joinable()) th.join();
+    }
+};
+struct WorkerPool {
+    std::mutex mu;  // one sharded call at a time
+    std::vector<int> ids;
+    std::vector<std::unique_ptr<Worker>> workers;
+    void reset(const std::vector<int> &want)
+    {
+        for (auto &w : workers) w->stop();
+        workers.clear();
+        ids = want;
+        for (int id : want) {
+            workers.emplace_back(new Worker);
+            Worker *w = workers.back().get();
+            w->device = id;
+            w->th = std::thread([w] { w->loop(); });
+        }
+    }
+    ~WorkerPool()
+    {
+        // process exit: the HIP runtime may already be shutting down; let the workers end without touching it
+        for (auto &w : workers) {
+            {
+                std::lock_guard<std::mutex> lk(w->mu);
+                w->quit = true;
+                w->cv.notify_all();
+            }
+            if (w->th.joinable()) w->th.detach();
+            (void)w.release();  // the detached thread may still look at its Worker
+        }
+    }
+};
+static WorkerPool g_pool;
+}  // namespace
+
 int run_sharded(const std::vector<int> &ids, size_t n, const uint64_t *byte_offsets,
                 const std::function<int(size_t, size_t)> &body)
 {
     const size_t world = ids.size();
-    if (world == 1) {  // one device: no worker thread, just run there
-        int cur = 0;
-        const bool have = hipGetDevice(&cur) == hipSuccess;
-        if (hipSetDevice(ids[0]) != hipSuccess) {
-            (void)hipGetLastError();
-            return fail(CAPY_ERR_HIP, "hipSetDevice(" + std::to_string(ids[0]) + ") failed");
-        }
-        g_in_shard = true;
-        const int rc = body(0, n);
-        g_in_shard = false;
-        if (have) (void)hipSetDevice(cur);
-        return rc;
-    }
+    std::lock_guard<std::mutex> pool_lock(g_pool.mu);
+    if (g_pool.ids != ids) g_pool.reset(ids);  // first call after capy_set_devices (or a changed list)
     const std::vector<size_t> b = shard_bounds(n, world, byte_offsets);
     std::vector<int> rcs(world, CAPY_OK);
     std::vector<std::string> errs(world);
-    auto work = [&](size_t r) {
-        g_in_shard = true;
-        if (hipSetDevice(ids[r]) != hipSuccess) {
-            rcs[r] = CAPY_ERR_HIP;
-            errs[r] = "hipSetDevice(" + std::to_string(ids[r]) + ") failed";
-            (void)hipGetLastError();
-        } else {
+    std::vector<size_t> used;
+    for (size_t r = 0; r < world; r++) {
+        if (b[r + 1] <= b[r]) continue;
+        used.push_back(r);
+        g_pool.workers[r]->submit([&, r] {
+            int cur = -1;
+            if (hipGetDevice(&cur) != hipSuccess || cur != ids[r]) {
+                if (hipSetDevice(ids[r]) != hipSuccess) {
+                    (void)hipGetLastError();
+                    rcs[r] = CAPY_ERR_HIP;
+                    errs[r] = "hipSetDevice(" + std::to_string(ids[r]) + ") failed";
+                    return;
+                }
+            }
             rcs[r] = body(b[r], b[r + 1] - b[r]);
             if (rcs[r]) errs[r] = g_err;
-        }
-        g_in_shard = false;
-    };
-    std::vector<std::thread> th;
-    for (size_t r = 0; r < world; r++)
-        if (b[r + 1] > b[r]) th.emplace_back(work, r);
-    for (auto &t : th) t.join();
+        });
+    }
+    for (size_t r : used) g_pool.workers[r]->wait();
     for (size_t r = 0; r < world; r++)
         if (rcs[r]) return fail(rcs[r], "device " + std::to_string(ids[r]) + ": " + errs[r]);
     return CAPY_OK;
@@ -112,17 +244,25 @@ struct WsEntry {
 // promise not to do.  Retired blocks (less than the final size in total, the growth is geometric) and the live ones
 // are returned by capy_release_workspace() or when the thread ends (at process exit that runs before the HIP
 // runtime's own teardown; a late hipFree only returns an error).
+struct CachedBlock {
+    void *p;
+    size_t cap;
+    int device;
+};
 struct WsList {
     std::vector<WsEntry> v;
     std::vector<void *> retired;
+    std::vector<CachedBlock> cache;  // device blocks of finished host-buffer calls (DevBuf), see devbuf_take
     void release()
     {
         for (auto &w : v)
             for (void *q : w.ptr)
                 if (q) (void)hipFree(q);
         for (void *q : retired) (void)hipFree(q);
+        for (auto &c : cache) (void)hipFree(c.p);
         v.clear();
         retired.clear();
+        cache.clear();
     }
     ~WsList() { release(); }
 };
@@ -157,6 +297,56 @@ void *workspace(hipStream_t stream, WsSlot slot, size_t bytes)
 }
 
 void workspace_release() { g_ws_list.release(); }
+
+// Device blocks of the host-buffer entry points (DevBuf: message / key / output staging).  r02 paid a hipMalloc and a
+// hipFree -- a device synchronisation -- per buffer per call; now a finished call's blocks wait in a per-thread cache
+// and the next call of that thread takes the smallest one that fits without wasting more than half of it.  All users
+// enqueue on the thread's default stream (or have synchronised their side stream before the DevBuf dies), so reuse is
+// stream-ordered.  At most 24 blocks are kept (the oldest go first); capy_release_workspace() / thread exit frees them.
+void *devbuf_take(size_t bytes, size_t *cap)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    auto &c = g_ws_list.cache;
+    size_t best = c.size();
+    for (size_t i = 0; i < c.size(); i++)
+        if (c[i].device == dev && c[i].cap >= bytes && c[i].cap <= 2 * bytes + 4096 && (best == c.size() || c[i].cap < c[best].cap))
+            best = i;
+    if (best != c.size()) {
+        void *p = c[best].p;
+        *cap = c[best].cap;
+        c.erase(c.begin() + best);
+        return p;
+    }
+    const size_t want = (bytes + 255) & ~(size_t)255;
+    void *p = nullptr;
+    if (hipMalloc(&p, want) != hipSuccess) {
+        // memory may be held by the cache itself: drop it and try once more
+        (void)hipGetLastError();
+        for (auto &b : c) (void)hipFree(b.p);
+        c.clear();
+        if (hipMalloc(&p, want) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+    }
+    *cap = want;
+    return p;
+}
+void devbuf_give(void *p, size_t cap)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        (void)hipFree(p);
+        return;
+    }
+    auto &c = g_ws_list.cache;
+    c.push_back(CachedBlock{p, cap, dev});
+    if (c.size() > 24) {
+        (void)hipFree(c.front().p);
+        c.erase(c.begin());
+    }
+}
 
 // Secret intermediates (z||pw, ke||ka, the Schnorr secret s and nonce k, the ECDH point W) sit in pooled scratch that
 // later, unrelated calls reuse: zero them on the same stream once the call's last reader has been enqueued.
@@ -1202,8 +1392,14 @@ int capy_set_devices(const int *ids, int n)
     if (hipGetDeviceCount(&have) != hipSuccess) have = 0;
     for (int i = 0; i < n; i++)
         if (ids[i] < 0 || ids[i] >= have) return fail(CAPY_ERR_ARG, "device id out of range");
-    std::lock_guard<std::mutex> lk(g_dev_mu);
-    g_dev_ids.assign(ids, ids + n);
+    {
+        std::lock_guard<std::mutex> lk(g_dev_mu);
+        g_dev_ids.assign(ids, ids + n);
+    }
+    // the workers of the previous list end now (their scratch is returned on their own threads); the new ones start
+    // with the first sharded call
+    std::lock_guard<std::mutex> pool_lock(g_pool.mu);
+    if (g_pool.ids != std::vector<int>(ids, ids + n)) g_pool.reset({});
     return CAPY_OK;
 }
 

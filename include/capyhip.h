@@ -19,7 +19,9 @@
  *   points       affine (x, y), 2 x 56-byte little-endian canonical field elements (x first)
  *   return       0 = ok, <0 = CAPY_ERR_*; capy_last_error() gives the text (thread local)
  *   *_dev        same operation on buffers already resident in device memory, enqueued on `stream`
- *                (a hipStream_t passed as void*, NULL = default stream), no host synchronisation and no device
+ *                (a hipStream_t passed as void*; NULL = the CALLING THREAD's default stream: the library is built with
+ *                -fgpu-default-stream=per-thread since r03, so that host threads -- the library's own per-device workers
+ *                among them -- do not serialise on one legacy stream), no host synchronisation and no device
  *                copy from host memory: internal scratch is pooled per (host thread, device, stream), grows by
  *                allocating (never by freeing) and is returned by capy_release_workspace(); secret intermediates
  *                in it (z||pw, ke||ka, s, k, the ECDH point) are zeroed on the stream at the end of the call.
@@ -57,7 +59,10 @@ int capy_set_device(int device); /* device used by the calling thread's subseque
 /* Multi-GPU ("batches shard trivially across the 8 GPUs of one node", BASELINE north_star).
  * After capy_set_devices(ids, n) every HOST-buffer entry point below cuts its batch into n contiguous shards --
  * balanced by message bytes where the call carries messages, by count otherwise --, runs shard k on device ids[k]
- * (one worker thread per device) and has it write its slice of the caller's output arrays.  Items are independent:
+ * (one PERSISTENT worker thread per list position: it keeps its device, its scratch pools and its cache of staging
+ * buffers from call to call and is pinned to the CPUs the device is attached to, /sys/bus/pci/devices/<bdf>/local_cpulist;
+ * sharded calls from several host threads take turns) and has it write its slice of the caller's output arrays.
+ * Items are independent:
  * no collective and no peer-to-peer traffic; results, output order and in-place effects are identical to the
  * single-device call for every device list (an id may repeat).  n = 0 returns to the calling thread's current
  * device.  Process-wide; the *_dev entry points are unaffected (their buffers live on one device).
