@@ -54,6 +54,7 @@ SIGNATURES = {
     "capy_ed448_set_wave_max": (C.c_int, [C.c_long]),
     "capy_ed448_set_generator": (C.c_int, [vp]),
     "capy_ed448_get_generator": (C.c_int, [vp]),
+    "capy_ed448_set_scalar_star": (C.c_int, [C.c_int]),
     "capy_ed448_validate_batch": (C.c_int, [sz, vp, vp]),
     "capy_ed448_validate_batch_dev": (C.c_int, [sz, vp, vp, vp]),
     "capy_keypair_batch": (C.c_int, [C.c_int, sz, vp, sz, vp, vp]),

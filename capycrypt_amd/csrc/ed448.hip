@@ -188,17 +188,28 @@ __global__ void sc_mul4_kernel(uint64_t n, const uint8_t *in, uint8_t *out)
     sc_to_be(out + i * 56, r);
 }
 
-// z = k - h*s mod r   (src/ecc/signable.rs:54)
-__global__ void sc_sign_z_kernel(uint64_t n, const uint8_t *k_be, const uint8_t *h_be, const uint8_t *s_be, uint8_t *z_be)
+// k = kb `*` 4 (src/ecc/signable.rs:46) under the chosen reading of the crate's `*` (ed448_algo.h: sc_star4)
+__global__ void sc_star4_kernel(uint64_t n, const uint8_t *in, uint8_t *out, int star)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    uint32_t k[14], h[14], s[14], hs[14], z[14];
+    uint32_t a[14], r[14];
+    sc_from_be(a, in + i * 56);
+    sc_star4(r, a, star);
+    sc_to_be(out + i * 56, r);
+}
+
+// z = k - h*s   (src/ecc/signable.rs:54; ed448_algo.h: sc_sign_z)
+__global__ void sc_sign_z_kernel(uint64_t n, const uint8_t *k_be, const uint8_t *h_be, const uint8_t *s_be, uint8_t *z_be,
+                                 int star)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t k[14], h[14], s[14], z[14];
     sc_from_be(k, k_be + i * 56);
     sc_from_be(h, h_be + i * 56);
     sc_from_be(s, s_be + i * 56);
-    sc_mul_mod(hs, h, s);
-    sc_sub_mod(z, k, hs);
+    sc_sign_z(z, k, h, s, star);
     sc_to_be(z_be + i * 56, z);
 }
 
@@ -230,6 +241,8 @@ static size_t pair_min_items()
 // crate advertises fixed-time lookups; 2 = also the raw capy_ed448_scalarmul / basemul calls, whose scalars the library
 // cannot classify.  Verification and the table builds work on public data and always take the indexed kernels.
 static std::atomic<int> g_hardened{1};
+// reading of the curve crate's `Scalar * Scalar` at signable.rs:46 (ed448_algo.h: sc_star4); 0 = product mod r
+static std::atomic<int> g_scalar_star{0};
 static bool harden(bool secret)
 {
     const int m = g_hardened.load();
@@ -447,14 +460,15 @@ static int sign_dev(int d, size_t n, const KeyView &pw, const MsgView &m, uint8_
     // k = 4 * KMAC(s_bytes, msg, 448, "N")  (`*` taken as arithmetic mod r)
     rc = kmac_launch(d, n, fixed_keys(s_be, 56, 56), m, true, (const uint8_t *)"N", 1, 0, k_be, 56, 56, nullptr, st);
     if (rc) return rc;
-    rc = sc_mul4_launch(n, k_be, k_be, st);
-    if (rc) return rc;
+    const int star = g_scalar_star.load();
+    hipLaunchKernelGGL(sc_star4_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, (uint64_t)n, k_be, k_be, star);
+    CAPY_HIP(hipGetLastError());
     rc = fb_launch(n, k_be, U, st, true);  // U = k*G, affine; k is the secret nonce
     if (rc) return rc;
     // h = KMAC(U.x bytes, msg, 448, "T")
     rc = kmac_launch(d, n, fixed_keys(U, 56, 112), m, true, (const uint8_t *)"T", 1, 0, h, 56, 56, nullptr, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(sc_sign_z_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, (uint64_t)n, k_be, h, s_be, z);
+    hipLaunchKernelGGL(sc_sign_z_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, (uint64_t)n, k_be, h, s_be, z, star);
     CAPY_HIP(hipGetLastError());
     return CAPY_OK;
 }
@@ -661,6 +675,13 @@ int capy_ed448_set_hardened(int mode)
 {
     if (mode < 0 || mode > 3) return fail(CAPY_ERR_ARG, "mode must be 0 (off), 1 (secret scalars of the protocol calls, default), 2 or 3");
     g_hardened.store(mode);
+    return CAPY_OK;
+}
+
+int capy_ed448_set_scalar_star(int mode)
+{
+    if (mode < 0 || mode > 2) return fail(CAPY_ERR_ARG, "mode must be 0 (product mod r), 1 or 2 (see capyhip.h)");
+    g_scalar_star.store(mode);
     return CAPY_OK;
 }
 

@@ -506,4 +506,47 @@ CAPY_HD inline void sc_sub_mod(uint32_t out[14], const uint32_t a_in[14], const 
     }
 }
 
+// ---- Signable::sign's `bytes_to_scalar(k_bytes) * Scalar::from(4)` (/root/reference/src/ecc/signable.rs:46) and the
+// `k - h.mul_mod(&s)` that consumes it (:54).  `*` and `-` are operators of the absent curve crate; what they do to a value
+// that is not reduced mod r cannot be read off /root/reference (assumption (iii)), so the reading is a
+// run-time choice (capy_ed448_set_scalar_star; the default is the one every other call site -- mul_mod -- spells out):
+//   0  `*` is the product mod r:  k = 4 kb mod r,            z = (k - h s) mod r
+//   1  `*` wraps at 2^448 (the U448 the Scalar wraps) and `-` is crypto-bigint's sub_mod applied to the unreduced value:
+//      k = 4 kb mod 2^448,  z = k - hs  (+ r if that borrows);  U = [k]G with the unreduced k
+//   2  `*` wraps at 2^448, `-` reduces: k = 4 kb mod 2^448,  z = (k - h s) mod r
+// All three give signatures that verify (z G + h V = U either way); they differ in k, hence in U, h and z.
+CAPY_HD inline void sc_star4(uint32_t out[14], const uint32_t a[14], int star)
+{
+    if (star == 0) {
+        sc_mul4_mod(out, a);
+        return;
+    }
+#pragma unroll
+    for (int i = 13; i > 0; i--) out[i] = (a[i] << 2) | (a[i - 1] >> 30);
+    out[0] = a[0] << 2;
+}
+CAPY_HD inline void sc_sign_z(uint32_t z[14], const uint32_t k[14], const uint32_t h[14], const uint32_t s[14], int star)
+{
+    uint32_t hs[14];
+    sc_mul_mod(hs, h, s);
+    if (star != 1) {
+        sc_sub_mod(z, k, hs);  // reduces both operands first
+        return;
+    }
+    uint64_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        const uint64_t v = (uint64_t)k[i] - hs[i] - borrow;
+        z[i] = (uint32_t)v;
+        borrow = (v >> 63) & 1;
+    }
+    uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        const uint64_t v = (uint64_t)z[i] + (borrow ? sc_r_word(i) : 0u) + c;
+        z[i] = (uint32_t)v;
+        c = v >> 32;
+    }
+}
+
 }  // namespace capy

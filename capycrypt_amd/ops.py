@@ -183,6 +183,12 @@ def ed448_validate_batch(points_xy):
     return [status[i] == 0 for i in range(n)]
 
 
+def ed448_set_scalar_star(mode):
+    """Reading of the curve crate's `Scalar * Scalar` in Signable::sign (include/capyhip.h: capy_ed448_set_scalar_star):
+    0 product mod r (default), 1 wrapping at 2^448 with crypto-bigint's sub_mod, 2 wrapping with a reducing subtraction."""
+    L.check(L.lib().capy_ed448_set_scalar_star(int(mode)))
+
+
 def ed448_set_hardened(mode):
     """Constant-address table lookups (include/capyhip.h: capy_ed448_set_hardened): 0 off, 1 secret scalars of the
     protocol calls (the default), 3 every scalar multiplication incl. the raw calls; True means 3, False 0."""

@@ -154,6 +154,14 @@ int capy_ed448_scalarmul_batch_dev(size_t n, const uint8_t *scalars_be, const ui
  * next use.  Calls already in flight finish on the old tables (retired, not freed); meant to be called once at start-up. */
 int capy_ed448_set_generator(const uint8_t *xy);
 int capy_ed448_get_generator(uint8_t *xy);
+/* The second hedge of that kind: Signable::sign computes its nonce as `bytes_to_scalar(k_bytes) * Scalar::from(4)`
+ * (src/ecc/signable.rs:46) -- the crate's `*` operator on a value that is NOT reduced mod r, where every other call
+ * site spells out mul_mod -- and then `k - h.mul_mod(&s)` (:54).  What `*` and `-` do to an unreduced Scalar cannot
+ * be read off /root/reference (assumption (iii)).  mode 0 (default): `*` is the product mod r.
+ * mode 1: `*` wraps at 2^448 and `-` is crypto-bigint's sub_mod on the unreduced value (z = k - hs, + r on borrow).
+ * mode 2: `*` wraps at 2^448, `-` reduces (z = (k - hs) mod r).  In modes 1 and 2 U = [k]G takes the unreduced k.
+ * Signatures of all three verify; their bytes differ.  Process-wide; affects capy_schnorr_sign_* only. */
+int capy_ed448_set_scalar_star(int mode);
 /* out_i = [scalar_i] G — `ExtendedPoint::generator() * Scalar`
  * (src/ecc/keypair.rs:44, src/ecc/signable.rs:48,77, src/ecc/encryptable.rs:38). */
 int capy_ed448_basemul_batch(size_t n, const uint8_t *scalars_be, uint8_t *out_xy);

@@ -248,3 +248,18 @@ def x448_via_edwards(k_bytes, u_bytes, mul=scalarmul):
     if out[0] == 0:
         return (0).to_bytes(56, "little")
     return x448_u_from_edwards(out).to_bytes(56, "little")
+
+
+def schnorr_scalars(kb, h, s, star=0):
+    """The scalar arithmetic of Signable::sign (/root/reference/src/ecc/signable.rs:46,54) for the three readings of the
+    curve crate's `*` / `-` on a value that is not reduced mod r (include/capyhip.h: capy_ed448_set_scalar_star):
+    returns (k used for U = [k]G, z).  kb, h, s are integers (s < r)."""
+    hs = h * s % R
+    if star == 0:
+        k = 4 * kb % R
+        return k, (k - hs) % R
+    k = 4 * kb % 2**448
+    if star == 1:
+        z = k - hs
+        return k, z + R if z < 0 else z
+    return k, (k - hs) % R

@@ -172,6 +172,11 @@ def keypair_pub(pw, d):
     return bytes(out)
 
 
+def set_scalar_star(mode):
+    """Reading of `Scalar * Scalar` in sign (oracle_ed448.c: oracle_set_scalar_star)."""
+    lib().oracle_set_scalar_star(int(mode))
+
+
 def sign(pw, msg, d):
     h = (C.c_uint8 * 56)()
     z = (C.c_uint8 * 56)()

@@ -427,17 +427,48 @@ void oracle_keypair_pub(const uint8_t *pw, size_t pwlen, int d, uint8_t pub_xy[1
     oracle_ed448_basemul(s, pub_xy);
 }
 
+/* Reading of the curve crate's `Scalar * Scalar` at signable.rs:46 and of the `-` at :54 for a value that is not reduced
+ * mod r (assumption (iii); capy_oracle.h: oracle_set_scalar_star).  0: product mod r.  1: `*` wraps at 2^448, `-` is
+ * crypto-bigint's sub_mod on the unreduced value (z = k - hs, + r on borrow).  2: `*` wraps, `-` reduces. */
+static int scalar_star = 0;
+void oracle_set_scalar_star(int mode) { scalar_star = mode; }
+
 void oracle_sign(const uint8_t *pw, size_t pwlen, const uint8_t *msg, size_t len, int d, uint8_t h[56],
                  uint8_t z_be[56])
 { /* signable.rs:40-57 */
     uint8_t s[56], kraw[56], k[56], U[112], hs[56];
     derive_s(pw, pwlen, d, s);
     oracle_kmac_xof(s, 56, msg, len, 448, (const uint8_t *)"N", 1, d, 1, kraw);
-    oracle_sc448_mul_mod(kraw, FOUR_BE, k); /* `*` taken as arithmetic mod r: assumption (iii) */
+    if (scalar_star == 0) {
+        oracle_sc448_mul_mod(kraw, FOUR_BE, k); /* `*` taken as arithmetic mod r: assumption (iii) */
+    } else { /* 4 kb mod 2^448 */
+        for (int i = 0; i < 56; i++) k[i] = (uint8_t)((kraw[i] << 2) | (i + 1 < 56 ? kraw[i + 1] >> 6 : 0));
+    }
     oracle_ed448_basemul(k, U);
     oracle_kmac_xof(U, 56, msg, len, 448, (const uint8_t *)"T", 1, d, 1, h);
     oracle_sc448_mul_mod(h, s, hs);
-    oracle_sc448_sub_mod(k, hs, z_be);
+    if (scalar_star != 1) {
+        oracle_sc448_sub_mod(k, hs, z_be); /* reduces both operands first */
+        return;
+    }
+    uint32_t x[14], y[14], r[14];
+    sc_from_be(x, k);
+    sc_from_be(y, hs);
+    uint64_t borrow = 0;
+    for (int i = 0; i < 14; i++) {
+        uint64_t v = (uint64_t)x[i] - y[i] - borrow;
+        r[i] = (uint32_t)v;
+        borrow = (v >> 63) & 1;
+    }
+    if (borrow) {
+        uint64_t c = 0;
+        for (int i = 0; i < 14; i++) {
+            uint64_t v = (uint64_t)r[i] + R_LE[i] + c;
+            r[i] = (uint32_t)v;
+            c = v >> 32;
+        }
+    }
+    sc_to_be(z_be, r);
 }
 
 int oracle_verify(const uint8_t pub_xy[112], const uint8_t *msg, size_t len, int d, const uint8_t h[56],

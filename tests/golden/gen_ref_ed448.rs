@@ -10,7 +10,9 @@
 //         > <capyhip>/tests/golden/ref_ed448.json
 //
 // tests/test_oracle_ed448.py::test_reference_emitted_vectors consumes ref_ed448.json when it exists (skips otherwise):
-// every public key, (h, z) signature and [k]G below must equal the oracle's, byte for byte.  That check machine-tests
+// every public key, (h, z) signature, [k]G, [k]P on non-generator points and ECDH shared point below must equal the
+// oracle's, byte for byte; the raw result of `Scalar * Scalar` tells which capy_ed448_set_scalar_star mode is the
+// reference's.  That check machine-tests
 // the three assumptions DESIGN.md records about the absent crate: (i) ExtendedPoint::generator() is the RFC 8032 base
 // point, (ii) FieldElement::to_bytes() is 56-byte little-endian canonical, (iii) Scalar `*`, `-`, mul_mod are
 // arithmetic mod r with reduced results.
@@ -70,9 +72,32 @@ fn main() {
         let s = Scalar { val: U448::from_be_slice(&k) };
         basemul.push(json!({ "k": t["k"], "out": point_xy_hex(&(ExtendedPoint::generator() * s)) }));
     }
+    // `ExtendedPoint * Scalar` on NON-generator points (BASELINE config 4; src/ecc/encryptable.rs:37,78, signable.rs:77):
+    // P_i = [k_{i+1}]G built with the crate itself, out_i = [k_i]P_i -- no point is ever constructed from bytes, so only API
+    // that the reference's own call sites use appears here
+    let ks: Vec<Scalar> = doc["scalarmul"].as_array().unwrap().iter()
+        .map(|t| Scalar { val: U448::from_be_slice(&hex::decode(t["k"].as_str().unwrap()).unwrap()) }).collect();
+    let khex: Vec<&str> = doc["scalarmul"].as_array().unwrap().iter().map(|t| t["k"].as_str().unwrap()).collect();
+    let mut scalarmul = Vec::new();
+    for i in 0..ks.len() {
+        let j = (i + 1) % ks.len();
+        let p = ExtendedPoint::generator() * ks[j];
+        scalarmul.push(json!({ "k": khex[i], "t": khex[j], "p": point_xy_hex(&p), "out": point_xy_hex(&(p * ks[i])) }));
+    }
+    // the ECDH step of KeyEncryptable::key_encrypt (src/ecc/encryptable.rs:36-40) with a FIXED k in place of
+    // get_random_bytes(56): k = bytes_to_scalar(k_rand).mul_mod(4), W = V * k, Z = G * k; only W.x enters the KMAC
+    let mut ecdh = Vec::new();
+    for i in 0..ks.len().min(16) {
+        let j = (i + 7) % ks.len();
+        let v = ExtendedPoint::generator() * ks[j].mul_mod(&Scalar::from(4_u64));  // a public key as KeyPair::new builds it
+        let k = ks[i].mul_mod(&Scalar::from(4_u64));
+        let w = (v * k).to_affine();
+        ecdh.push(json!({ "k_rand": khex[i], "pub": point_xy_hex(&v), "w_x": hex::encode(w.x.to_bytes()),
+                          "z": point_xy_hex(&(ExtendedPoint::generator() * k)) }));
+    }
     // the scalar-field identities assumption (iii) rests on: 4*k via mul_mod, via `*`, and k - h*s
     let mut scalars = Vec::new();
-    for t in doc["scalarmul"].as_array().unwrap().iter().take(16) {
+    for t in doc["scalarmul"].as_array().unwrap().iter() {
         let k = Scalar { val: U448::from_be_slice(&hex::decode(t["k"].as_str().unwrap()).unwrap()) };
         let four = Scalar::from(4_u64);
         scalars.push(json!({
@@ -84,6 +109,6 @@ fn main() {
     }
     println!("{}", serde_json::to_string_pretty(&json!({
         "_comment": "emitted by tests/golden/gen_ref_ed448.rs from capycrypt 0.7.5 / tiny_ed448_goldilocks 0.1.8",
-        "sign": sign, "basemul": basemul, "scalars": scalars,
+        "sign": sign, "basemul": basemul, "scalarmul": scalarmul, "ecdh": ecdh, "scalars": scalars,
     })).unwrap());
 }

@@ -613,6 +613,30 @@ def test_hardened_mode_is_bit_identical(capy, O):
     assert plain["fb"] == [O.ed448_basemul(k) for k in ks] and all(plain["ver"]) and all(plain["dec"][1])
 
 
+def test_scalar_star_modes_match_oracle(capy, O):
+    """capy_ed448_set_scalar_star: the three readings of `bytes_to_scalar(k_bytes) * Scalar::from(4)` in Signable::sign
+    (/root/reference/src/ecc/signable.rs:46,54).  In every mode the GPU's (h, z) equal the oracle's in the same mode and
+    verify; the modes differ from each other."""
+    rng = random.Random(0x57A2)
+    n = 70
+    pws = [rng.randbytes(rng.randrange(1, 70)) for _ in range(n)]
+    msgs = [rng.randbytes(rng.randrange(0, 400)) for _ in range(n)]
+    pubs = capy.ops.keypair_batch(pws, 512)
+    got = {}
+    try:
+        for mode in (0, 1, 2):
+            capy.ops.ed448_set_scalar_star(mode)
+            O.set_scalar_star(mode)
+            sigs = capy.ops.schnorr_sign_batch(pws, msgs, 512)
+            assert sigs == [O.sign(pw, m, 512) for pw, m in zip(pws, msgs)], mode
+            assert all(capy.ops.schnorr_verify_batch(pubs, msgs, sigs, 512)), mode
+            got[mode] = sigs
+    finally:
+        capy.ops.ed448_set_scalar_star(0)
+        O.set_scalar_star(0)
+    assert got[0] != got[1] and got[0] != got[2] and got[1] != got[2]
+
+
 def test_hardened_pair_kernels_match(capy, O, ed448_kernel_family):
     """The kernels of batches from 262 144 items: two items per lane sharing one inversion (vb2_kernel, fb2_kernel<false>)
     against their constant-address counterparts (vb_ct_kernel, fb2_kernel<true>).  CAPY_ED448_PAIR cannot be switched at

@@ -174,29 +174,124 @@ def test_openssl_generated_vectors():
         assert E.x448_via_edwards(H(t["b"]), H(t["a_public"]), mul=_c_mul).hex() == t["shared"]
 
 
+def _check_reference_file(path):
+    """The checks of test_reference_emitted_vectors on one ref_ed448.json; returns the capy_ed448_set_scalar_star mode whose
+    signatures the file holds."""
+    with open(path) as f:
+        v = json.load(f)
+    for t in v["sign"]:
+        assert O.keypair_pub(H(t["pw"]), t["d"]).hex() == t["pub"]
+    for t in v["basemul"]:
+        assert O.ed448_basemul(H(t["k"])).hex() == t["out"]
+    for t in v["scalars"]:
+        k = int(t["k"], 16)
+        assert t["mul_mod_4"] == E.sc_to_bytes(4 * k % E.R).hex()
+        assert t["k_minus_4k"] == E.sc_to_bytes((k - 4 * k) % E.R).hex()
+    # Which reading of `Scalar * Scalar` (signable.rs:46) the crate implements: the recipe emits the operator's raw result
+    # for every scalar, so the file itself says which capy_ed448_set_scalar_star mode is the reference's; the signatures
+    # must then match in that mode (a wrapping `*` leaves the subtraction to decide between modes 1 and 2).
+    stars = {0: lambda k: 4 * k % E.R, 1: lambda k: 4 * k % 2**448}
+    fits = [m for m, f in stars.items() if all(t["star_4"] == E.sc_to_bytes(f(int(t["k"], 16))).hex() for t in v["scalars"])]
+    assert fits, "Scalar * Scalar is neither the product mod r nor the product mod 2^448"
+    for mode in ((0,) if 0 in fits else (1, 2)):
+        O.set_scalar_star(mode)
+        try:
+            ok = all(tuple(x.hex() for x in O.sign(H(t["pw"]), H(t["msg"]), t["d"])) == (t["h"], t["z"]) for t in v["sign"])
+        finally:
+            O.set_scalar_star(0)
+        if ok:
+            found = mode
+            break
+    else:
+        raise AssertionError("no reading of `*` / `-` reproduces the reference's signatures")
+    # variable base on NON-generator points and the ECDH shared point of key_encrypt (ecc/encryptable.rs:36-40, 77-80)
+    for t in v.get("scalarmul", []):
+        assert O.ed448_scalarmul(H(t["k"]), H(t["p"])).hex() == t["out"]
+    for t in v.get("ecdh", []):
+        k4 = E.sc_to_bytes(4 * int(t["k_rand"], 16) % E.R)
+        assert O.ed448_scalarmul(k4, H(t["pub"])).hex()[:112] == t["w_x"]
+        assert O.ed448_basemul(k4).hex() == t["z"]
+    return found
+
+
 def test_reference_emitted_vectors():
     """tests/golden/ref_ed448.json is emitted by tests/golden/gen_ref_ed448.rs from the REAL reference crate (a
     maintainer with cargo runs it; this build environment has no Rust toolchain).  When the file exists every public
-    key, signature, [k]G and scalar identity in it must equal the oracle's -- which pins assumptions (i)-(iii) of
-    DESIGN.md section 2 to the reference itself."""
+    key, signature, [k]G, [k]P on non-generator points, ECDH shared point and scalar identity in it must equal the
+    oracle's -- which pins assumptions (i)-(iii) of DESIGN.md section 2 to the reference itself and says which reading of
+    `Scalar * Scalar` (capy_ed448_set_scalar_star) the crate implements."""
     import pytest
 
     path = os.path.join(HERE, "golden", "ref_ed448.json")
     if not os.path.exists(path):
         pytest.skip("ref_ed448.json not generated (needs cargo + the reference crate, see gen_ref_ed448.rs)")
-    with open(path) as f:
-        v = json.load(f)
-    for t in v["sign"]:
-        pw, msg = H(t["pw"]), H(t["msg"])
-        assert O.keypair_pub(pw, t["d"]).hex() == t["pub"]
-        h, z = O.sign(pw, msg, t["d"])
-        assert (h.hex(), z.hex()) == (t["h"], t["z"])
-    for t in v["basemul"]:
-        assert O.ed448_basemul(H(t["k"])).hex() == t["out"]
-    for t in v["scalars"]:
-        k = int(t["k"], 16)
-        assert t["mul_mod_4"] == t["star_4"] == E.sc_to_bytes(4 * k % E.R).hex()
-        assert t["k_minus_4k"] == E.sc_to_bytes((k - 4 * k) % E.R).hex()
+    print("reference signatures match capy_ed448_set_scalar_star(%d)" % _check_reference_file(path))
+
+
+def test_reference_consumer_recognises_every_reading(tmp_path):
+    """Dry run of the consumer above: ref_ed448.json as gen_ref_ed448.rs would emit it, simulated with the oracle for each
+    of the three readings of `*` / `-` -- the consumer must accept the file and name the reading that produced it."""
+    with open(os.path.join(HERE, "golden", "ed448_vectors.json")) as f:
+        doc = json.load(f)
+    ks = [t["k"] for t in doc["scalarmul"]][:12]
+    n = len(ks)
+    for star in (0, 1, 2):
+        out = {"sign": [], "basemul": [], "scalarmul": [], "ecdh": [], "scalars": []}
+        O.set_scalar_star(star)
+        try:
+            for t in doc["sign"][:6]:
+                h, z = O.sign(H(t["pw"]), H(t["msg"]), t["d"])
+                out["sign"].append({"d": t["d"], "pw": t["pw"], "msg": t["msg"], "pub": O.keypair_pub(H(t["pw"]), t["d"]).hex(),
+                                    "h": h.hex(), "z": z.hex()})
+        finally:
+            O.set_scalar_star(0)
+        for i, k in enumerate(ks):
+            ki, p = int(k, 16), O.ed448_basemul(H(ks[(i + 1) % n]))
+            out["basemul"].append({"k": k, "out": O.ed448_basemul(H(k)).hex()})
+            out["scalarmul"].append({"k": k, "t": ks[(i + 1) % n], "p": p.hex(), "out": O.ed448_scalarmul(H(k), p).hex()})
+            v = O.ed448_basemul(E.sc_to_bytes(4 * int(ks[(i + 7) % n], 16) % E.R))
+            k4 = E.sc_to_bytes(4 * ki % E.R)
+            out["ecdh"].append({"k_rand": k, "pub": v.hex(), "w_x": O.ed448_scalarmul(k4, v).hex()[:112], "z": O.ed448_basemul(k4).hex()})
+            out["scalars"].append({"k": k, "mul_mod_4": E.sc_to_bytes(4 * ki % E.R).hex(),
+                                   "star_4": E.sc_to_bytes(4 * ki % (E.R if star == 0 else 2**448)).hex(),
+                                   "k_minus_4k": E.sc_to_bytes((ki - 4 * ki) % E.R).hex()})
+        path = tmp_path / ("ref_%d.json" % star)
+        path.write_text(json.dumps(out))
+        assert _check_reference_file(str(path)) == star
+
+
+def test_scalar_star_readings_differ_and_all_verify():
+    """capy_ed448_set_scalar_star / oracle_set_scalar_star: the three readings of `bytes_to_scalar(k_bytes) * Scalar::from(4)`
+    and of the `-` that consumes it (/root/reference/src/ecc/signable.rs:46,54).  On the committed sign vectors the three
+    give three different (h, z), every one of them verifies, mode 0 is the committed fixture, and the C oracle agrees with
+    the python big-int model of the scalar arithmetic in each mode."""
+    with open(os.path.join(HERE, "golden", "ed448_vectors.json")) as f:
+        vec = json.load(f)["sign"]
+    for t in vec[:6]:
+        pw, msg, d = H(t["pw"]), H(t["msg"]), t["d"]
+        pub = O.keypair_pub(pw, d)
+        s = 4 * int.from_bytes(O.kmac_xof(pw, b"", 448, b"SK", d), "big") % E.R
+        kb = int.from_bytes(O.kmac_xof(E.sc_to_bytes(s), msg, 448, b"N", d), "big")
+        sigs = []
+        for mode in (0, 1, 2):
+            O.set_scalar_star(mode)
+            try:
+                h, z = O.sign(pw, msg, d)
+            finally:
+                O.set_scalar_star(0)
+            assert O.verify(pub, msg, d, h, z), mode
+            k, z_model = E.schnorr_scalars(kb, int.from_bytes(h, "big"), s, mode)
+            assert int.from_bytes(z, "big") == z_model, mode
+            ux = O.ed448_basemul(k.to_bytes(56, "big"))[:56]
+            assert O.kmac_xof(ux, msg, 448, b"T", d) == h, mode
+            sigs.append((h.hex(), z.hex()))
+        assert sigs[0] == (t["h"], t["z"])
+        wraps = 4 * kb >= 2**448  # without a wrap modes 0 and 2 coincide (4 kb mod r either way) ...
+        assert sigs[0] != sigs[1] or not wraps
+        assert (sigs[0] != sigs[2]) == wraps
+    # ... so make sure the fixture exercises the wrap at least once
+    assert any(4 * int.from_bytes(O.kmac_xof(E.sc_to_bytes(4 * int.from_bytes(O.kmac_xof(H(t["pw"]), b"", 448, b"SK", t["d"]), "big") % E.R),
+                                             H(t["msg"]), 448, b"N", t["d"]), "big") >= 2**448 for t in vec[:6])
 
 
 def test_protocol_roundtrips():
