@@ -25,15 +25,18 @@ MSG_BYTES = 5242880  # benches/benchmark_sha3.rs:17
 # padding per message spreads them (1.03x).  Speed is the same either way (the kernel is VALU-bound).
 MSG_STRIDE = MSG_BYTES + 128
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-# Integer-VALU ceiling for keccak-f[1600] on MI355X, MEASURED (profiles/r01_keccak_loop_forms.txt): a
-# register-resident loop of nothing but permutations tops out at 10.68e9 permutations/s (16k waves, best loop
-# form), i.e. 1453 GB/s of absorbed message at 136 B per permutation ("Rooflines").
-VALU_CEIL_GBS = 10.68e9 * 136.0 / 1e9
-# What MI355X_MICROARCH.md's SIMD-32 figure (one wave64 VALU instruction per 2 cycles per SIMD) would allow for the
-# 4320 VALU instructions of one permutation of a wave's 64 sponges: 1024 SIMDs x 2.4 GHz / 2 / 4320 x 64 x 136 B.  Not reachable for this
-# instruction mix: with every SIMD busy the chip sustains one instruction of it per ~1.45-1.7 ns per SIMD whatever
-# the number of waves (profiles/r02_second_issue_slot.txt); reported beside the measured ceiling for reference.
-VALU_ARCH_CEIL_GBS = 1024 * 2.4e9 / 2 / 4320 * 64 * 136.0 / 1e9
+# Integer-VALU ceilings for keccak-f[1600] on MI355X (profiles/r03_valu_issue_bisect.txt).  A SIMD issues a wave64 VALU
+# instruction of the simple class (v_bitop3_b32, xor/and/or, add/sub) in 2 cycles and every other one (v_alignbit_b32, DPP,
+# multiplies, 64-bit ops) in 4, but ONE wave issues at most one instruction per 4 cycles, and a second wave only gets the
+# spare half windows if the first raises its priority around its 4-cycle blocks (keccak_dev.h: keccak_round_blocked).
+#   many waves per SIMD: (58 x 4 + 122 x 2) cycles per round of 64 sponges -> 1024 SIMDs x 2.4 GHz / (476 x 24) x 64 x 136 B
+VALU_ARCH_CEIL_GBS = 1024 * 2.4e9 / ((58 * 4 + 122 * 2) * 24) * 64 * 136.0 / 1e9
+#   ONE wave per SIMD (the headline: 288 GB of HBM hold 53 sponges of 5 MiB per SIMD, less than one wave each): 4 cycles
+#   for every one of the 4320 instructions of a permutation
+VALU_ARCH_CEIL_ONE_WAVE_GBS = 1024 * 2.4e9 / (4 * 4320) * 64 * 136.0 / 1e9
+# measured stand-ins when the live probe cannot run (part 4 of that file): 13.9 / 8.2 G permutations/s
+VALU_CEIL_GBS = 13.9e9 * 136.0 / 1e9
+VALU_CEIL_ONE_WAVE_GBS = 8.2e9 * 136.0 / 1e9
 
 
 def kernel_source_digest():
@@ -92,6 +95,28 @@ def _cpu_model():
     return "unknown cpu"
 
 
+def usable_cpus():
+    """Host cores this job may really use: the scheduler affinity, capped by the cgroup CPU quota (a GPU box shows all
+    256 CPUs of the host in its affinity mask but is throttled to its share)."""
+    n = len(os.sched_getaffinity(0))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts and parts[0] != "max":
+                    n = min(n, max(1, int(int(parts[0]) / int(parts[1]) + 0.5)))
+            else:
+                q = int(parts[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                        n = min(n, max(1, int(q / int(g.read()) + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
 def cpu_baseline(seconds):
     """The oracle's scalar C SHA3-256 (a port of the reference algorithm; the Rust reference cannot
     be built here) timed on one host core over a bounded sample of the same workload."""
@@ -117,11 +142,11 @@ def cpu_baseline(seconds):
     import hashlib
 
     assert bytes(out) == hashlib.sha3_256(msg).digest()
-    # also the same port over independent messages on ALL host cores this job may use (the reference
-    # itself is single-threaded on this path; ctypes drops the GIL during the call)
+    # also the same port over independent messages on ALL host cores this job may use (affinity capped by
+    # the cgroup quota; the reference itself is single-threaded on this path; ctypes drops the GIL during the call)
     import threading
 
-    nthr = max(1, len(os.sched_getaffinity(0)))
+    nthr = usable_cpus()
     counts = [0] * nthr
     span = min(5.0, seconds)
 
@@ -384,20 +409,26 @@ def main():
             if want in k and "valu_insts_per_wave" in e:
                 ed_pmc = (k, e)
 
-    # measured VALU ceiling of this box, live: nothing but permutations, 16 waves per SIMD, rolled form with the round
-    # constants fetched one trip ahead (the best form, profiles/r01_keccak_loop_forms.txt)
-    valu_live = None
+    # measured VALU ceilings of this box, live: nothing but permutations -- (a) 16 waves per SIMD on the blocked round with
+    # raised priority around its rotation blocks (the best many-waves form, profiles/r03_valu_issue_bisect.txt), (b) one
+    # wave per SIMD on the unrolled round, the regime the headline batch is confined to by HBM capacity
+    valu_live = valu_live_one = None
+    simds = 4 * torch.cuda.get_device_properties(dev).multi_processor_count  # 4 SIMDs per CU
     if rank == 0:
         chk = torch.zeros(1, dtype=torch.int64, device=dev)
-        n_states, iters = 16384 * 64, 600
-        _lib.check(lib.capy_keccak_valu_probe_dev(n_states, (2 << 30) | 60, chk.data_ptr(), sp))
-        torch.cuda.synchronize()
-        p0, p1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        p0.record(stream)
-        _lib.check(lib.capy_keccak_valu_probe_dev(n_states, (2 << 30) | iters, chk.data_ptr(), sp))
-        p1.record(stream)
-        torch.cuda.synchronize()
-        valu_live = n_states * iters / (p0.elapsed_time(p1) * 1e-3) * 136.0 / 1e9
+
+        def probe(n_states, iters, variant):
+            _lib.check(lib.capy_keccak_valu_probe_dev(n_states, (variant << 30) | max(1, iters // 10), chk.data_ptr(), sp))
+            torch.cuda.synchronize()
+            p0, p1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            p0.record(stream)
+            _lib.check(lib.capy_keccak_valu_probe_dev(n_states, (variant << 30) | iters, chk.data_ptr(), sp))
+            p1.record(stream)
+            torch.cuda.synchronize()
+            return n_states * iters / (p0.elapsed_time(p1) * 1e-3) * 136.0 / 1e9
+
+        valu_live = probe(16384 * 64, 600, 3)
+        valu_live_one = probe(simds * 64, 2000, 0)
 
     if rank == 0:
         total_bytes = world * B * MSG_BYTES * a.steps
@@ -434,11 +465,17 @@ def main():
                          "kernel": kname, "launches_per_step": launches, "kernel_ms": launch_ms,
                          # the binding resource is integer VALU issue, not HBM: measured ceilings
                          "binding_resource": "valu",
+                         # the regime of this batch: fewer sponges than one wave per SIMD
+                         "sponges_per_simd": B / simds,
+                         "valu_ceiling_one_wave_per_simd_GBs": valu_live_one if valu_live_one else VALU_CEIL_ONE_WAVE_GBS,
+                         "frac_of_one_wave_ceiling": achieved / (valu_live_one if valu_live_one else VALU_CEIL_ONE_WAVE_GBS),
                          "valu_ceiling_GBs": valu_live if valu_live else VALU_CEIL_GBS,
-                         "valu_ceiling_source": "bare permutation loop at 16 waves per SIMD, measured in this run"
-                                                if valu_live else "profiles/r01_keccak_loop_forms.txt",
+                         "valu_ceiling_source": "bare permutation loops measured in this run: 16 waves per SIMD on the blocked "
+                                                "round with priority (many waves), one wave per SIMD on the unrolled round"
+                                                if valu_live else "profiles/r03_valu_issue_bisect.txt",
                          "frac_of_valu_ceiling": achieved / (valu_live if valu_live else VALU_CEIL_GBS),
                          "valu_arch_ceiling_GBs": VALU_ARCH_CEIL_GBS,
+                         "valu_arch_ceiling_one_wave_per_simd_GBs": VALU_ARCH_CEIL_ONE_WAVE_GBS,
                          "frac_of_valu_arch_ceiling": achieved / VALU_ARCH_CEIL_GBS},
         }
         if ed:

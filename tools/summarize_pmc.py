@@ -20,7 +20,8 @@ for d in dirs:
             agg[k]["_dur_ns"] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
             agg[k]["_grid"] = int(r["Grid_Size"])
             agg[k]["_vgpr"] = int(r["VGPR_Count"]) + int(r["Accum_VGPR_Count"])
-            if os.environ.get("CAPY_PMC_ITEMS") and "sponge_" in k:
+            # (only the passes over bench.py itself: the extra kernels of refresh_profiles.sh run on other batches)
+            if os.environ.get("CAPY_PMC_ITEMS") and "sponge_" in k and not d.rstrip("/").endswith(("_short", "_wide")):
                 agg[k]["_items"] = int(os.environ["CAPY_PMC_ITEMS"])  # batch size behind the grid (bench.py matches on it)
 res = {"_meta": {"kernel_source_digest": os.environ.get("CAPY_PMC_DIGEST", ""),
                  "msg_stride": int(os.environ.get("CAPY_PMC_STRIDE", "0")), "items": int(os.environ.get("CAPY_PMC_ITEMS", "0"))}}
