@@ -1370,7 +1370,7 @@ using namespace capy;
 extern "C" {
 
 const char *capy_last_error(void) { return capy::g_err.c_str(); }
-const char *capy_version(void) { return "capyhip 0.2 (gfx950)"; }
+const char *capy_version(void) { return "capyhip 0.3 (gfx950)"; }
 
 int capy_device_count(void)
 {

@@ -91,3 +91,63 @@ def test_sharded_error_is_reported_and_batch_smaller_than_device_list(devices):
     assert e.value.code == _lib.CAPY_ERR_UNSUPPORTED_SECPARAM
     lib = _lib.lib()
     assert lib.capy_set_devices((C.c_int * 1)(99), 1) == _lib.CAPY_ERR_ARG
+
+
+def test_persistent_workers_survive_list_changes_and_concurrent_callers(devices):
+    """r03: the workers of capy_set_devices are long-lived (one per list position, own scratch pools and staging-buffer
+    cache).  Changing the list stops the old workers and starts new ones with the next sharded call; releasing the calling
+    thread's workspace between calls must not disturb them; sharded calls from several host threads take turns and every
+    one of them gets the single-device result."""
+    import threading
+
+    from capycrypt_amd import _lib, ops
+
+    rng = random.Random(0x70B)
+    msgs = [rng.randbytes(rng.randrange(0, 4000)) for _ in range(150)]
+    pws = [rng.randbytes(20) for _ in msgs]
+    want_sha, want_sig = ops.sha3_batch(msgs, 512), ops.schnorr_sign_batch(pws, msgs, 256)
+    for ids in ([0, 0], [0, 0, 0, 0], [0], [0, 0]):
+        devices(ids)
+        for _ in range(3):  # repeated calls reuse the workers' pools; sizes differ from call to call
+            k = rng.randrange(1, len(msgs))
+            assert ops.sha3_batch(msgs[:k], 512) == want_sha[:k]
+        assert ops.schnorr_sign_batch(pws, msgs, 256) == want_sig
+        _lib.check(_lib.lib().capy_release_workspace())
+    devices([0, 0, 0])
+    errors = []
+
+    def caller(seed):
+        r = random.Random(seed)
+        try:
+            for _ in range(4):
+                k = r.randrange(1, len(msgs))
+                if ops.sha3_batch(msgs[:k], 512) != want_sha[:k] or ops.schnorr_sign_batch(pws[:k], msgs[:k], 256) != want_sig[:k]:
+                    errors.append("mismatch in thread %d" % seed)
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=caller, args=(s,)) for s in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+
+
+def test_staging_buffer_cache_reuse_and_release():
+    """r03: the host-buffer entry points take their device staging buffers from a per-thread cache (common.h: DevBuf).
+    Calls of growing, shrinking and equal sizes must give the same results as fresh allocations would, secrets are
+    zeroed before a block is reused (a later, larger KMAC with a shorter key must not see the previous key's bytes), and
+    capy_release_workspace() empties the cache without affecting later calls."""
+    from capycrypt_amd import _lib, ops
+    from oracle import oracle as O
+
+    rng = random.Random(0xCAC4E)
+    for n, mlen, klen in ((300, 2000, 64), (7, 90000, 200), (300, 2000, 3), (1, 5, 0), (64, 136, 64), (300, 1999, 64)):
+        msgs = [rng.randbytes(mlen) for _ in range(n)]
+        keys = [rng.randbytes(klen) for _ in range(n)]
+        got = ops.kmac_xof_batch(keys, msgs, 512, b"cache", 512)
+        for i in (0, n // 2, n - 1):
+            assert got[i] == O.kmac_xof(keys[i], msgs[i], 512, b"cache", 512), (n, mlen, klen, i)
+        if n == 7:
+            _lib.check(_lib.lib().capy_release_workspace())
