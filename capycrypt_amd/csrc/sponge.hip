@@ -494,7 +494,16 @@ static void kmac_head(int d, size_t key_len, SpongeParams &p)
 static std::atomic<int> g_lanes_per_sponge{0};
 static std::atomic<unsigned> g_debug_flags{0};
 static std::atomic<bool> g_fused_enabled{true};
-static const size_t FUSED_MAX_ITEMS = 16384;  // 16 items per wave x one wave per SIMD
+// 16 items per wave x one wave per SIMD with the plain round; beyond that the blocked round at raised priority pairs the
+// waves of a SIMD (r03, profiles/r03_chipfull.txt: 32 768 x 5 MiB 353 -> 451 GiB/s, 49 152 x 4 MiB 405 -> 472, 98 304 x
+// 1 MiB 432 -> 515 against the two-pass form; at 131 072 x 1 MiB the two passes win again, 541 vs 527).
+// CAPY_FUSED_MAX overrides for A/B.
+static const size_t FUSED_ONE_WAVE_ITEMS = 16384;
+static const size_t FUSED_MAX_ITEMS = [] {
+    const char *e = getenv("CAPY_FUSED_MAX");
+    const long v = e ? atol(e) : 98304;
+    return (size_t)(v > 0 ? v : 98304);
+}();
 // Kernel choice by batch size relative to the device's SIMD count S (1024 on MI355X; measured crossovers, profiles/):
 //   n <= 32 S        two lanes per sponge, at most one wave per SIMD
 //   32 S < n < 64 S  rotating one-lane / two-lane schedule when eligible (sponge_mixed.h), else one lane
@@ -1140,6 +1149,7 @@ int symmetric_crypt_dev(bool encrypt, int d, size_t n, const uint8_t *keka, size
         fp.tag_len = (uint32_t)tag_len;
         fp.decrypt = encrypt ? 0 : 1;
         fp.staged = (g_debug_flags.load() & 64) ? 1 : 0;  // A/B switch (debug bit 6)
+        fp.paired = (n > FUSED_ONE_WAVE_ITEMS && !fp.staged) ? 1 : 0;
         fp.n = n;
         // One wave per item (sponge_wide.h) while every wave still has most of a SIMD pair's LDS bandwidth to itself:
         // 1.3x per permutation at n = 128, break-even near one wave per SIMD (profiles/r02_wide_lane_probe.txt).

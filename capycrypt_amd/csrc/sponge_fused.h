@@ -41,6 +41,7 @@ struct FusedParams {
     const uint32_t *order;  // optional processing order, see SpongeParams::order
     uint32_t wide;          // launcher's choice: 1 = one wave per item (sponge_wide.h), 0 = four lanes per item (here)
     uint32_t staged;        // A/B (debug bit 6): the round-1 form of this kernel, blocks staged through LDS
+    uint32_t paired;        // launcher's choice: more than one wave per SIMD -> the blocked round with priority
     uint64_t n;
 };
 
@@ -56,7 +57,9 @@ __device__ __forceinline__ uint32_t quad_swap_pairs(uint32_t v)
 // they were before this step), the keystream lanes store the XORed half straight back, and on decrypt the tag lanes
 // take the keystream from their partner lanes with one DPP move per word.  No LDS and no barrier in the block loop.
 // STAGED = true: the round-1 form (wave-cooperative 8-byte transfers through LDS, four barriers per block), kept for A/B.
-template <int RW, bool STAGED = false>
+// PAIRED (r03): the launch puts two or three waves on a SIMD (16 384 < n <= 49 152): the hot loop runs the blocked round
+// with raised priority around its DPP / rotation blocks (sponge_kernels_k2.h: keccak_round_k2_blocked).
+template <int RW, bool STAGED = false, bool PAIRED = false>
 __global__ __launch_bounds__(64) void sponge_fused_crypt_kernel(const FusedParams fp)
 {
     constexpr uint32_t RB = RW * 8;
@@ -183,7 +186,10 @@ __global__ __launch_bounds__(64) void sponge_fused_crypt_kernel(const FusedParam
 #pragma unroll
                         for (int w = 0; w < RW; w++) a.a[w] ^= wv[w];
                     }
-                    keccakf1600_k2_unrolled(a, hmask);
+                    if constexpr (PAIRED)
+                        keccakf1600_k2_paired_unrolled<true>(a, hmask);
+                    else
+                        keccakf1600_k2_unrolled(a, hmask);
                 }
             }
         }

@@ -27,6 +27,15 @@ hipError_t launch_sponge_fused(int rw, const FusedParams &fp, hipStream_t s)
         }
         return hipGetLastError();
     }
+    if (fp.paired) {  // more than one wave per SIMD
+        switch (rw) {
+        case 17: hipLaunchKernelGGL((sponge_fused_crypt_kernel<17, false, true>), grid, block, 0, s, fp); break;
+        case 19: hipLaunchKernelGGL((sponge_fused_crypt_kernel<19, false, true>), grid, block, 0, s, fp); break;
+        case 21: hipLaunchKernelGGL((sponge_fused_crypt_kernel<21, false, true>), grid, block, 0, s, fp); break;
+        default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     switch (rw) {
     case 17: hipLaunchKernelGGL(sponge_fused_crypt_kernel<17>, grid, block, 0, s, fp); break;
     case 19: hipLaunchKernelGGL(sponge_fused_crypt_kernel<19>, grid, block, 0, s, fp); break;

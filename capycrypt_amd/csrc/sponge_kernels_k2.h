@@ -79,6 +79,48 @@ __device__ __forceinline__ void keccak_round_k2(KHalf &s, uint32_t rc_lo, uint32
     s.a[0] = xor3(s.a[0], rc_x & hmask, rc_lo);
 }
 
+// The two-lane round for TWO OR MORE WAVES PER SIMD (keccak_dev.h: keccak_round_blocked; profiles/
+// r03_valu_issue_bisect.txt): 62 simple instructions (parity, theta-apply, chi + iota) and 58 four-cycle ones (a DPP move +
+// v_alignbit_b32 per rotation) in two blocks that run at raised priority, kept apart by sched_barrier.  Synthetic stream
+// of this shape at two waves per SIMD: 4.07 -> 2.74 cycles per instruction.
+template <bool PRIO>
+__device__ __forceinline__ void keccak_round_k2_blocked(KHalf &s, uint32_t rc_lo, uint32_t rc_x, uint32_t hmask)
+{
+    uint32_t c[5], r[5];
+#pragma unroll
+    for (int x = 0; x < 5; x++) c[x] = xor3(xor3(s.a[x], s.a[x + 5], s.a[x + 10]), s.a[x + 15], s.a[x + 20]);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int x = 0; x < 5; x++) r[x] = rol64_half<1>(c[x], dpp_swap_pair(c[x]));
+    if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    KHalf e, b;
+#pragma unroll
+    for (int i = 0; i < 25; i++) e.a[i] = xor3(s.a[i], c[(i % 5 + 4) % 5], r[(i % 5 + 1) % 5]);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
+    rho_pi_half_all(e, b, std::make_integer_sequence<int, 25>{});
+    if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int y = 0; y < 5; y++)
+#pragma unroll
+        for (int x = 0; x < 5; x++) s.a[x + 5 * y] = chi3(b.a[x + 5 * y], b.a[(x + 1) % 5 + 5 * y], b.a[(x + 2) % 5 + 5 * y]);
+    s.a[0] = xor3(s.a[0], rc_x & hmask, rc_lo);
+}
+template <bool PRIO, int... Rs>
+__device__ __forceinline__ void keccakf1600_k2_paired_unrolled_impl(KHalf &s, uint32_t hmask, std::integer_sequence<int, Rs...>)
+{
+    // literal round constants: an SGPR operand would turn iota into a 4-cycle instruction inside a simple block
+    (keccak_round_k2_blocked<PRIO>(s, (uint32_t)keccak_rc64(Rs), (uint32_t)keccak_rc64(Rs) ^ (uint32_t)(keccak_rc64(Rs) >> 32), hmask), ...);
+}
+template <bool PRIO>
+__device__ __forceinline__ void keccakf1600_k2_paired_unrolled(KHalf &s, uint32_t hmask)
+{
+    keccakf1600_k2_paired_unrolled_impl<PRIO>(s, hmask, std::make_integer_sequence<int, 24>{});
+}
+
 template <int... Rs>
 __device__ __forceinline__ void keccakf1600_k2_unrolled_impl(KHalf &s, uint32_t hmask, std::integer_sequence<int, Rs...>)
 {
