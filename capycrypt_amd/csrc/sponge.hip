@@ -678,7 +678,7 @@ static int sponge_plan(int rw, const SpongeParams &p, int *phases)
     }
     // the wave-quantisation split of launch_sponge(): a full-chip head of 64 S one-lane sponges + a remainder that
     // takes the two-lane kernel or the rotating schedule
-    if (forced == 0 && !p.offsets && !p.mask && !p.order && p.n > 64 * simds && p.n < 128 * simds) {
+    if (forced == 0 && (dbg & 256) && !p.offsets && !p.mask && !p.order && p.n > 64 * simds && p.n < 128 * simds) {
         SpongeParams tail = p;
         tail.n = p.n - 64 * simds;
         if (tail.n <= 32 * simds) {
@@ -722,10 +722,13 @@ static int launch_sponge(int rw, const SpongeParams &p, hipStream_t s)
         if (m < 0) return m;
         if (m > 0) return CAPY_OK;
     }
-    // Wave quantisation between one and two one-lane waves per SIMD: a uniform batch of 64 S + rem sponges would run
-    // at the two-waves-per-SIMD time (1.96x) although most SIMDs hold one wave.  Launch the first 64 S on their own
-    // (1.0x) and the remainder with whatever suits its size (two-lane 0.68x, rotating schedule 0.8-0.92x).
-    if (forced == 0 && !p.offsets && !p.mask && !p.order && p.n > 64 * simds && p.n < 128 * simds) {
+    // Wave quantisation between one and two one-lane waves per SIMD: with the PLAIN round a uniform batch of 64 S + rem
+    // sponges runs at the two-waves-per-SIMD time (1.96x) although most SIMDs hold one wave, so r01/r02 launched the first
+    // 64 S on their own (1.0x) and the remainder with whatever suits its size (two-lane 0.68x, rotating schedule
+    // 0.8-0.92x).  Since r03 the paired latency-tuned instance (two waves of a SIMD cost 1.32x, not 1.96x) takes the whole
+    // batch in one launch: 73 728 / 81 920 / 98 304 / 114 688 x 1 MiB 92.4 / 92.8 / 99.6 / 103.2 ms against 99.5 / 99.1 /
+    // 99.2 / 109.6 ms for the split (profiles/r03_chipfull.txt).  The split stays behind debug bit 8 (no paired instance).
+    if (forced == 0 && (q.debug_flags & 256) && !p.offsets && !p.mask && !p.order && p.n > 64 * simds && p.n < 128 * simds) {
         auto subrange = [&](uint64_t first, uint64_t count) {
             SpongeParams r = p;
             r.msgs = p.msgs ? p.msgs + first * p.msg_stride : nullptr;

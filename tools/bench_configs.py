@@ -56,7 +56,7 @@ emit(config=2, what="2^20 x KMACXOF256 1 KiB squeeze (64-B keys)", seconds=s, un
 del keys, out
 
 # ---- config 3: sha3_encrypt D512 over 5 MiB messages: 128 per GPU (the 8-GPU split of 1024) and a larger batch
-for nmsg in (128, 512, 2048, 16384):
+for nmsg in (128, 512, 2048, 16384, 32768):
     msgs = rand(nmsg * MIB5, 3)
     pws = rand(nmsg * 64, 31)
     zs = rand(nmsg * 512, 32)
@@ -90,8 +90,11 @@ for nmsg in (128, 512, 2048, 16384):
     perms = MIB5 // 136 + 3
     two_lane_bound = perms * 24 * 120 * 4.04 / 2.38e9
     wide_floor = perms * 24 * (3 * 64 + 22 * 4) / 2.38e9
-    kernel = "sponge_wide_crypt_kernel<17>" if nmsg <= 512 else "sponge_fused_crypt_kernel<17, false>"
-    bound = wide_floor if nmsg <= 512 else two_lane_bound
+    kernel = ("sponge_wide_crypt_kernel<17>" if nmsg <= 512 else "sponge_fused_crypt_kernel<17, false, false>" if nmsg <= 16384
+              else "sponge_fused_crypt_kernel<17, false, true> (two waves per SIMD, blocked round with priority)")
+    # two waves per SIMD on the blocked two-lane round: 2.74 cycles per instruction (profiles/r03_valu_issue_bisect.txt, mix21)
+    paired_bound = perms * 24 * 120 * 2 * 2.74 / 2.38e9
+    bound = wide_floor if nmsg <= 512 else two_lane_bound if nmsg <= 16384 else paired_bound
     emit(config=3, what="sha3_encrypt / sha3_decrypt D512, %d x 5 MiB" % nmsg, enc_seconds=te, dec_seconds=td,
          enc_GiBps=nmsg * MIB5 / te / 2**30, dec_GiBps=nmsg * MIB5 / td / 2**30, roundtrip_ok=ok, kernel=kernel,
          algorithmic_GBps=2 * nmsg * MIB5 / te / 1e9, frac_of_hbm_peak=2 * nmsg * MIB5 / te / 8e12,
