@@ -1699,7 +1699,8 @@ int capy_release_workspace(void)
 int capy_set_sponge_lanes(int lanes)
 {
     // undocumented A/B switches in the high bits; bit 18 of the argument = debug bit 8 (no paired latency-tuned instance)
-    g_debug_flags.store((((unsigned)lanes >> 8) & 0xff) | ((((unsigned)lanes >> 18) & 1) << 8));
+    // bit 19 = debug bit 9 (blocked two-lane round in forced two-lane launches)
+    g_debug_flags.store((((unsigned)lanes >> 8) & 0xff) | ((((unsigned)lanes >> 18) & 3) << 8));
     g_fused_enabled.store((((unsigned)lanes >> 16) & 1) == 0);  // bit 16: disable the fused encrypt kernel
     g_mixed_enabled.store((((unsigned)lanes >> 17) & 1) == 0);  // bit 17: disable the mixed one/two-lane schedule
     lanes &= 0xff;

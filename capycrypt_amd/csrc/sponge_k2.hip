@@ -14,6 +14,11 @@ hipError_t launch_sponge_k2(int rw, int mode, const SpongeParams &p, hipStream_t
         hipLaunchKernelGGL((sponge_kernel_k2<17, 0, 1>), grid, block, 0, s, p);
         return hipGetLastError();
     }
+    if ((p.debug_flags & 512) && rw == 17 && mode == 0) {
+        // A/B (debug bit 9): the blocked round with priority, for forced two-lane launches with two waves per SIMD
+        hipLaunchKernelGGL((sponge_kernel_k2<17, 0, 2>), grid, block, 0, s, p);
+        return hipGetLastError();
+    }
     switch (rw * 2 + mode) {
         CAPY_CASE(9, 0)
         CAPY_CASE(13, 0)

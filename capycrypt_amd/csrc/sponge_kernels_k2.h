@@ -168,6 +168,8 @@ __device__ __forceinline__ void keccakf1600_k2_pipelined(KHalf &s, uint32_t hmas
 
 // BODY 0: fully unrolled permutation with literal round constants in the block loop (default);
 // BODY 1: the rolled two-round form above (A/B instance, selected by debug bit 3 of capy_set_sponge_lanes)
+// BODY 2: the blocked round with raised priority (keccak_round_k2_blocked), for two waves per SIMD (A/B instance for
+//         SHA3-256 digests, forced two-lane launches of more than 32 sponges per SIMD: profiles/r03_chipfull.txt)
 template <int RW, int MODE, int BODY = 0>
 __global__ __launch_bounds__(64) void sponge_kernel_k2(const SpongeParams p)
 {
@@ -263,6 +265,8 @@ __global__ __launch_bounds__(64) void sponge_kernel_k2(const SpongeParams p)
                 if (t < nfull) {
                     if constexpr (BODY == 1)
                         keccakf1600_k2_pipelined(a, hmask);
+                    else if constexpr (BODY == 2)
+                        keccakf1600_k2_paired_unrolled<true>(a, hmask);
                     else
                         keccakf1600_k2_unrolled(a, hmask);
                 }

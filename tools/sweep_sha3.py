@@ -19,7 +19,7 @@ for B,LL,lanes_list in cfgs:
     dig=torch.empty(B*32,dtype=torch.uint8,device=dev)
     _lib.check(lib.capy_fill_random_dev(msgs.data_ptr(),B*LL,1,sp))
     for lanes in lanes_list:
-        lib.capy_set_sponge_lanes(lanes | (int(os.environ.get("DBG","0"))<<8))
+        lib.capy_set_sponge_lanes(lanes | (int(os.environ.get("DBG","0"))<<8) | int(os.environ.get("FLAGS","0")))
         ms=timeit(lambda: _lib.check(lib.capy_sha3_batch_dev(256,B,msgs.data_ptr(),None,LL,LL,dig.data_ptr(),sp)))
         ok = bytes(dig[:32].cpu().numpy())==hashlib.sha3_256(bytes(msgs[:LL].cpu().numpy())).digest()
         print("B=%d L=%d lanes=%d: %.2f ms  %.1f GB/s ok=%s" % (B,LL,lanes,ms,B*LL/(ms*1e-3)/1e9, ok), flush=True)
