@@ -122,6 +122,7 @@ struct Worker {
     std::condition_variable cv;
     std::function<void()> job;
     bool has_job = false, done = false, quit = false;
+    bool release_on_quit = true;  // false at process exit: the HIP runtime may already be shutting down
     void loop()
     {
         g_in_shard = true;  // a worker never shards again: its body is the single-device form of the entry point
@@ -139,8 +140,9 @@ struct Worker {
             done = true;
             cv.notify_all();
         }
+        const bool release = release_on_quit;
         lk.unlock();
-        workspace_release();  // on this thread: its scratch pools and buffer cache
+        if (release) workspace_release();  // on this thread: its scratch pools and buffer cache
     }
     void submit(std::function<void()> f)
     {
@@ -187,6 +189,7 @@ struct WorkerPool {
         for (auto &w : workers) {
             {
                 std::lock_guard<std::mutex> lk(w->mu);
+                w->release_on_quit = false;
                 w->quit = true;
                 w->cv.notify_all();
             }
