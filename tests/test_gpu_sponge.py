@@ -495,9 +495,12 @@ def test_kmac_rotating_schedule_with_per_item_keys(capy, O, sponge_lanes):
 
 
 def test_wave_quantisation_split_matches_one_lane(capy, O, sponge_lanes):
-    """Uniform batches between 64 and 128 sponges per SIMD are launched as a full-chip head + a remainder
-    (sponge.hip: launch_sponge).  Automatic choice vs forced one-lane kernel: digests, KMAC outputs and the two-pass
-    encrypt (keystream XOR mode) must agree for every item, and with the oracle for a sample."""
+    """Uniform batches between 64 and 128 sponges per SIMD: since r03 ONE launch of the paired latency-tuned instance
+    (blocked round with priority; digest and keystream-XOR modes) -- the automatic choice --, before that a full-chip
+    head + a remainder on the two-lane kernel (sponge.hip: launch_sponge; still reachable with bit 18 of
+    capy_set_sponge_lanes, which also selects the plain round).  Forced one-lane, automatic and split launches must agree
+    for every item in digests, KMAC outputs and sha3_encrypt (fused paired kernel / two-pass with bit 16), and with the
+    oracle for a sample."""
     import torch
 
     from capycrypt_amd import _lib
@@ -510,7 +513,7 @@ def test_wave_quantisation_split_matches_one_lane(capy, O, sponge_lanes):
     keys = _dev_rand(n * 64, 42)
     zs = _dev_rand(n * 512, 43)
     res = []
-    for lanes in (1, 0):
+    for lanes in (1, 0, 1 << 18, (1 << 18) | (1 << 16), 1 << 16):
         _lib.check(lib.capy_set_sponge_lanes(lanes))
         dig = torch.zeros(n * 32, dtype=torch.uint8, device="cuda")
         out = torch.zeros(n * 64, dtype=torch.uint8, device="cuda")
@@ -523,8 +526,10 @@ def test_wave_quantisation_split_matches_one_lane(capy, O, sponge_lanes):
                                                    stride, tags.data_ptr(), None))
         torch.cuda.synchronize()
         res.append((dig, out, work, tags))
-    for a, b in zip(res[0], res[1]):
-        assert torch.equal(a, b)
+    _lib.check(lib.capy_set_sponge_lanes(1))
+    for other in res[1:]:
+        for a, b in zip(res[0], other):
+            assert torch.equal(a, b)
     host, hk, hz = bytes(msgs.cpu().numpy()), bytes(keys.cpu().numpy()), bytes(zs.cpu().numpy())
     hd, hc, ht = (bytes(t.cpu().numpy()) for t in (res[1][0], res[1][2], res[1][3]))
     for i in (0, 65535, 65536, 65537, n - 1):
