@@ -105,6 +105,46 @@ def test_config3_per_gpu_share_round_trips():
     assert torch.equal(m2[ok.cuda()], p2[ok.cuda()]) and torch.equal(m2[77], c2[77])
 
 
+def test_config3_saturating_batch_fused_paired_kernel(O=None):
+    """Config 3's GPU-saturating variant: 32 768 x 1 MiB through sha3_encrypt -- two waves per SIMD of the fused
+    four-lane kernel on the blocked round with priority (r03).  Every tag must equal the two-pass form's (tag kernel +
+    keystream kernel, bit 16 of capy_set_sponge_lanes), every ciphertext byte too; decrypt restores every plaintext byte;
+    two items are checked against the oracle."""
+    import torch
+
+    from capycrypt_amd import _lib
+    from oracle import oracle
+
+    lib = _lib.lib()
+    n, L = 32768, 1 << 20
+    plain = _rand(n * L, 0xCA9C0013)
+    pws, zs = _rand(n * 64, 33), _rand(n * 512, 34)
+    outs = []
+    try:
+        for flags in (0, 1 << 16):
+            _lib.check(lib.capy_set_sponge_lanes(flags))
+            work = plain.clone()
+            tags = torch.zeros(n * 64, dtype=torch.uint8, device="cuda")
+            _lib.check(lib.capy_sha3_encrypt_batch_dev(512, n, pws.data_ptr(), 64, None, 0, zs.data_ptr(), work.data_ptr(), None, L, L,
+                                                       tags.data_ptr(), None))
+            torch.cuda.synchronize()
+            outs.append((work, tags))
+    finally:
+        _lib.check(lib.capy_set_sponge_lanes(0))
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][0], outs[1][0])
+    work, tags = outs[0]
+    del outs
+    hp, hz, ht = bytes(pws.cpu().numpy()), bytes(zs.cpu().numpy()), bytes(tags.cpu().numpy())
+    for i in (0, n - 1):
+        ect, etag = oracle.sha3_encrypt(hp[64 * i:64 * i + 64], hz[512 * i:512 * i + 512], bytes(plain[i * L:(i + 1) * L].cpu().numpy()), 512)
+        assert bytes(work[i * L:(i + 1) * L].cpu().numpy()) == ect and ht[64 * i:64 * i + 64] == etag, i
+    status = torch.full((n,), 5, dtype=torch.int32, device="cuda")
+    _lib.check(lib.capy_sha3_decrypt_batch_dev(512, n, pws.data_ptr(), 64, None, 0, zs.data_ptr(), work.data_ptr(), None, L, L,
+                                               tags.data_ptr(), status.data_ptr(), None))
+    torch.cuda.synchronize()
+    assert int(status.sum().item()) == 0 and torch.equal(work, plain)
+
+
 def test_config5_full_batch_sign_then_verify():
     """2^16 x 1 KiB: every signature verifies; after flipping one message byte exactly that item fails; a sample of
     signatures equals the oracle's."""
