@@ -184,6 +184,68 @@ def stream(spec, target=512):
     return lines, per * reps
 
 
+# ---- VERDICT r2 item 6, one bounded probe: the TIMING skeleton (dependencies as in the real round, values meaningless) of
+# (a) today's wave-per-item round (sponge_wide.h: three dependent LDS round trips, 18 ds_bpermute + ~22 VALU) and
+# (b) the proposed round with the theta / chi neighbourhoods on DPP row operations and v_permlane{16,32}_swap, planes laid
+#     out 8 lanes apart, and only pi left on ds_bpermute -- to decide whether (b) is worth building (bar: 1.25x).
+def wide_today():
+    L = []
+    # theta trip 1: 4 + 4 gathers of the column, parity
+    for h in (8, 9):
+        for k in range(4):
+            L.append(f"ds_bpermute_b32 v{10 + 4 * (h - 8) + k}, v{40 + k}, v{h}")
+    L.append("s_waitcnt lgkmcnt(0)")
+    L += ["v_bitop3_b32 v18, v8, v10, v11 bitop3:0x96", "v_bitop3_b32 v18, v18, v12, v13 bitop3:0x96",
+          "v_bitop3_b32 v19, v9, v14, v15 bitop3:0x96", "v_bitop3_b32 v19, v19, v16, v17 bitop3:0x96"]
+    # trip 2: C[x-1], C[x+1]
+    L += ["ds_bpermute_b32 v20, v44, v18", "ds_bpermute_b32 v21, v44, v19", "ds_bpermute_b32 v22, v45, v18", "ds_bpermute_b32 v23, v45, v19",
+          "s_waitcnt lgkmcnt(0)"]
+    L += ["v_alignbit_b32 v24, v22, v23, 31", "v_alignbit_b32 v25, v23, v22, 31", "v_bitop3_b32 v26, v8, v20, v24 bitop3:0x96",
+          "v_bitop3_b32 v27, v9, v21, v25 bitop3:0x96"]
+    # rho: selects + rotation by a per-lane amount + selects
+    L += ["v_bitop3_b32 v28, v27, v26, v46 bitop3:0xca", "v_bitop3_b32 v29, v26, v27, v46 bitop3:0xca", "v_alignbit_b32 v30, v28, v29, v47",
+          "v_alignbit_b32 v31, v29, v28, v47", "v_bitop3_b32 v26, v28, v30, v34 bitop3:0xca", "v_bitop3_b32 v27, v29, v31, v34 bitop3:0xca"]
+    # trip 3: pi + chi gathers
+    for h, src in ((0, 26), (1, 27)):
+        for k in range(3):
+            L.append(f"ds_bpermute_b32 v{10 + 3 * h + k}, v{48 + k}, v{src}")
+    L.append("s_waitcnt lgkmcnt(0)")
+    L += ["v_bitop3_b32 v8, v10, v11, v12 bitop3:0xd2", "v_bitop3_b32 v9, v13, v14, v15 bitop3:0xd2",
+          "v_bitop3_b32 v8, v8, v35, v36 bitop3:0x78", "v_bitop3_b32 v9, v9, v35, v37 bitop3:0x78"]
+    return L
+
+
+def wide_proposed():
+    L = []
+    row = "row_mask:0xf bank_mask:0xf bound_ctrl:1"
+    for h, t in ((8, 10), (9, 14)):  # parity over the five planes: in-row pair, then the two swaps
+        L += [f"v_and_b32 v{t}, v{h}, v33", f"v_mov_b32_dpp v{t + 1}, v{t} row_ror:8 {row}", f"v_xor_b32 v{t}, v{t}, v{t + 1}",
+              f"v_mov_b32 v{t + 1}, v{t}", f"v_permlane16_swap_b32 v{t}, v{t + 1}", f"v_xor_b32 v{t}, v{t}, v{t + 1}",
+              f"v_mov_b32 v{t + 1}, v{t}", f"v_permlane32_swap_b32 v{t}, v{t + 1}", f"v_xor_b32 v{t}, v{t}, v{t + 1}"]
+    for t, o in ((10, 18), (14, 22)):  # C[x-1], C[x+1]: two DPP moves + a select each (the wrap-around lanes)
+        L += [f"v_mov_b32_dpp v{o}, v{t} row_shr:1 {row}", f"v_mov_b32_dpp v{o + 1}, v{t} row_shl:4 {row}",
+              f"v_bitop3_b32 v{o}, v{o}, v{o + 1}, v38 bitop3:0xca",
+              f"v_mov_b32_dpp v{o + 2}, v{t} row_shl:1 {row}", f"v_mov_b32_dpp v{o + 3}, v{t} row_shr:4 {row}",
+              f"v_bitop3_b32 v{o + 2}, v{o + 2}, v{o + 3}, v39 bitop3:0xca"]
+    L += ["v_alignbit_b32 v26, v20, v24, 31", "v_alignbit_b32 v27, v24, v20, 31", "v_bitop3_b32 v28, v8, v18, v26 bitop3:0x96",
+          "v_bitop3_b32 v29, v9, v22, v27 bitop3:0x96"]
+    L += ["v_bitop3_b32 v30, v29, v28, v46 bitop3:0xca", "v_bitop3_b32 v31, v28, v29, v46 bitop3:0xca", "v_alignbit_b32 v10, v30, v31, v47",
+          "v_alignbit_b32 v11, v31, v30, v47", "v_bitop3_b32 v28, v30, v10, v34 bitop3:0xca", "v_bitop3_b32 v29, v31, v11, v34 bitop3:0xca"]
+    L += ["ds_bpermute_b32 v12, v48, v28", "ds_bpermute_b32 v13, v48, v29", "s_waitcnt lgkmcnt(0)"]
+    for b, o in ((12, 14), (13, 16)):  # chi neighbours by row shifts (the pi gather fills the replica lanes)
+        L += [f"v_mov_b32_dpp v{o}, v{b} row_shl:1 {row}", f"v_mov_b32_dpp v{o + 1}, v{b} row_shl:2 {row}"]
+    L += ["v_bitop3_b32 v8, v12, v14, v15 bitop3:0xd2", "v_bitop3_b32 v9, v13, v16, v17 bitop3:0xd2",
+          "v_bitop3_b32 v8, v8, v35, v36 bitop3:0x78", "v_bitop3_b32 v9, v9, v35, v37 bitop3:0x78"]
+    # inline asm gets no hazard handling: a DPP / permlane read of a VGPR written by the previous VALU instruction needs two
+    # wait states on gfx9-class hardware (the compiler would insert the same s_nop)
+    out = []
+    for k, ins in enumerate(L):
+        if ("_dpp" in ins or "permlane" in ins) and k and not L[k - 1].startswith(("v_mov_b32_dpp", "s_")):
+            out.append("s_nop 1")
+        out.append(ins)
+    return out
+
+
 kernels = []  # (ident, label, lines, count)
 for i, op in enumerate(OPS):
     lines = block(op, 512)
@@ -191,6 +253,10 @@ for i, op in enumerate(OPS):
 for i, (label, spec) in enumerate(MIXES.items()):
     lines, n = stream(spec)
     kernels.append(("mix%d" % i, label, lines, n))
+
+for ident, label, fn in (("wide0", "wide round today (18 bpermute, 3 trips) x8 [rounds]", wide_today),
+                         ("wide1", "wide round proposed (DPP + permlane swaps, 2 bpermute) x8 [rounds]", wide_proposed)):
+    kernels.append((ident, label, fn() * 8, 8))  # count = rounds per trip: the table then reads ns and cycles PER ROUND
 
 out = []
 w = out.append
@@ -204,11 +270,14 @@ init = '"v_mov_b32 v8, %0\\n\\t" ' + " ".join("INITR(%d, %d)" % (r, r - 1) for r
 for ident, label, lines, n in kernels:
     body = "\\n\\t".join(lines)
     w(f"// {label}")
-    w(f"__global__ __launch_bounds__(256) void k_{ident}(Rec *rec, unsigned iters, unsigned m, unsigned long long *sink)")
+    w(f"__global__ __launch_bounds__(256) void k_{ident}(Rec *rec, unsigned iters, unsigned m, unsigned long long *sink, unsigned active)")
     w("{")
+    w("    if (threadIdx.x >= active) return;  // active = 64: one wave per workgroup (per CU at W = 1), the others leave")
     w("    const unsigned seed = ((blockIdx.x * 256 + threadIdx.x) * 2654435761u | 1u) & m;")
     w(f"    asm volatile({init} : : \"v\"(seed), \"s\"(0x9E3779B1u) : CLOB);")
     w('    asm volatile("s_mov_b32 s10, 0x55555555\\n\\ts_mov_b32 s11, 0x33333333\\n\\ts_mov_b64 vcc, s[10:11]" ::: "s10", "s11", "vcc");')
+    if ident.startswith("wide"):
+        w('    asm volatile("' + "\\n\\t".join("v_and_b32 v%d, 0xfc, v%d" % (r, r) for r in range(40, 51)) + '" ::: CLOB);')
     w("    unsigned long long t0, t1, r0, r1; unsigned hwid, xcc;")
     w('    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\\n\\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hwid), "=s"(xcc));')
     w('    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\\n\\ts_memrealtime %0\\n\\ts_memtime %1\\n\\ts_waitcnt lgkmcnt(0)" : "=s"(r0), "=s"(t0)::"memory");')
@@ -220,7 +289,7 @@ for ident, label, lines, n in kernels:
     w("    unsigned x; asm volatile(\"v_xor_b32 %0, v48, v63\" : \"=v\"(x)::CLOB);")
     w("    if (x == 0x12345678u && m == 0x5a5a5a5au) atomicXor(sink, (unsigned long long)x);")
     w("}")
-w("typedef void (*kfn)(Rec *, unsigned, unsigned, unsigned long long *);")
+w("typedef void (*kfn)(Rec *, unsigned, unsigned, unsigned long long *, unsigned);")
 w("struct Ent { const char *ident; const char *label; kfn f; int count; };")
 w("static Ent ents[] = {")
 for ident, label, lines, n in kernels:
@@ -231,6 +300,7 @@ int main(int argc, char **argv)
 {
     const char *filter = argc > 1 ? argv[1] : "";
     const int wmax = argc > 2 ? atoi(argv[2]) : 4;
+    const unsigned active = argc > 3 ? (unsigned)atoi(argv[3]) : 256u;  // 64: only the first wave of every workgroup works
     Rec *rec;
     unsigned long long *sink;
     (void)hipMalloc(&rec, sizeof(Rec) * 8192);
@@ -242,16 +312,16 @@ int main(int argc, char **argv)
     for (auto &e : ents) {
         if (*filter && !strstr(e.label, filter) && !strstr(e.ident, filter)) continue;
         printf("%-6s %-42s %5d", e.ident, e.label, e.count);
-        const unsigned iters = 12000u * 512u / (unsigned)e.count;
+        const unsigned iters = e.count <= 16 ? 6000u : 12000u * 512u / (unsigned)e.count;
         for (int W = 1; W <= wmax; W *= 2) {
             const int blocks = 256 * W, waves = blocks * 4;
-            hipLaunchKernelGGL(e.f, dim3(blocks), dim3(256), 0, 0, rec, 20u, 0xffffffffu, sink);
+            hipLaunchKernelGGL(e.f, dim3(blocks), dim3(256), 0, 0, rec, 20u, 0xffffffffu, sink, active);
             (void)hipDeviceSynchronize();
             hipEvent_t e0, e1;
             (void)hipEventCreate(&e0);
             (void)hipEventCreate(&e1);
             (void)hipEventRecord(e0);
-            hipLaunchKernelGGL(e.f, dim3(blocks), dim3(256), 0, 0, rec, iters, 0xffffffffu, sink);
+            hipLaunchKernelGGL(e.f, dim3(blocks), dim3(256), 0, 0, rec, iters, 0xffffffffu, sink, active);
             (void)hipEventRecord(e1);
             (void)hipDeviceSynchronize();
             float ms = 0;
