@@ -80,6 +80,23 @@ void ht_sc_mul4_mod(const uint8_t *a, uint8_t *out)
     sc_mul4_mod(r, x);
     sc_to_be(out, r);
 }
+// the scalar arithmetic of Signable::sign under the three readings of the curve crate's `*` / `-` (ed448_algo.h)
+void ht_sc_star4(const uint8_t *a, int star, uint8_t *out)
+{
+    uint32_t x[14], r[14];
+    sc_from_be(x, a);
+    sc_star4(r, x, star);
+    sc_to_be(out, r);
+}
+void ht_sc_sign_z(const uint8_t *k, const uint8_t *h, const uint8_t *s, int star, uint8_t *out)
+{
+    uint32_t kk[14], hh[14], ss[14], z[14];
+    sc_from_be(kk, k);
+    sc_from_be(hh, h);
+    sc_from_be(ss, s);
+    sc_sign_z(z, kk, hh, ss, star);
+    sc_to_be(out, z);
+}
 // fixed-base table built on the host with the same entry format the device uses
 static std::vector<uint32_t> g_tab;
 static const uint32_t *gtab_aligned() { return (const uint32_t *)(((uintptr_t)g_tab.data() + 15) & ~(uintptr_t)15); }

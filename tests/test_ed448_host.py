@@ -116,6 +116,21 @@ def test_scalar_field(L):
         assert call(L, "ht_sc_mul4_mod", E.sc_to_bytes(a)) == E.sc_to_bytes(4 * a % E.R)
 
 
+def test_sign_scalars_under_every_reading_of_the_star(L):
+    """sc_star4 / sc_sign_z (ed448_algo.h: what sc_star4_kernel and sc_sign_z_kernel run) against the python model
+    ed448_ref.schnorr_scalars for the three readings of `bytes_to_scalar(k_bytes) * Scalar::from(4)` and of the `-` that
+    consumes it (/root/reference/src/ecc/signable.rs:46,54): random and extreme kb (wrapping and not), h, s."""
+    rng = random.Random(0x57A4)
+    kbs = [0, 1, 2**446 - 1, 2**446, 2**447, 2**448 - 1, E.R, E.R - 1, (E.R + 3) // 4] + [rng.getrandbits(448) for _ in range(200)]
+    for kb in kbs:
+        h, s = rng.getrandbits(448), rng.randrange(E.R)
+        for star in (0, 1, 2):
+            k, z = E.schnorr_scalars(kb, h, s, star)
+            kbytes = call(L, "ht_sc_star4", E.sc_to_bytes(kb), star)
+            assert kbytes == k.to_bytes(56, "big"), (star, kb)
+            assert call(L, "ht_sc_sign_z", kbytes, E.sc_to_bytes(h), E.sc_to_bytes(s), star) == z.to_bytes(56, "big"), (star, kb)
+
+
 def test_pair_affine_shares_one_inversion(L):
     """pt_pair_to_affine_bytes == two independent conversions, for random projective representatives, Z = 1, Z = p
     (non-canonical zero) and Z = 0 (an invalid point must not spoil its partner and still yields (0, 0))."""
