@@ -122,7 +122,6 @@ struct Worker {
     std::condition_variable cv;
     std::function<void()> job;
     bool has_job = false, done = false, quit = false;
-    bool release_on_quit = true;  // false at process exit: the HIP runtime may already be shutting down
     void loop()
     {
         g_in_shard = true;  // a worker never shards again: its body is the single-device form of the entry point
@@ -140,9 +139,8 @@ struct Worker {
             done = true;
             cv.notify_all();
         }
-        const bool release = release_on_quit;
         lk.unlock();
-        if (release) workspace_release();  // on this thread: its scratch pools and buffer cache
+        workspace_release();  // on this thread: its scratch pools and buffer cache (the list changed; the runtime is alive)
     }
     void submit(std::function<void()> f)
     {
@@ -185,16 +183,12 @@ struct WorkerPool {
     }
     ~WorkerPool()
     {
-        // process exit: the HIP runtime may already be shutting down; let the workers end without touching it
+        // Process exit: the HIP runtime may already be shutting down, so the workers must not run their scratch release
+        // (nor the thread-local destructors that free device memory).  They are left blocked on their condition
+        // variables -- the process ends them -- and their Worker objects are deliberately not destroyed.
         for (auto &w : workers) {
-            {
-                std::lock_guard<std::mutex> lk(w->mu);
-                w->release_on_quit = false;
-                w->quit = true;
-                w->cv.notify_all();
-            }
             if (w->th.joinable()) w->th.detach();
-            (void)w.release();  // the detached thread may still look at its Worker
+            (void)w.release();
         }
     }
 };
