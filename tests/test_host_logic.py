@@ -397,3 +397,27 @@ def test_header_is_plain_c(tmp_path):
                            "-o", str(exe), "-L", libdir, "-lcapyhip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0 and int(out.stdout) == len(names)
+
+
+def test_bench_helpers_on_the_cpu():
+    """bench.py pieces that do not need a GPU: the digest over all device sources (a profiles/*_pmc_summary.json is only
+    trusted on the build it was taken on), the CPU count the cpu_baseline leg uses, and the ceilings of DESIGN 4.0."""
+    import glob
+    import json
+
+    import bench
+
+    d = bench.kernel_source_digest()
+    assert len(d) == 16 and d == bench.kernel_source_digest()
+    assert 1 <= bench.usable_cpus() <= len(os.sched_getaffinity(0))
+    # one wave per SIMD: 4 cycles for each of the 4320 instructions; many waves: 58 four-cycle + 122 two-cycle per round
+    assert abs(bench.VALU_ARCH_CEIL_ONE_WAVE_GBS - 1024 * 2.4e9 / (4 * 4320) * 64 * 136 / 1e9) < 1e-6
+    assert abs(bench.VALU_ARCH_CEIL_GBS - 1024 * 2.4e9 / (476 * 24) * 64 * 136 / 1e9) < 1e-6
+    assert bench.VALU_ARCH_CEIL_ONE_WAVE_GBS < bench.VALU_ARCH_CEIL_GBS < bench.HBM_PEAK_GBS
+    # the committed summary of this round belongs to the committed sources
+    newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))[-1]
+    with open(newest) as f:
+        if json.load(f)["_meta"]["kernel_source_digest"] != d:  # a reminder, not a failure: bench.py then reports traffic = null
+            import warnings
+
+            warnings.warn("%s was taken on other kernel sources: re-run tools/refresh_profiles.sh" % os.path.basename(newest))
