@@ -510,7 +510,10 @@ static const size_t FUSED_MAX_ITEMS = [] {
 //                    latency-tuned instance
 
 static std::atomic<bool> g_mixed_enabled{true};
-// largest batch that takes the one-wave-per-item encrypt kernel: half a wave per SIMD (CAPY_WIDE_MAX overrides)
+// largest batch that takes the one-wave-per-item encrypt kernel: one wave per SIMD (the digest kernel holds two items per
+// wave, so twice as many).  Measured r03 with the DPP theta (profiles/r03_wide_round_probe.txt): at one wave per SIMD the
+// wave-per-item kernels still win 1.2-1.3x (1024 x 5 MiB encrypt 0.163 s vs 0.211, 2048 x 5 MiB digest 0.164 vs 0.198),
+// at 1.5 waves per SIMD they lose (0.88x).  CAPY_WIDE_MAX overrides
 static size_t wide_max_items();
 
 // SIMDs of the current device (4 per CU)
@@ -535,7 +538,7 @@ static size_t wide_max_items()
         const char *e = getenv("CAPY_WIDE_MAX");
         return e ? atol(e) : -1L;
     }();
-    return forced >= 0 ? (size_t)forced : device_simds() / 2;
+    return forced >= 0 ? (size_t)forced : device_simds();
 }
 
 // speed of the two-lane form relative to the one-lane form, per sponge, when both share the chip at one wave per SIMD.

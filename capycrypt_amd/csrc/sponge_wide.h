@@ -4,12 +4,13 @@
 // chain of ~38 553 permutations, on a chip with 1024 SIMDs.  Nothing but the latency of one permutation matters
 // there.  The two-lane form of sponge_fused.h issues 120 VALU instructions per round per sponge pair (~4.8 us per
 // permutation); this kernel spreads a sponge over 25 lanes -- one 64-bit Keccak lane per GPU lane -- so that a round
-// is ~22 VALU instructions plus 18 ds_bpermute_b32 in three dependent LDS round trips (measured 3.7 us per
-// permutation at one wave per 8 SIMDs, tools/probe_wide.hip, profiles/r02_wide_lane_probe.txt: 1.31x).
+// is ~22 VALU instructions plus 14 ds_bpermute_b32 in two dependent LDS round trips (3.16 us per permutation, r03;
+// 3.7-3.8 us with 18 gathers in three trips in r02: tools/probe_wide.hip, profiles/r02_wide_lane_probe.txt,
+// profiles/r03_wide_round_probe.txt).
 //
 //   lanes  0..24   tag sponge        kmac_xof(ka, m, 8 tag_len, "..A")       Keccak lane i = x + 5y in GPU lane i
 //   lanes 32..56   keystream sponge  kmac_xof(ke, "", |m|, "..E") XOR m      same layout at lane offset 32
-//   theta   column parity: 4 + 4 gathers from rows y+1..y+4, then C[x-1], C[x+1]: 2 + 2 gathers
+//   theta   column parity: 4 + 4 gathers from rows y+1..y+4, then C[x-1], C[x+1]: whole-wave DPP rotations by one lane
 //   rho     the lane's own rotation amount: v_alignbit_b32 with a VGPR shift, selects for >= 32 and for 0
 //   pi+chi  B[x], B[x+1], B[x+2] gathered straight from the rho output (pi folded into the gather index): 3 + 3
 // Message blocks need no staging: GPU lane i < RW loads word i of the block (both sponges read the same 8 RW bytes),
@@ -36,10 +37,10 @@ __device__ __forceinline__ uint32_t wide_sel(uint32_t m, uint32_t a, uint32_t b)
 
 struct WideIdx {
     uint32_t up[4];                 // byte index of GPU lane (x, y+k), k = 1..4
-    uint32_t xm1, xp1;              // (x-1, y), (x+1, y)
     uint32_t b0, b1, b2;            // pi sources of B[x], B[x+1], B[x+2] in row y
     uint32_t sh;                    // alignbit shift of the lane's rho offset r: (32 - r % 32) % 32
     uint32_t m_swap, m_zero, m_l0;  // all-ones masks: r >= 32, r % 32 == 0, "this is Keccak lane 0"
+    uint32_t self;                  // byte index of the lane whose state this lane holds (itself, or the lane it mirrors)
 };
 
 __device__ __forceinline__ uint32_t wide_rho(uint32_t i)
@@ -51,18 +52,37 @@ __device__ __forceinline__ uint32_t wide_rho(uint32_t i)
     return r;
 }
 
+// Which Keccak lane a GPU lane stands for.  Lanes 0..24 / 32..56 are the two sponges; the idle lanes MIRROR a lane
+// (same index registers, so they compute the same values).  Four of them are placed where the whole-wave rotations of
+// theta wrap to (r03): the column parity C does not depend on y, so in the x + 5y layout lane i - 1 / i + 1 always holds
+// C[x - 1] / C[x + 1] -- except at the ends of a sponge's 25 lanes, where the rotation reads an idle lane:
+//   lane 63 mirrors (4, 0) of the lower sponge   (wave_ror:1 feeds lane 0 from lane 63)
+//   lane 25 mirrors (0, 0) of the lower sponge   (wave_rol:1 feeds lane 24 from lane 25)
+//   lane 31 mirrors (4, 0) of the upper sponge   (lane 32 <- lane 31)
+//   lane 57 mirrors (0, 0) of the upper sponge   (lane 56 <- lane 57)
+// the other idle lanes mirror (4, 4) of their own half as before; nobody reads them.
 __device__ __forceinline__ WideIdx wide_setup()
 {
-    const uint32_t lane = threadIdx.x & 63, base = lane & 32;
-    uint32_t i = lane & 31;
-    if (i > 24) i = 24;  // lanes 25..31 of each half mirror lane 24; their values are never read
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t base = lane & 32, i = lane & 31;
+    if (lane == 63) {
+        base = 0;
+        i = 4;
+    } else if (lane == 25) {
+        i = 0;
+    } else if (lane == 31) {
+        base = 32;
+        i = 4;
+    } else if (lane == 57) {
+        i = 0;
+    } else if (i > 24) {
+        i = 24;
+    }
     const uint32_t x = i % 5, y = i / 5;
     auto at = [&](uint32_t xx, uint32_t yy) { return 4 * (base + (xx % 5) + 5 * (yy % 5)); };
     WideIdx w;
 #pragma unroll
     for (int k = 0; k < 4; k++) w.up[k] = at(x, y + 1 + k);
-    w.xm1 = at(x + 4, y);
-    w.xp1 = at(x + 1, y);
     auto src = [&](uint32_t X, uint32_t Y) { return at((X + 3 * Y) % 5, X % 5); };  // B[X,Y] = rho(E)[(X+3Y)%5, X]
     w.b0 = src(x, y);
     w.b1 = src(x + 1, y);
@@ -71,9 +91,15 @@ __device__ __forceinline__ WideIdx wide_setup()
     w.sh = (32 - (r & 31)) & 31;
     w.m_swap = r >= 32 ? ~0u : 0u;
     w.m_zero = (r & 31) == 0 ? ~0u : 0u;
-    w.m_l0 = (lane & 31) == 0 ? ~0u : 0u;
+    w.m_l0 = i == 0 ? ~0u : 0u;
+    w.self = 4 * (base + i);
     return w;
 }
+
+// whole-wave rotations by one lane (DPP_WF_RR1 / DPP_WF_RL1): lane i <- lane i - 1 (lane 0 <- lane 63) / lane i <- lane i + 1
+// (every lane has a source, so there is no "old" value to keep: mov_dpp, not update_dpp with a zero to materialise)
+__device__ __forceinline__ uint32_t wave_ror1(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x13C, 0xF, 0xF, false); }
+__device__ __forceinline__ uint32_t wave_rol1(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x134, 0xF, 0xF, false); }
 
 __device__ __forceinline__ void wide_round(uint32_t &lo, uint32_t &hi, const WideIdx &w, uint32_t rc_lo, uint32_t rc_hi)
 {
@@ -83,8 +109,10 @@ __device__ __forceinline__ void wide_round(uint32_t &lo, uint32_t &hi, const Wid
     const uint32_t h0 = wide_bperm(w.up[0], hi), h1 = wide_bperm(w.up[1], hi), h2 = wide_bperm(w.up[2], hi),
                    h3 = wide_bperm(w.up[3], hi);
     const uint32_t cl = xor3(xor3(lo, g0, g1), g2, g3), ch = xor3(xor3(hi, h0, h1), h2, h3);
-    const uint32_t ml = wide_bperm(w.xm1, cl), mh = wide_bperm(w.xm1, ch), pl = wide_bperm(w.xp1, cl),
-                   ph = wide_bperm(w.xp1, ch);
+    // C[x - 1] and C[x + 1] by whole-wave rotations instead of a second LDS round trip (four DPP moves for four
+    // ds_bpermute + a wait: timing skeletons 404 -> 338 cycles per round at one wave per CU,
+    // profiles/r03_wide_round_probe.txt); the lanes the rotation wraps to mirror the right columns (wide_setup)
+    const uint32_t ml = wave_ror1(cl), mh = wave_ror1(ch), pl = wave_rol1(cl), ph = wave_rol1(ch);
     const uint32_t rl = __builtin_amdgcn_alignbit(pl, ph, 31), rh = __builtin_amdgcn_alignbit(ph, pl, 31);  // rol 1
     uint32_t el = xor3(lo, ml, rl), eh = xor3(hi, mh, rh);
     // rho: rotate left by this lane's own offset
@@ -92,7 +120,7 @@ __device__ __forceinline__ void wide_round(uint32_t &lo, uint32_t &hi, const Wid
     const uint32_t ra = __builtin_amdgcn_alignbit(a, b, w.sh), rb = __builtin_amdgcn_alignbit(b, a, w.sh);
     el = wide_sel(w.m_zero, a, ra);
     eh = wide_sel(w.m_zero, b, rb);
-    // pi + chi
+    // pi + chi (the gathers read lanes 0..24 / 32..56 only, so a mirroring lane ends the round with its original's state)
     const uint32_t b0l = wide_bperm(w.b0, el), b1l = wide_bperm(w.b1, el), b2l = wide_bperm(w.b2, el);
     const uint32_t b0h = wide_bperm(w.b0, eh), b1h = wide_bperm(w.b1, eh), b2h = wide_bperm(w.b2, eh);
     lo = xor_and(chi3(b0l, b1l, b2l), rc_lo, w.m_l0);
@@ -106,6 +134,10 @@ __device__ __forceinline__ void wide_permute_impl(uint32_t &lo, uint32_t &hi, co
 }
 __device__ __forceinline__ void wide_permute(uint32_t &lo, uint32_t &hi, const WideIdx &w)
 {
+    // the mirroring lanes take their original's state (absorbed words, restored states: whatever happened between two
+    // permutations happened in lanes 0..24 / 32..56): two gathers per permutation
+    lo = wide_bperm(w.self, lo);
+    hi = wide_bperm(w.self, hi);
     wide_permute_impl(lo, hi, w, std::make_integer_sequence<int, 24>{});
 }
 
@@ -283,7 +315,7 @@ namespace capy {
 // of long messages: two items per wave (lanes 0..24 and 32..56), each sponge spread over 25 lanes as above.  The
 // reference's own benches and integration tests hash / sign ONE 5 MiB message at a time
 // (benches/benchmark_sha3.rs:11-19, tests/integration_tests.rs:62-81): a batch that small is nothing but one serial
-// chain per sponge, and this form runs the chain 1.3x faster than the two-lane kernel.
+// chain per sponge, and this form runs the chain 1.6x faster than the two-lane kernel.
 //
 // Same SpongeParams and stream semantics as sponge_kernel / sponge_kernel_k2 (shared prefix folded into init_state,
 // per-item head, body, suffix, pad; every reference quirk is a parameter of the framing), except that raw prefix bytes
@@ -340,28 +372,51 @@ __global__ __launch_bounds__(64) void sponge_wide_digest_kernel(const SpongePara
         }
     }
 
-    // ---- absorb: step s handles block s of both items
+    // ---- absorb: step s handles block s of both items.  A half is FAST at step s when its block s is a directly loaded
+    // body block, IDLE when its item is finished (or the half is empty); while every half is one or the other the wave
+    // runs the tight loop (a load, an XOR, the permutation -- the generic step's framing logic costs 5-8 % of a block,
+    // profiles/r03_wide_round_probe.txt), otherwise one generic step.  A finished half's state is set aside once
+    // (flo, fhi) instead of being restored after every wave-wide permutation.
     const uint32_t steps = wave_max_u32(nb);
     const uint8_t *my = c.msg ? c.msg + 8 * i : nullptr;
+    const uint32_t fast_end = hb + nfull;
     uint64_t pf = 0;
+    uint32_t flo = lo, fhi = hi;
     if (word_lane && nfull && hb == 0) pf = load_global_u64(my);
-    for (uint32_t s = 0; s < steps; s++) {
-        const bool fast = s >= hb && s - hb < nfull;
+    uint32_t s = 0;
+    while (s < steps) {  // wave-uniform
+        const bool fast = s >= hb && s < fast_end;
+        if (wave_max_u32((fast || s >= nb) ? 0u : 1u) == 0) {
+            const uint32_t end = ~wave_max_u32(~(fast ? fast_end : steps));  // first step at which some half leaves its range
+            const bool mine = word_lane && fast;
+            for (; s < end; s++) {
+                const uint64_t word = pf;
+                if (mine && s + 1 < fast_end) pf = load_global_u64(my + (uint64_t)(s + 1 - hb) * RB);
+                if (mine) {
+                    lo ^= (uint32_t)word;
+                    hi ^= (uint32_t)(word >> 32);
+                }
+                wide_permute(lo, hi, w);
+            }
+            continue;
+        }
         uint64_t word = pf;
         // the block after this one, while this one is permuted
-        if (word_lane && s + 1 >= hb && s + 1 - hb < nfull) pf = load_global_u64(my + (uint64_t)(s + 1 - hb) * RB);
+        if (word_lane && s + 1 >= hb && s + 1 < fast_end) pf = load_global_u64(my + (uint64_t)(s + 1 - hb) * RB);
         if (!fast) word = (word_lane && s < nb) ? stream_word(p, c, (uint64_t)s * RB + 8 * i) : 0;
-        const uint32_t klo = lo, khi = hi;
         if (word_lane && s < nb) {
             lo ^= (uint32_t)word;
             hi ^= (uint32_t)(word >> 32);
         }
         wide_permute(lo, hi, w);
-        if (s >= nb) {  // my item is done (or this half is empty): keep the state across the other half's steps
-            lo = klo;
-            hi = khi;
+        if (s + 1 == nb) {  // my item's last absorb block: this is the state the squeeze starts from
+            flo = lo;
+            fhi = hi;
         }
+        s++;
     }
+    lo = flo;
+    hi = fhi;
 
     // ---- squeeze: sq_words words per block, out_len bytes per item
     uint8_t *o = active ? p.out + item * p.out_stride : nullptr;

@@ -875,3 +875,47 @@ def test_short_message_kernel_matches_generic_kernel(capy, O, sponge_lanes, d):
     ho = bytes(outs[0].cpu().numpy())
     for i in range(4):
         assert ho[i * 32:(i + 1) * 32] == O.cshake(host[i * stride:i * stride + L], lbits, b"FN", b"custom", d), (d, i)
+
+
+def test_wave_per_item_digest_pairs_of_unequal_length(capy, O, sponge_lanes):
+    """sponge_wide_digest_kernel holds two items per wave and switches between a tight body loop (every half either in
+    its directly loaded body blocks or finished) and the generic step.  Unsorted device batches (no length sort on this
+    path) whose wave partners differ wildly -- long next to empty, one block next to thousands, aligned next to unaligned
+    offsets, an odd item count -- must still give hashlib's digests (SHA3-256) and the oracle's (SHA3-512: the reference's
+    135 mod 136 suffix rule applies at every d), with the kernel forced (debug bit 5)."""
+    import hashlib
+
+    import torch
+
+    from capycrypt_amd import _lib
+
+    if sponge_lanes != 1:
+        pytest.skip("sets the kernel choice itself")
+    lib = _lib.lib()
+    rng = random.Random(0xD1E5)
+    base = [200000, 0, 1, 136 * 700, 136 * 700 + 8, 135, 136, 137, 99999, 136 * 3, 7, 136 * 1200 - 1, 64, 136 * 2 + 8, 150001]
+    for align in (8, 1):
+        lens = list(base)
+        offs, pos = [], 0
+        for x in lens:
+            offs.append(pos)
+            pos += x if align == 1 else (x + 7) // 8 * 8
+        total = pos
+        blob = rng.randbytes(total + 8)
+        # the C ABI takes n + 1 offsets and lens = differences: lay the messages out back to back at the chosen alignment
+        # by hashing the padded extents when align == 8 (the padding bytes are part of the message then)
+        ext = [(offs[i + 1] if i + 1 < len(offs) else total) - offs[i] for i in range(len(offs))]
+        data = torch.frombuffer(bytearray(blob), dtype=torch.uint8).cuda()
+        d_offs = torch.tensor(offs + [total], dtype=torch.int64).cuda()
+        n = len(lens)
+        for d, ref in ((256, lambda m: hashlib.sha3_256(m).digest()), (512, lambda m: O.sha3(m, 512))):
+            dig = torch.zeros(n * d // 8, dtype=torch.uint8, device="cuda")
+            _lib.check(lib.capy_set_sponge_lanes(32 << 8))
+            try:
+                _lib.check(lib.capy_sha3_batch_dev(d, n, data.data_ptr(), d_offs.data_ptr(), 0, 0, dig.data_ptr(), None))
+                torch.cuda.synchronize()
+            finally:
+                _lib.check(lib.capy_set_sponge_lanes(0))
+            got = bytes(dig.cpu().numpy())
+            for i in range(n):
+                assert got[i * d // 8:(i + 1) * d // 8] == ref(blob[offs[i]:offs[i] + ext[i]]), (align, d, i, ext[i])

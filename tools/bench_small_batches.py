@@ -40,7 +40,10 @@ def timed(fn):
 print("# n x 5 MiB messages, seconds per call: two-lane kernels (wave-per-item off) | wave-per-item kernels on | ratio")
 print("%6s | %9s %9s %6s | %9s %9s %6s | %9s %9s %6s | %9s %9s %6s" % ("n", "sha3 off", "on", "x", "kmac off", "on", "x",
                                                                           "sign off", "on", "x", "verify off", "on", "x"))
-for n in (1, 2, 16, 128, 512, 1024, 2048):
+# N_LIST overrides the batch sizes; FORCE_WIDE=1 forces the wave-per-item kernels (debug bit 5, n <= 4096) to find the crossover
+N_LIST = [int(x) for x in os.environ.get("N_LIST", "1,2,16,128,512,1024,2048").split(",")]
+ON_BITS = 32 if os.environ.get("FORCE_WIDE") else 0
+for n in N_LIST:
     msgs = rand(n * L, 7)
     keys, pws = rand(n * 64, 8), rand(n * 32, 9)
     dig = torch.zeros(n * 32, dtype=torch.uint8, device=dev)
@@ -60,7 +63,7 @@ for n in (1, 2, 16, 128, 512, 1024, 2048):
                                                                        h.data_ptr(), z.data_ptr(), status.data_ptr(), sp)),
     }
     res, outs = {}, {}
-    for name, dbg in (("off", 16), ("on", 0)):
+    for name, dbg in (("off", 16), ("on", ON_BITS)):
         _lib.check(lib.capy_set_sponge_lanes(dbg << 8))
         for k, fn in ops.items():
             res[(k, name)] = timed(fn)

@@ -215,6 +215,33 @@ def wide_today():
     return L
 
 
+def wide_dpp_theta():
+    """today's round with its SECOND LDS trip (C[x-1], C[x+1]: four ds_bpermute + a wait) replaced by four whole-wave DPP
+    rotations (wave_ror:1 / wave_rol:1): C does not depend on y, so lane i - 1 / i + 1 of the x + 5y layout always holds
+    C[x -+ 1], and four idle lanes mirror the lanes the rotation wraps to."""
+    L = []
+    for h in (8, 9):
+        for k in range(4):
+            L.append(f"ds_bpermute_b32 v{10 + 4 * (h - 8) + k}, v{40 + k}, v{h}")
+    L.append("s_waitcnt lgkmcnt(0)")
+    L += ["v_bitop3_b32 v18, v8, v10, v11 bitop3:0x96", "v_bitop3_b32 v18, v18, v12, v13 bitop3:0x96",
+          "v_bitop3_b32 v19, v9, v14, v15 bitop3:0x96", "v_bitop3_b32 v19, v19, v16, v17 bitop3:0x96"]
+    full = "row_mask:0xf bank_mask:0xf"
+    L += ["s_nop 1", f"v_mov_b32_dpp v20, v18 wave_ror:1 {full}", f"v_mov_b32_dpp v21, v19 wave_ror:1 {full}",
+          f"v_mov_b32_dpp v22, v18 wave_rol:1 {full}", f"v_mov_b32_dpp v23, v19 wave_rol:1 {full}"]
+    L += ["v_alignbit_b32 v24, v22, v23, 31", "v_alignbit_b32 v25, v23, v22, 31", "v_bitop3_b32 v26, v8, v20, v24 bitop3:0x96",
+          "v_bitop3_b32 v27, v9, v21, v25 bitop3:0x96"]
+    L += ["v_bitop3_b32 v28, v27, v26, v46 bitop3:0xca", "v_bitop3_b32 v29, v26, v27, v46 bitop3:0xca", "v_alignbit_b32 v30, v28, v29, v47",
+          "v_alignbit_b32 v31, v29, v28, v47", "v_bitop3_b32 v26, v28, v30, v34 bitop3:0xca", "v_bitop3_b32 v27, v29, v31, v34 bitop3:0xca"]
+    for h, src in ((0, 26), (1, 27)):
+        for k in range(3):
+            L.append(f"ds_bpermute_b32 v{10 + 3 * h + k}, v{48 + k}, v{src}")
+    L.append("s_waitcnt lgkmcnt(0)")
+    L += ["v_bitop3_b32 v8, v10, v11, v12 bitop3:0xd2", "v_bitop3_b32 v9, v13, v14, v15 bitop3:0xd2",
+          "v_bitop3_b32 v8, v8, v35, v36 bitop3:0x78", "v_bitop3_b32 v9, v9, v35, v37 bitop3:0x78"]
+    return L
+
+
 def wide_proposed():
     L = []
     row = "row_mask:0xf bank_mask:0xf bound_ctrl:1"
@@ -246,6 +273,33 @@ def wide_proposed():
     return out
 
 
+def wide_split():
+    """ONE sponge per wave: the low words of the 25 Keccak lanes in GPU lanes 0..24, the high words in lanes 32..56 (one state
+    register per lane instead of two; the idle lanes mirror as in wide2).  Seven ds_bpermute per round instead of fourteen,
+    but the two 64-bit rotations need the other half of the word: v_permlane32_swap of two copies + a select by half."""
+    L = []
+    full = "row_mask:0xf bank_mask:0xf"
+    for k in range(4):
+        L.append(f"ds_bpermute_b32 v{10 + k}, v{40 + k}, v8")
+    L.append("s_waitcnt lgkmcnt(0)")
+    L += ["v_bitop3_b32 v18, v8, v10, v11 bitop3:0x96", "v_bitop3_b32 v18, v18, v12, v13 bitop3:0x96"]
+    # C[x-1]; C[x+1] three times (own + the two copies the swap consumes)
+    L += ["s_nop 1", f"v_mov_b32_dpp v20, v18 wave_ror:1 {full}", f"v_mov_b32_dpp v21, v18 wave_rol:1 {full}",
+          f"v_mov_b32_dpp v22, v18 wave_rol:1 {full}", f"v_mov_b32_dpp v23, v18 wave_rol:1 {full}",
+          "s_nop 1", "v_permlane32_swap_b32 v22, v23", "v_bitop3_b32 v22, v22, v23, v38 bitop3:0xca",
+          "v_alignbit_b32 v24, v21, v22, 31"]
+    # E three times (own + two copies), exchange, rho
+    L += ["v_bitop3_b32 v26, v8, v20, v24 bitop3:0x96", "v_bitop3_b32 v27, v8, v20, v24 bitop3:0x96", "v_bitop3_b32 v28, v8, v20, v24 bitop3:0x96",
+          "s_nop 1", "v_permlane32_swap_b32 v27, v28", "v_bitop3_b32 v27, v27, v28, v38 bitop3:0xca"]
+    L += ["v_bitop3_b32 v28, v27, v26, v46 bitop3:0xca", "v_bitop3_b32 v29, v26, v27, v46 bitop3:0xca", "v_alignbit_b32 v30, v28, v29, v47",
+          "v_bitop3_b32 v26, v28, v30, v34 bitop3:0xca"]
+    for k in range(3):
+        L.append(f"ds_bpermute_b32 v{10 + k}, v{48 + k}, v26")
+    L.append("s_waitcnt lgkmcnt(0)")
+    L += ["v_bitop3_b32 v8, v10, v11, v12 bitop3:0xd2", "v_bitop3_b32 v8, v8, v35, v36 bitop3:0x78"]
+    return L
+
+
 kernels = []  # (ident, label, lines, count)
 for i, op in enumerate(OPS):
     lines = block(op, 512)
@@ -255,7 +309,9 @@ for i, (label, spec) in enumerate(MIXES.items()):
     kernels.append(("mix%d" % i, label, lines, n))
 
 for ident, label, fn in (("wide0", "wide round today (18 bpermute, 3 trips) x8 [rounds]", wide_today),
-                         ("wide1", "wide round proposed (DPP + permlane swaps, 2 bpermute) x8 [rounds]", wide_proposed)):
+                         ("wide1", "wide round proposed (DPP + permlane swaps, 2 bpermute) x8 [rounds]", wide_proposed),
+                         ("wide2", "wide round, trip 2 by wave_ror/rol DPP (14 bpermute, 2 trips) x8 [rounds]", wide_dpp_theta),
+                         ("wide3", "one sponge per wave, lo/hi words in the wave's halves (7 bpermute, 2 permlane32_swap) x8 [rounds]", wide_split)):
     kernels.append((ident, label, fn() * 8, 8))  # count = rounds per trip: the table then reads ns and cycles PER ROUND
 
 out = []
@@ -277,7 +333,10 @@ for ident, label, lines, n in kernels:
     w(f"    asm volatile({init} : : \"v\"(seed), \"s\"(0x9E3779B1u) : CLOB);")
     w('    asm volatile("s_mov_b32 s10, 0x55555555\\n\\ts_mov_b32 s11, 0x33333333\\n\\ts_mov_b64 vcc, s[10:11]" ::: "s10", "s11", "vcc");')
     if ident.startswith("wide"):
-        w('    asm volatile("' + "\\n\\t".join("v_and_b32 v%d, 0xfc, v%d" % (r, r) for r in range(40, 51)) + '" ::: CLOB);')
+        # gather indices: a permutation of the lanes each (conflict-free like the real index registers), not random
+        w('    asm volatile("v_mbcnt_lo_u32_b32 v39, -1, 0\\n\\tv_mbcnt_hi_u32_b32 v39, -1, v39\\n\\t'
+          + "\\n\\t".join("v_add_u32 v%d, %d, v39\\n\\tv_and_b32 v%d, 63, v%d\\n\\tv_lshlrev_b32 v%d, 2, v%d" % (r, 5 * (r - 39), r, r, r, r)
+                             for r in range(40, 51)) + '" ::: CLOB);')
     w("    unsigned long long t0, t1, r0, r1; unsigned hwid, xcc;")
     w('    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\\n\\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hwid), "=s"(xcc));')
     w('    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\\n\\ts_memrealtime %0\\n\\ts_memtime %1\\n\\ts_waitcnt lgkmcnt(0)" : "=s"(r0), "=s"(t0)::"memory");')
