@@ -328,7 +328,8 @@ for ident, label, lines, n in kernels:
     w(f"// {label}")
     w(f"__global__ __launch_bounds__(256) void k_{ident}(Rec *rec, unsigned iters, unsigned m, unsigned long long *sink, unsigned active)")
     w("{")
-    w("    if (threadIdx.x >= active) return;  // active = 64: one wave per workgroup (per CU at W = 1), the others leave")
+    w("    if (threadIdx.x >= (active & 0xffff)) return;  // active = 64: one wave per workgroup (per CU at W = 1), the others leave")
+    w("    if ((active >> 16) && (threadIdx.x & 63) >= (active >> 16)) return;  // lanes per wave that stay (EXEC = low lanes only)")
     w("    const unsigned seed = ((blockIdx.x * 256 + threadIdx.x) * 2654435761u | 1u) & m;")
     w(f"    asm volatile({init} : : \"v\"(seed), \"s\"(0x9E3779B1u) : CLOB);")
     w('    asm volatile("s_mov_b32 s10, 0x55555555\\n\\ts_mov_b32 s11, 0x33333333\\n\\ts_mov_b64 vcc, s[10:11]" ::: "s10", "s11", "vcc");')
@@ -359,7 +360,8 @@ int main(int argc, char **argv)
 {
     const char *filter = argc > 1 ? argv[1] : "";
     const int wmax = argc > 2 ? atoi(argv[2]) : 4;
-    const unsigned active = argc > 3 ? (unsigned)atoi(argv[3]) : 256u;  // 64: only the first wave of every workgroup works
+    unsigned active = argc > 3 ? (unsigned)atoi(argv[3]) : 256u;  // 64: only the first wave of every workgroup works
+    if (argc > 4) active |= (unsigned)atoi(argv[4]) << 16;        // 32: only the low 32 lanes of every wave work (EXEC half empty)
     Rec *rec;
     unsigned long long *sink;
     (void)hipMalloc(&rec, sizeof(Rec) * 8192);
