@@ -252,7 +252,9 @@ static bool harden(bool secret)
 // Small batches: one item per WAVE (ed448_wave.h) instead of one per lane -- 7x lower latency for the variable-base
 // and 3.6x for the fixed-base multiplication, worth it while the batch is too small to fill the chip's lanes: the
 // crossover is at ~10 000 items for variable base / double-scalar and ~5 000 for fixed base (profiles/r02_ed448_wave.txt),
-// hence a threshold of 8192 and half of it; the same thresholds serve the constant-address forms (wave::*<true>).
+// hence a threshold of 8192 for those.  Fixed base, re-measured with the division-step inversion of r03 (lane kernel
+// 0.46 -> 0.30 ms at one wave per SIMD, wave kernel 0.147 -> 0.119 ms; profiles/r03_ed448_gcd_inversion.txt): the
+// crossover is ~3000 items indexed and ~6500 with constant-address lookups, hence 5/16 and 3/4 of the threshold.
 // capy_ed448_set_wave_max() / CAPY_ED448_WAVE_MAX override the threshold (0 = never).
 static std::atomic<long> g_wave_max{-1};
 static size_t wave_max_items()
@@ -392,7 +394,7 @@ static int fb_launch(size_t n, const uint8_t *scalars, uint8_t *out, hipStream_t
     int rc = ensure_gtab(&gt, ct);
     if (rc) return rc;
     const dim3 pair_grid((unsigned)((n + 127) / 128));
-    if (n <= wave_max_items() / 2) {
+    if (n <= (ct ? wave_max_items() * 3 / 4 : wave_max_items() * 5 / 16)) {
         if (ct)
             hipLaunchKernelGGL(wave::fb_wave_kernel<true>, dim3((unsigned)n), dim3(64), 0, s, (uint64_t)n, scalars, out, gt);
         else

@@ -229,12 +229,33 @@ __device__ __forceinline__ RV wv_from_affine_bytes(const WC &c, const uint8_t *x
     return (x & c.r0) | (y & c.r1) | (c.one & c.r2) | (t & c.r3);
 }
 
-// pt_to_affine_bytes through 128 B of LDS: lanes 0 and 1 finish x and y with the in-lane canonical reduction
-__device__ __forceinline__ void wv_to_affine_bytes(const WC &c, uint8_t *xy, RV P, uint32_t *stage /* [32] */)
+// pt_to_affine_bytes through LDS.  CAPY_ED448_WAVE_GCD_INV = 1 (default): the point's four rows are staged, every lane
+// reads Z as a whole field element and runs the division-step inversion of ed448_dev.h in the LANE form (wave-uniform
+// work, ~40 000 instructions against 458 row-form multiplications of ~200 ns each), and lanes 0 and 1 multiply x and y
+// out and finish them with the in-lane canonical reduction.  0: the a^(p-2) chain in row form (A/B).
+#ifndef CAPY_ED448_WAVE_GCD_INV
+#define CAPY_ED448_WAVE_GCD_INV 1
+#endif
+__device__ __forceinline__ void wv_to_affine_bytes(const WC &c, uint8_t *xy, RV P, uint32_t *stage /* [64] */)
 {
+    const uint32_t lane = threadIdx.x & 63;
+#if CAPY_ED448_WAVE_GCD_INV
+    stage[lane] = P;
+    __syncthreads();
+    Fe z;
+#pragma unroll
+    for (int i = 0; i < 16; i++) z.l[i] = stage[32 + i];
+    const Fe zi = fe_inv_gcd(z);
+    if (lane < 2) {
+        Fe f;
+#pragma unroll
+        for (int i = 0; i < 16; i++) f.l[i] = stage[lane * 16 + i];
+        fe_to_bytes(xy + 56 * lane, fe_mul(f, zi));
+    }
+    __syncthreads();
+#else
     const RV zi = rv_inv(c, row_bcast<2>(c, P));
     const RV r = rv_mul(c, P, zi);  // (x, y, 1, t)
-    const uint32_t lane = threadIdx.x & 63;
     if (lane < 32) stage[lane] = r;
     __syncthreads();
     if (lane < 2) {
@@ -244,6 +265,7 @@ __device__ __forceinline__ void wv_to_affine_bytes(const WC &c, uint8_t *xy, RV 
         fe_to_bytes(xy + 56 * lane, f);
     }
     __syncthreads();
+#endif
 }
 
 // ---- variable base: table {0..16} P (cached) in LDS, one row vector per entry
@@ -344,7 +366,7 @@ __global__ __launch_bounds__(64) void vb_wave_kernel(uint64_t n, const uint8_t *
                                                      const uint8_t *points_xy, uint64_t point_stride, uint8_t *out_xy)
 {
     __shared__ VbTable tab;
-    __shared__ uint32_t stage[32];
+    __shared__ uint32_t stage[64];
     const uint64_t i = blockIdx.x;
     const WC c = wc_init();
     const RV P = wv_from_affine_bytes(c, points_xy + i * point_stride);
@@ -355,7 +377,7 @@ __global__ __launch_bounds__(64) void vb_wave_kernel(uint64_t n, const uint8_t *
 template <bool CT>  // CT: gtab is the hardened table (FBCT_WBITS-bit windows)
 __global__ __launch_bounds__(64) void fb_wave_kernel(uint64_t n, const uint8_t *scalars_be, uint8_t *out_xy, const uint32_t *gtab)
 {
-    __shared__ uint32_t stage[32];
+    __shared__ uint32_t stage[64];
     const uint64_t i = blockIdx.x;
     const WC c = wc_init();
     const RV r = wv_fb_accumulate<CT>(c, rv_identity(c), scalars_be + i * 56, gtab);
@@ -367,7 +389,7 @@ __global__ __launch_bounds__(64) void dsm_wave_kernel(uint64_t n, const uint8_t 
                                                       uint8_t *out_xy, const uint32_t *gtab)
 {
     __shared__ VbTable tab;
-    __shared__ uint32_t stage[32];
+    __shared__ uint32_t stage[64];
     const uint64_t i = blockIdx.x;
     const WC c = wc_init();
     const RV P = wv_from_affine_bytes(c, points_xy + i * 112);

@@ -18,6 +18,37 @@ void ht_fe_sqr(const uint8_t *a, uint8_t *out) { fe_to_bytes(out, fe_sqr(fe_from
 void ht_fe_add(const uint8_t *a, const uint8_t *b, uint8_t *out) { fe_to_bytes(out, fe_add(fe_from_bytes(a), fe_from_bytes(b))); }
 void ht_fe_sub(const uint8_t *a, const uint8_t *b, uint8_t *out) { fe_to_bytes(out, fe_sub(fe_from_bytes(a), fe_from_bytes(b))); }
 void ht_fe_inv(const uint8_t *a, uint8_t *out) { fe_to_bytes(out, fe_inv(fe_from_bytes(a))); }
+void ht_fe_inv_gcd(const uint8_t *a, uint8_t *out) { fe_to_bytes(out, fe_inv_gcd(fe_from_bytes(a))); }
+// how many 30-step rounds of the division-step inversion an input needs until g = 0 (the code always runs 44)
+int ht_fe_inv_gcd_rounds(const uint8_t *a)
+{
+    Fe x = fe_from_bytes(a);
+    fe_canon(x);
+    uint8_t b[56];
+    fe_to_bytes(b, x);
+    GcdNum f, g;
+    for (int k = 0; k < 15; k++) {
+        uint32_t v = 0;
+        for (int j = 0; j < 30; j++) {
+            const int bit = 30 * k + j;
+            if (bit < 448 && ((b[bit >> 3] >> (bit & 7)) & 1)) v |= 1u << j;
+        }
+        g.v[k] = (int32_t)v;
+        f.v[k] = GCD_M30;
+    }
+    f.v[7] = GCD_M30 - (1 << 14);
+    f.v[14] = (1 << 28) - 1;
+    int32_t eta = -1;
+    for (int it = 0; it < 64; it++) {
+        bool zero = true;
+        for (int k = 0; k < 15; k++) zero = zero && g.v[k] == 0;
+        if (zero) return it;
+        GcdMat t;
+        eta = gcd_divsteps_30(eta, (uint32_t)f.v[0] | ((uint32_t)f.v[1] << 30), (uint32_t)g.v[0] | ((uint32_t)g.v[1] << 30), t);
+        gcd_update_fg(f, g, t);
+    }
+    return 64;
+}
 void ht_fe_roundtrip(const uint8_t *a, uint8_t *out) { fe_to_bytes(out, fe_from_bytes(a)); }
 // chained: ((a*b)^2 - a + b) * ... exercises lazily reduced operands
 void ht_fe_chain(const uint8_t *a, const uint8_t *b, int n, uint8_t *out)

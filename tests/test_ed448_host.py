@@ -57,6 +57,31 @@ def test_field_ops(L):
         assert call(L, "ht_fe_inv", a.to_bytes(56, "little")) == fb(pow(a, -1, E.P))
 
 
+def test_division_step_inversion_equals_fermat(L):
+    """fe_inv_gcd (Bernstein-Yang division steps, 44 x 30 steps for every input) against pow(a, -1, p) and against the
+    a^(p-2) chain it replaces: zero (-> 0, like the chain), one, p - 1, powers of two and their neighbours, values with
+    long runs of zeros / ones, non-canonical encodings (>= p), random values.  No input may need more than the 44 rounds
+    the code runs (the paper's bound for 448-bit inputs is 1294 steps = 43.1 rounds)."""
+    rng = random.Random(0x6CD)
+    vals = [0, 1, 2, 3, E.P - 1, E.P - 2, E.P, E.P + 1, 2**448 - 1, 2**224, 2**224 - 1, 2**224 + 1, 2**447, 2**447 - 1, (E.P - 1) // 2,
+            (E.P + 1) // 2, 2**446 - 1, 39081, E.P - 39081]
+    vals += [2**k for k in range(1, 448, 13)] + [2**k - 1 for k in range(2, 448, 17)] + [E.P - 2**k for k in range(1, 447, 19)]
+    vals += [rng.getrandbits(448) & ~((1 << rng.randrange(1, 440)) - 1) for _ in range(60)]
+    vals += [rng.getrandbits(rng.randrange(1, 449)) for _ in range(300)]
+    vals += [rng.getrandbits(448) for _ in range(600)]
+    L.ht_fe_inv_gcd_rounds.restype = C.c_int
+    worst = 0
+    for a in vals:
+        ab = a.to_bytes(56, "little")
+        want = fb(pow(a, -1, E.P)) if a % E.P else bytes(56)
+        assert call(L, "ht_fe_inv_gcd", ab) == want, hex(a)
+        worst = max(worst, L.ht_fe_inv_gcd_rounds(C.c_char_p(ab)))
+    for a in vals[:40]:
+        ab = a.to_bytes(56, "little")
+        assert call(L, "ht_fe_inv_gcd", ab) == call(L, "ht_fe_inv", ab)
+    assert worst <= 44, worst
+
+
 def test_lazy_reduction_chain(L):
     rng = random.Random(6)
     for _ in range(10):
