@@ -25,14 +25,29 @@ namespace capy {
 #ifdef CAPY_ED448_NUMVGPR
 __attribute__((amdgpu_num_vgpr(CAPY_ED448_NUMVGPR)))
 #endif
+// Table entries fetched ahead through LDS (ed448_algo.h: lds_prefetch) in the lane-per-item kernels that run at ONE wave
+// per SIMD (the two-items-per-lane kernels run two, which hide each other's waits).  Measured at 65 536 items
+// (profiles/r03_ed448_prefetch.txt): fixed base 0.327 -> 0.299 ms, on by default; variable base 2.886 -> 2.984 ms (the
+// loop's register allocation gets worse: 96 instead of 44 spilled VGPRs), off by default.
+#ifndef CAPY_ED448_PREFETCH_FB
+#define CAPY_ED448_PREFETCH_FB 1
+#endif
+#ifndef CAPY_ED448_PREFETCH_VB
+#define CAPY_ED448_PREFETCH_VB 0
+#endif
 __global__ __launch_bounds__(64, CAPY_ED448_WAVES) void vb_kernel(uint64_t n, const uint8_t *scalars_be, uint64_t scalar_stride,
                                                 const uint8_t *points_xy, uint64_t point_stride, uint8_t *out_xy,
                                                 uint32_t *table_ws)
 {
     const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
     if (i >= n) return;
+#if CAPY_ED448_PREFETCH_VB
+    __shared__ uint32_t pf[VB_PF_DWORDS];
+#else
+    uint32_t *const pf = nullptr;
+#endif
     const Pt P = pt_from_affine_bytes(points_xy + i * point_stride);
-    const Pt r = vb_scalarmul(scalars_be + i * scalar_stride, P, table_ws + i * VB_TABLE_DWORDS);
+    const Pt r = vb_scalarmul(scalars_be + i * scalar_stride, P, table_ws + i * VB_TABLE_DWORDS, pf);
     pt_to_affine_bytes(out_xy + i * 112, r);
 }
 
@@ -63,7 +78,12 @@ __global__ __launch_bounds__(64, CAPY_ED448_WAVES) void fb_kernel(uint64_t n, co
 {
     const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
     if (i >= n) return;
-    pt_to_affine_bytes(out_xy + i * 112, fb_scalarmul(scalars_be + i * 56, gtab));
+#if CAPY_ED448_PREFETCH_FB
+    __shared__ uint32_t pf[FB_PF_DWORDS];
+#else
+    uint32_t *const pf = nullptr;
+#endif
+    pt_to_affine_bytes(out_xy + i * 112, fb_scalarmul(scalars_be + i * 56, gtab, pf));
 }
 
 // Two items per lane sharing one inversion (pt_pair_to_affine_bytes): a wave takes 128 consecutive items, lane l the
@@ -146,8 +166,15 @@ __global__ __launch_bounds__(64, CAPY_ED448_WAVES) void dsm_kernel(uint64_t n, c
 {
     const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
     if (i >= n) return;
+#if CAPY_ED448_PREFETCH_VB
+    __shared__ uint32_t pf[VB_PF_DWORDS];
+#elif CAPY_ED448_PREFETCH_FB
+    __shared__ uint32_t pf[FB_PF_DWORDS];
+#else
+    uint32_t *const pf = nullptr;
+#endif
     const Pt P = pt_from_affine_bytes(points_xy + i * 112);
-    const Pt r = double_scalarmul(a_be + i * 56, b_be + i * 56, P, table_ws + i * VB_TABLE_DWORDS, gtab);
+    const Pt r = double_scalarmul(a_be + i * 56, b_be + i * 56, P, table_ws + i * VB_TABLE_DWORDS, gtab, pf);
     pt_to_affine_bytes(out_xy + i * 112, r);
 }
 

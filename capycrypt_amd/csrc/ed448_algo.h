@@ -48,6 +48,50 @@ CAPY_HD inline Fe load_fe(const uint32_t *src)
     return a;
 }
 
+// ---- table entries fetched AHEAD through LDS (device only; r03).  At one wave per SIMD nothing hides the latency of an
+// indexed table read (a different line per lane): the wait before every addition was 8 % of a variable-base and 12 % of a
+// fixed-base multiplication (SQ_WAIT_ANY, profiles/r03_ed448_prefetch.txt), and the registers to hold the next entry
+// during the doublings do not exist (the kernels already fill 256 VGPRs).  global_load_lds_dwordx4 copies memory -> LDS
+// without passing through VGPRs: the entry for the next window is requested before the doublings (variable base) /
+// before the current addition (fixed base) and read from LDS when it is needed; the compiler's vmcnt wait sits in
+// front of that read.  Piece q (16 bytes) of lane l lands at dword (q * 64 + l) * 4 of the wave's staging area.
+// `lds` = nullptr (host build, constant-address forms, one-item-per-wave kernels) keeps the direct loads.
+#ifndef CAPY_ED448_PREFETCH_VB_IN_DSM
+#define CAPY_ED448_PREFETCH_VB_IN_DSM 0  // the staging area of double_scalarmul serves its fixed-base part only
+#endif
+constexpr int VB_PF_DWORDS = 16 * 64 * 4;  // one cached point (64 dwords) per lane
+constexpr int FB_PF_DWORDS = 12 * 64 * 4;  // one affine cached entry (48 dwords) per lane
+#if defined(__HIP_DEVICE_COMPILE__)
+template <int QUADS>
+__device__ __forceinline__ void lds_prefetch(uint32_t *lds, const uint32_t *src)
+{
+    // the staging area may still be being read (ds_read of the previous entry): let those reads land first
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+#pragma unroll
+    for (int q = 0; q < QUADS; q++)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 4 * q),
+                                         (__attribute__((address_space(3))) void *)(lds + q * 256), 16, 0, 0);
+}
+// the requested entry has arrived.  The compiler puts this wait in front of an LDS read that follows the request in
+// straight-line code, but NOT when the request was made in the previous trip of a loop (seen in fb_kernel: ds_read at
+// the loop head with no vmcnt wait), so it is explicit
+__device__ __forceinline__ void lds_prefetch_wait() { __builtin_amdgcn_s_waitcnt(0x0f70); /* vmcnt(0) */ }
+__device__ __forceinline__ Fe lds_load_fe(const uint32_t *lds, int f)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    Fe a;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(lds + ((f * 4 + q) * 64 + lane) * 4);
+        a.l[4 * q] = v.x;
+        a.l[4 * q + 1] = v.y;
+        a.l[4 * q + 2] = v.z;
+        a.l[4 * q + 3] = v.w;
+    }
+    return a;
+}
+#endif
+
 // Build the per-item table {0,1,..,WHALF}P (cached form) at tab[0 .. VB_TABLE_DWORDS).
 CAPY_HD inline void vb_build_table(uint32_t *tab, const Pt &P)
 {
@@ -187,8 +231,9 @@ CAPY_HD_INLINE Pt vb_scalarmul_ct(const uint8_t *k_be, const Pt &P, const CtTabl
     return acc;
 }
 
-// [k]P, k = 56 big-endian bytes (all 448 bits used), tab = VB_TABLE_DWORDS of scratch for this item.
-CAPY_HD_INLINE Pt vb_scalarmul(const uint8_t *k_be, const Pt &P, uint32_t *tab)
+// [k]P, k = 56 big-endian bytes (all 448 bits used), tab = VB_TABLE_DWORDS of scratch for this item; lds = the wave's
+// VB_PF_DWORDS of staging (or nullptr: direct table reads).
+CAPY_HD_INLINE Pt vb_scalarmul(const uint8_t *k_be, const Pt &P, uint32_t *tab, uint32_t *lds = nullptr)
 {
     vb_build_table(tab, P);
     uint32_t k[14], w[15];
@@ -196,6 +241,24 @@ CAPY_HD_INLINE Pt vb_scalarmul(const uint8_t *k_be, const Pt &P, uint32_t *tab)
     const uint32_t top = sc_recode_signed<WBITS>(w, k);
     sc_msb_align<WBITS>(w);
     Pt acc = vb_add_digit(pt_identity(), tab, (int)top);
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (lds) {
+#pragma unroll 1
+        for (int i = 0; i < NWIN; i++) {
+            const int digit = sc_next_digit_msb<WBITS>(w);
+            const bool neg = digit < 0;
+            lds_prefetch<16>(lds, tab + (neg ? -digit : digit) * 64);
+            CAPY_UNROLL(CAPY_ED448_DBL_UNROLL)
+            for (int j = 0; j < WBITS; j++) acc = pt_dbl<true>(acc);
+            lds_prefetch_wait();
+            Fe X2 = lds_load_fe(lds, 0), Y2 = lds_load_fe(lds, 1), Z2 = lds_load_fe(lds, 2), Td2 = lds_load_fe(lds, 3);
+            X2 = fe_select(neg, X2, fe_neg_nr(X2));
+            Td2 = fe_select(neg, Td2, fe_neg_nr(Td2));
+            acc = pt_add_cached(acc, X2, Y2, Z2, Td2);
+        }
+        return acc;
+    }
+#endif
 #pragma unroll 1
     for (int i = 0; i < NWIN; i++) {
         // one doubling body keeps the loop inside the I-cache; the compiler sinks the T product (dead in all but
@@ -269,31 +332,56 @@ CAPY_HD_INLINE Pt fb_scalarmul_ct(const uint8_t *k_be, const uint32_t *gtab)
     return acc;
 }
 
-// [k]G from the shared table gtab[FB_TABLE_DWORDS]
-CAPY_HD_INLINE Pt fb_scalarmul(const uint8_t *k_be, const uint32_t *gtab)
+// acc += sum over the FbWin::NWIN windows of the recoded scalar w (the top digit is the caller's business); with lds the
+// entry of window i + 1 is on its way while window i is added
+CAPY_HD_INLINE Pt fb_add_windows(Pt acc, uint32_t *w, const uint32_t *gtab, uint32_t *lds)
 {
-    uint32_t k[14], w[15];
-    sc_from_be(k, k_be);
-    const uint32_t top = sc_recode_signed<FB_WBITS>(w, k);
-    Pt acc = fb_add_digit(pt_identity(), gtab, FbWin::NWIN, (int)top);
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (lds) {
+        int digit = sc_next_digit_lsb<FB_WBITS>(w);
+        lds_prefetch<12>(lds, gtab + (0 * FB_TAB_ENTRIES + (digit < 0 ? -digit : digit)) * FB_ENTRY_DWORDS);
+#pragma unroll 1
+        for (int i = 0; i < FbWin::NWIN; i++) {
+            const bool neg = digit < 0;
+            lds_prefetch_wait();
+            Fe x2 = lds_load_fe(lds, 0), y2 = lds_load_fe(lds, 1), td2 = lds_load_fe(lds, 2);
+            x2 = fe_select(neg, x2, fe_neg_nr(x2));
+            td2 = fe_select(neg, td2, fe_neg_nr(td2));
+            if (i + 1 < FbWin::NWIN) {
+                digit = sc_next_digit_lsb<FB_WBITS>(w);
+                lds_prefetch<12>(lds, gtab + ((i + 1) * FB_TAB_ENTRIES + (digit < 0 ? -digit : digit)) * FB_ENTRY_DWORDS);
+            }
+            acc = pt_add_affine_cached(acc, x2, y2, td2);
+        }
+        return acc;
+    }
+#endif
 #pragma unroll 1
     for (int i = 0; i < FbWin::NWIN; i++) acc = fb_add_digit(acc, gtab, i, sc_next_digit_lsb<FB_WBITS>(w));
     return acc;
 }
 
+// [k]G from the shared table gtab[FB_TABLE_DWORDS]; lds = the wave's FB_PF_DWORDS of staging (or nullptr)
+CAPY_HD_INLINE Pt fb_scalarmul(const uint8_t *k_be, const uint32_t *gtab, uint32_t *lds = nullptr)
+{
+    uint32_t k[14], w[15];
+    sc_from_be(k, k_be);
+    const uint32_t top = sc_recode_signed<FB_WBITS>(w, k);
+    const Pt acc = fb_add_digit(pt_identity(), gtab, FbWin::NWIN, (int)top);
+    return fb_add_windows(acc, w, gtab, lds);
+}
+
 // [a]G + [b]P: the variable-base window loop for [b]P, then [a]G added from the shared fixed-base table (39 mixed
 // additions with 12-bit digits; interleaving 5-bit digits of `a` into the doubling chain, Straus style, costs 91).
 CAPY_HD_INLINE Pt double_scalarmul(const uint8_t *a_be, const uint8_t *b_be, const Pt &P, uint32_t *tab,
-                                   const uint32_t *gtab)
+                                   const uint32_t *gtab, uint32_t *lds = nullptr)
 {
-    Pt acc = vb_scalarmul(b_be, P, tab);
+    Pt acc = vb_scalarmul(b_be, P, tab, CAPY_ED448_PREFETCH_VB_IN_DSM ? lds : nullptr);
     uint32_t ka[14], wa[15];
     sc_from_be(ka, a_be);
     const uint32_t topa = sc_recode_signed<FB_WBITS>(wa, ka);
     acc = fb_add_digit(acc, gtab, FbWin::NWIN, (int)topa);
-#pragma unroll 1
-    for (int i = 0; i < FbWin::NWIN; i++) acc = fb_add_digit(acc, gtab, i, sc_next_digit_lsb<FB_WBITS>(wa));
-    return acc;
+    return fb_add_windows(acc, wa, gtab, lds);
 }
 
 // ------------------------------------------------------------------ scalars mod r (Schnorr / ECDHIES glue)

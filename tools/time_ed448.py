@@ -11,7 +11,7 @@ def timeit(fn, reps=3):
     for _ in range(reps): fn()
     e1.record(st); torch.cuda.synchronize()
     return e0.elapsed_time(e1)/reps
-n=1<<18
+n=int(os.environ.get("N", str(1<<18)))
 def rand(nb,seed):
     t=torch.empty(nb,dtype=torch.uint8,device=dev); _lib.check(lib.capy_fill_random_dev(t.data_ptr(),nb,seed,sp)); return t
 sc=rand(n*56,4); tsc=rand(n*56,41)
