@@ -658,9 +658,11 @@ static bool short_kernel_ok(int rw, const SpongeParams &p, int forced, unsigned 
 static bool wide_digest_ok(int rw, const SpongeParams &p, int forced, unsigned dbg)
 {
     const bool shape_ok = p.out_mode == 0 && p.pre_len == 0 && p.stride_bytes == (uint32_t)rw * 8 && !p.resume_state && !p.head_state;
-    const uint64_t max_len = p.offsets ? ~0ULL : p.uniform_len;  // lengths of a ragged device batch are not known here
+    // any message length: measured r03 (profiles/r03_small_calls.txt), KMACXOF256 of 64 B / 1 KiB / 16 KiB messages at
+    // n <= 2048: 0.029 -> 0.015, 0.066 -> 0.038, 0.645 -> 0.394 ms against the two-lane kernel (r02 took this kernel for
+    // messages of at least 64 KiB only)
     return shape_ok && (((dbg & 32) && p.n <= 4096) ||
-                        (forced == 0 && !(dbg & 16) && p.n <= 2 * wide_max_items() && p.absorb_body && max_len >= 64 * 1024));
+                        (forced == 0 && !(dbg & 16) && p.n <= 2 * wide_max_items()));
 }
 
 static int sponge_plan(int rw, const SpongeParams &p, int *phases)
@@ -1159,8 +1161,8 @@ int symmetric_crypt_dev(bool encrypt, int d, size_t n, const uint8_t *keka, size
         // Worth it only when the serial chains are long; debug bits 4 / 5: never / always (A/B and tests).
         {
             const unsigned dbg = g_debug_flags.load();
-            const uint64_t max_len = m.offsets ? ~0ULL : m.uniform_len;
-            fp.wide = ((dbg & 32) && n <= 4096) || (!(dbg & 16) && n <= wide_max_items() && max_len >= 64 * 1024) ? 1 : 0;
+            // any message length (r03: 1.3-2.0x the four-lane kernel from 64 B to 5 MiB at n <= 1024, profiles/r03_small_calls.txt)
+            fp.wide = ((dbg & 32) && n <= 4096) || (!(dbg & 16) && n <= wide_max_items()) ? 1 : 0;
         }
         fp.tags = encrypt ? tags : tag2;
         CAPY_HIP(launch_sponge_fused(ff.rw, fp, s));
