@@ -242,8 +242,8 @@ int capy_key_decrypt_batch_dev(int d, size_t n, const uint8_t *pws, size_t pw_le
 
 /* ------------------------------------------------------------------ measurement helpers */
 
-/* Tuning / test knob: GPU lanes per sponge. 0 = automatic (a wave per item or per two items for very small batches of
- * long messages, 2 lanes for batches of at most 32 items per SIMD, the rotating one-/two-lane schedule for uniform
+/* Tuning / test knob: GPU lanes per sponge. 0 = automatic (a wave per item or per two items for batches of at most
+ * one / two items per SIMD, 2 lanes for batches of at most 32 items per SIMD, the rotating one-/two-lane schedule for uniform
  * digest batches between 32 and 64 items per SIMD, else 1), 1 or 2 = forced, 3 = the rotating schedule wherever it is
  * eligible. Results are identical either way. Process-wide and not synchronised with calls in flight: set it before
  * the threads that use the library start, not while they run. */
