@@ -32,6 +32,7 @@ SIGNATURES = {
     "capy_shard_plan": (C.c_int, [sz, C.c_int, vp, vp]),
     "capy_device_synchronize": (C.c_int, []),
     "capy_release_workspace": (C.c_int, []),
+    "capy_debug_secret_scratch_nonzero": (C.c_int, [vp, vp]),
     "capy_sha3_batch": (C.c_int, [C.c_int, sz, vp, vp, vp]),
     "capy_sha3_batch_dev": (C.c_int, [C.c_int, sz, vp, vp, u64, u64, vp, vp]),
     "capy_cshake_batch": (C.c_int, [C.c_int, sz, vp, vp, sz, vp, sz, vp, sz, vp]),

@@ -62,6 +62,7 @@ enum WsSlot { WS_PRE = 0, WS_ZPW, WS_ZOFF, WS_KEKA, WS_TAG2, WS_A, WS_B, WS_C, W
 void *workspace(hipStream_t stream, WsSlot slot, size_t bytes);  // nullptr on allocation failure
 void workspace_release();                                           // free this thread's scratch (synchronises)
 void workspace_scrub(hipStream_t stream, WsSlot slot, size_t bytes);  // zero a slot's first bytes, stream-ordered
+void workspace_scrub_many(hipStream_t stream, const WsSlot *slots, const size_t *bytes, int count);  // the same, one launch
 // Scrubs the named slots when the enclosing function returns -- on EVERY path, also the early error returns (a failed
 // launch must not leave z || pw, ke || ka, a secret scalar or an ECDH point behind in scratch that later calls reuse).
 struct WsScrubGuard {
@@ -80,7 +81,13 @@ struct WsScrubGuard {
     }
     ~WsScrubGuard()
     {
-        for (int i = 0; i < count; i++) workspace_scrub(stream, items[i].slot, items[i].bytes);
+        WsSlot slots[4];
+        size_t bytes[4];
+        for (int i = 0; i < count; i++) {
+            slots[i] = items[i].slot;
+            bytes[i] = items[i].bytes;
+        }
+        workspace_scrub_many(stream, slots, bytes, count);
     }
 };
 

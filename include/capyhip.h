@@ -76,6 +76,10 @@ int capy_shard_plan(size_t n, int n_devices, const uint64_t *byte_offsets, uint6
 int capy_device_synchronize(void); /* every configured device, else the current one */
 /* Free the calling thread's pooled device scratch on every device (synchronises); also done when the thread ends. */
 int capy_release_workspace(void);
+/* Test hook: how many bytes of the scratch ranges that the calling thread's LAST protocol call declared secret (secret
+ * scalars, nonces, shared points, derived keys, z || pw) are non-zero now.  Synchronises `stream`.  Must be 0 once the
+ * call has returned and the stream is idle. */
+int capy_debug_secret_scratch_nonzero(void *stream, uint64_t *nonzero_bytes);
 
 /* ------------------------------------------------------------------ sponge (src/sha3) */
 

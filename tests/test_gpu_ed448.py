@@ -452,6 +452,20 @@ def test_dev_api_protocols_roundtrip(capy, O):
                                               tags.data_ptr(), st.data_ptr(), None))
     torch.cuda.synchronize()
     assert not st.cpu().numpy().any() and bytes(work.cpu().numpy()) == hm
+    # every protocol call scrubs its secret intermediates (s, k, W, ke || ka) from the pooled scratch when it returns
+    # (one launch for all ranges, csrc/sponge.hip: workspace_scrub_many): check it after each kind of call
+    import ctypes as C
+    nz = C.c_uint64(1)
+    _lib.check(lib.capy_debug_secret_scratch_nonzero(None, C.byref(nz)))
+    assert nz.value == 0  # key_decrypt: s, W, ke || ka
+    _lib.check(lib.capy_schnorr_sign_batch_dev(d, n, pws.data_ptr(), 32, None, msgs.data_ptr(), None, L, stride, h.data_ptr(),
+                                               z.data_ptr(), None))
+    _lib.check(lib.capy_debug_secret_scratch_nonzero(None, C.byref(nz)))
+    assert nz.value == 0  # sign: s, k
+    _lib.check(lib.capy_key_encrypt_batch_dev(d, n, pubs.data_ptr(), kr.data_ptr(), work.data_ptr(), None, L, stride,
+                                              zxy.data_ptr(), tags.data_ptr(), None))
+    _lib.check(lib.capy_debug_secret_scratch_nonzero(None, C.byref(nz)))
+    assert nz.value == 0  # key_encrypt: k, W, ke || ka
 
 
 def test_full_batch_pair_inversion_kernels(capy, O):
