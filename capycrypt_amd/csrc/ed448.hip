@@ -7,6 +7,7 @@
 #include "common.h"
 #include "ed448_algo.h"
 #include "ed448_wave.h"
+#include "ed448_fb7.h"
 #include "sponge_host.h"
 
 namespace capy {
@@ -71,6 +72,36 @@ __global__ __launch_bounds__(64, CAPY_ED448_WAVES) void fb_ct_kernel(uint64_t n,
     const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
     if (i >= n) return;
     pt_to_affine_bytes(out_xy + i * 112, fb_scalarmul_ct(scalars_be + i * 56, gtab_ct));
+}
+
+// hardened fixed base with the table lookups on the matrix cores (ed448_fb7.h).  All 64 lanes stay in the loop (an MFMA
+// wants the whole wave): the lanes past the end of the batch repeat the last item and do not store.
+__global__ __launch_bounds__(64, CAPY_ED448_WAVES) void fb_ct7_kernel(uint64_t n, const uint8_t *scalars_be, uint8_t *out_xy,
+                                                    const uint8_t *gt7)
+{
+#if defined(__HIP_DEVICE_COMPILE__)  // (the MFMA builtins exist in the device pass only)
+    __shared__ uint32_t xpose[64 * FB7_XPOSE_STRIDE];
+    const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+    const uint64_t src = i < n ? i : n - 1;
+    const Pt r = fb7_scalarmul(scalars_be + src * 56, gt7, xpose);
+    if (i < n) pt_to_affine_bytes(out_xy + i * 112, r);
+#endif
+}
+
+// the linear table (rows x 65 affine cached entries of 48 limb dwords) re-laid as MFMA A operands (ed448_fb7.h)
+__global__ void gtab7_pack_kernel(const uint32_t *lin, uint32_t *gt7_words)
+{
+    const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;  // output dword: ((row * 12 + mb) * 64 + lane) * 4 + sq
+    if (o >= FB7_TABLE_BYTES / 4) return;
+    const uint32_t sq = o & 3, lane = (o >> 2) & 63, rm = o >> 8, mb = rm % FB7_GROUPS, row = rm / FB7_GROUPS;
+    const uint32_t g = lane >> 4, c = lane & 15, bi = 16 * mb + c;
+    uint32_t v = 0;
+    for (uint32_t t = 0; t < 4; t++) {
+        const uint32_t entry = 16 * g + 4 * sq + t + 1;
+        const uint32_t w = lin[((size_t)row * FB7_ENTRIES + entry) * FB_ENTRY_DWORDS + bi / 4];
+        v |= ((w >> (8 * (bi & 3))) & 0xffu) << (8 * t);
+    }
+    gt7_words[o] = v;
 }
 
 __global__ __launch_bounds__(64, CAPY_ED448_WAVES) void fb_kernel(uint64_t n, const uint8_t *scalars_be, uint8_t *out_xy,
@@ -396,6 +427,40 @@ static int build_gtab(int rows, int entries, int wbits, uint32_t **slot)
     return CAPY_OK;
 }
 
+// the hardened table in the form the matrix cores read (ed448_fb7.h), built from a linear 7-bit table on first use
+#ifndef CAPY_ED448_FBCT_MFMA
+#define CAPY_ED448_FBCT_MFMA 1  // 0: the VALU scan of fb_ct_kernel / fb2_kernel<true> for every lane-per-item hardened fixed base (A/B)
+#endif
+static uint8_t *g_gtab7[64] = {nullptr};
+static int ensure_gtab7(const uint8_t **out)
+{
+    int dev = 0;
+    CAPY_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return fail(CAPY_ERR_ARG, "device index out of range");
+    std::lock_guard<std::mutex> lk(g_gtab_mu);
+    if (!g_gtab7[dev]) {
+        uint32_t *lin = nullptr;
+        const int rc = build_gtab(FB7_ROWS, FB7_ENTRIES, FB7_WBITS, &lin);
+        if (rc) return rc;
+        uint8_t *gt7 = nullptr;
+        if (hipMalloc((void **)&gt7, FB7_TABLE_BYTES) != hipSuccess) {
+            (void)hipFree(lin);
+            return fail(CAPY_ERR_HIP, "hipMalloc of the fixed-base table failed");
+        }
+        const unsigned words = (unsigned)(FB7_TABLE_BYTES / 4);
+        hipLaunchKernelGGL(gtab7_pack_kernel, dim3((words + 255) / 256), dim3(256), 0, nullptr, lin, reinterpret_cast<uint32_t *>(gt7));
+        const hipError_t e1 = hipGetLastError(), e2 = hipDeviceSynchronize();
+        (void)hipFree(lin);
+        if (e1 != hipSuccess || e2 != hipSuccess) {
+            (void)hipFree(gt7);
+            return fail(CAPY_ERR_HIP, "building the fixed-base table failed");
+        }
+        g_gtab7[dev] = gt7;
+    }
+    *out = g_gtab7[dev];
+    return CAPY_OK;
+}
+
 static int ensure_gtab(const uint32_t **out, bool hardened_table = false)
 {
     int dev = 0;
@@ -416,12 +481,23 @@ static int fb_launch(size_t n, const uint8_t *scalars, uint8_t *out, hipStream_t
 {
     if (!n) return CAPY_OK;
     const bool ct = harden(secret);
+    const bool small = n <= (ct ? wave_max_items() * 3 / 4 : wave_max_items() * 5 / 16);
+    if (ct && !small && CAPY_ED448_FBCT_MFMA) {
+        // every byte of the window's table row is read per window by every wave and the wanted entry is picked by a
+        // one-hot matrix product on the matrix cores: no address depends on the scalar (ed448_fb7.h)
+        const uint8_t *gt7 = nullptr;
+        const int rc7 = ensure_gtab7(&gt7);
+        if (rc7) return rc7;
+        hipLaunchKernelGGL(fb_ct7_kernel, grid64(n), dim3(64), 0, s, (uint64_t)n, scalars, out, gt7);
+        CAPY_HIP(hipGetLastError());
+        return CAPY_OK;
+    }
     const uint32_t *gt = nullptr;
     // ct: every entry of the window's row of the 5-bit table is read per window: no address depends on the scalar
     int rc = ensure_gtab(&gt, ct);
     if (rc) return rc;
     const dim3 pair_grid((unsigned)((n + 127) / 128));
-    if (n <= (ct ? wave_max_items() * 3 / 4 : wave_max_items() * 5 / 16)) {
+    if (small) {
         if (ct)
             hipLaunchKernelGGL(wave::fb_wave_kernel<true>, dim3((unsigned)n), dim3(64), 0, s, (uint64_t)n, scalars, out, gt);
         else
@@ -744,8 +820,10 @@ int capy_ed448_set_generator(const uint8_t *xy)
     for (int dev = 0; dev < 64; dev++) {
         if (g_gtab[dev]) retired.push_back(g_gtab[dev]);
         if (g_gtab_ct[dev]) retired.push_back(g_gtab_ct[dev]);
+        if (g_gtab7[dev]) retired.push_back(reinterpret_cast<uint32_t *>(g_gtab7[dev]));
         g_gtab[dev] = nullptr;
         g_gtab_ct[dev] = nullptr;
+        g_gtab7[dev] = nullptr;
     }
     memcpy(g_gen_xy, want, 112);
     return CAPY_OK;

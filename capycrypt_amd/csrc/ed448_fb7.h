@@ -1,0 +1,114 @@
+// ed448_fb7.h — hardened fixed-base multiplication [k]G with the table lookups done by the MATRIX cores (device only; r03).
+//
+// Constant-address lookups mean that every entry of a window's table row is read and the wanted one kept, whatever the
+// (secret) digit is.  fb_scalarmul_ct (ed448_algo.h) does the keeping on the VALU: one v_bitop3_b32 per limb and entry,
+// 48 x 17 = 816 instructions per 5-bit window on top of a 2650-instruction mixed addition, 90 windows.  Wider windows
+// mean fewer additions but a longer scan, and the product is flat (ed448_algo.h) -- as long as the scan is VALU work.
+//
+// A table row is the same for all 64 items of a wave, and "keep entry idx[n] for item n" is a matrix product with a
+// one-hot matrix:  D[m][n] = sum_k T[k][m] * (idx[n] == k)  =  T[idx[n]][m].  With bytes as the elements that is
+// v_mfma_i32_16x16x64_i8 -- 64 table entries (k) x 16 bytes (m) x 16 items (n) per instruction, exact in int32, on a
+// pipe that runs beside the VALU.  So: 7-bit signed windows (|digit| - 1 = k in 0..63; digit 0 selects nothing, which
+// leaves all-zero bytes = the affine cached identity once y's limb 0 is set to 1), 65 windows instead of 90, and per
+// window 48 MFMAs (4 groups of 16 items x 12 groups of 16 bytes of the 192-byte entry) instead of 816 VALU selects.
+// Register r of lane l of a result holds byte 4 (l / 16) + r of the byte group for item l % 16 (+ 16 per item group) --
+// four consecutive bytes = one 28-bit limb, packed with two v_perm_b32 and one v_lshl_or_b32 and handed to the lane
+// that owns the item through LDS (row stride 68 dwords: conflict-free 16-byte reads).  Operand layouts checked on the
+// hardware by tools/probe_mfma_onehot.hip.  No address, branch or instruction count depends on the scalar: the digits
+// only enter as VALU data (the one-hot bytes, the negation mask, the identity fix-up).
+//
+// Table (built once per device from the ordinary affine cached entries, ed448.hip: build_gtab7): for row r (window r of
+// the recoded scalar, row 64 = the recoding carry), byte group mb, lane l = 16 g + c, slot s:
+//   gt7[((r * 12 + mb) * 64 + l) * 16 + s] = byte 16 mb + c of entry (16 g + s + 1) * 2^(7 r) * G      (798 720 bytes)
+// which is exactly the A operand of the instruction for (r, mb): one 16-byte load per lane.
+#pragma once
+#include "ed448_algo.h"
+
+namespace capy {
+
+constexpr int FB7_WBITS = 7;
+using Fb7Win = Win<FB7_WBITS>;
+constexpr int FB7_ROWS = Fb7Win::NWIN + 1;    // 64 windows + the recoding carry
+constexpr int FB7_ENTRIES = Fb7Win::ENTRIES;  // 65: 0 .. 64 times the row's base point (the linear table build_gtab7 starts from)
+constexpr int FB7_K = 64;                     // entries an MFMA sees: 1 .. 64 times the base point
+constexpr int FB7_GROUPS = 12;                // 192 bytes per entry / 16
+constexpr size_t FB7_TABLE_BYTES = (size_t)FB7_ROWS * FB7_GROUPS * 64 * 16;
+constexpr int FB7_XPOSE_STRIDE = 68;          // dwords per item in the LDS hand-over (48 used)
+static_assert(Fb7Win::HALF == FB7_K, "one MFMA covers the 64 non-zero magnitudes of a 7-bit signed digit");
+
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef int fb7_v4i __attribute__((ext_vector_type(4)));
+
+// the affine cached entry  sign(digit) * |digit| * 2^(7 row) * G  for every lane's own digit, selected by the matrix cores
+__device__ __forceinline__ void fb7_select(const uint8_t *__restrict__ gt7, int row, int digit, uint32_t *xpose, Fe &x2, Fe &y2, Fe &td2)
+{
+    const uint32_t lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+    const uint32_t neg = (uint32_t)(digit >> 31);            // all ones for a negative digit
+    const uint32_t mag = ((uint32_t)digit ^ neg) - neg;      // |digit|, 0 .. 64
+    // A operands: this row's 12 byte groups (the address depends on the row only)
+    const uint4 *rowp = reinterpret_cast<const uint4 *>(gt7) + ((size_t)row * FB7_GROUPS) * 64 + lane;
+    fb7_v4i a[FB7_GROUPS];
+#pragma unroll
+    for (int mb = 0; mb < FB7_GROUPS; mb++) {
+        const uint4 v = rowp[mb * 64];
+        a[mb] = fb7_v4i{(int)v.x, (int)v.y, (int)v.z, (int)v.w};
+    }
+    // B operands: one-hot bytes.  Lane (g, c) holds, for the item group ib, the k-slots 16 g .. 16 g + 15 of item 16 ib + c
+#pragma unroll
+    for (int ib = 0; ib < 4; ib++) {
+        const uint32_t m = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4 * (16 * ib + c)), (int)mag);
+        const uint32_t t = m - 1u - 16u * g;                  // slot within my 16, if < 16 (wraps to a huge value otherwise)
+        const uint32_t one = 1u << ((t & 3u) * 8u);
+        fb7_v4i b;
+#pragma unroll
+        for (int q = 0; q < 4; q++) b[q] = (int)(one & (0u - (uint32_t)((t >> 2) == (uint32_t)q)));
+#pragma unroll
+        for (int mb = 0; mb < FB7_GROUPS; mb++) {
+            const fb7_v4i d = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[mb], b, fb7_v4i{0, 0, 0, 0}, 0, 0, 0);
+            // bytes 4 g .. 4 g + 3 of group mb = limb dword 4 mb + g of item 16 ib + c
+            const uint32_t lo = __builtin_amdgcn_perm((uint32_t)d[1], (uint32_t)d[0], 0x0c0c0400u);
+            const uint32_t hi = __builtin_amdgcn_perm((uint32_t)d[3], (uint32_t)d[2], 0x0c0c0400u);
+            xpose[(16 * ib + c) * FB7_XPOSE_STRIDE + 4 * mb + g] = (hi << 16) | lo;
+        }
+    }
+    __syncthreads();  // one wave per block: orders the LDS writes above before the reads below
+    const uint32_t *mine = xpose + lane * FB7_XPOSE_STRIDE;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint4 vx = *reinterpret_cast<const uint4 *>(mine + 4 * q);
+        const uint4 vy = *reinterpret_cast<const uint4 *>(mine + 16 + 4 * q);
+        const uint4 vt = *reinterpret_cast<const uint4 *>(mine + 32 + 4 * q);
+        x2.l[4 * q] = vx.x, x2.l[4 * q + 1] = vx.y, x2.l[4 * q + 2] = vx.z, x2.l[4 * q + 3] = vx.w;
+        y2.l[4 * q] = vy.x, y2.l[4 * q + 1] = vy.y, y2.l[4 * q + 2] = vy.z, y2.l[4 * q + 3] = vy.w;
+        td2.l[4 * q] = vt.x, td2.l[4 * q + 1] = vt.y, td2.l[4 * q + 2] = vt.z, td2.l[4 * q + 3] = vt.w;
+    }
+    __syncthreads();  // the next window's writes come after these reads
+    y2.l[0] |= (uint32_t)(mag == 0);  // digit 0 selected nothing: (0, 0, 0) -> (0, 1, 0), the identity
+    // -(x, y) = (-x, y): negate x and d x y under the sign mask (limb-wise select, no branch)
+    const Fe nx = fe_neg_nr(x2), nt = fe_neg_nr(td2);
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        x2.l[i] = (nx.l[i] & neg) | (x2.l[i] & ~neg);
+        td2.l[i] = (nt.l[i] & neg) | (td2.l[i] & ~neg);
+    }
+}
+
+// [k]G: 65 mixed additions, every table byte of every row read by every wave
+__device__ __forceinline__ Pt fb7_scalarmul(const uint8_t *k_be, const uint8_t *__restrict__ gt7, uint32_t *xpose)
+{
+    uint32_t k[14], w[15];
+    sc_from_be(k, k_be);
+    const uint32_t top = sc_recode_signed<FB7_WBITS>(w, k);
+    Fe x2, y2, td2;
+    fb7_select(gt7, Fb7Win::NWIN, (int)top, xpose, x2, y2, td2);
+    Pt acc = pt_add_affine_cached(pt_identity(), x2, y2, td2);
+#pragma unroll 1
+    for (int i = 0; i < Fb7Win::NWIN; i++) {
+        fb7_select(gt7, i, sc_next_digit_lsb<FB7_WBITS>(w), xpose, x2, y2, td2);
+        acc = pt_add_affine_cached(acc, x2, y2, td2);
+    }
+    return acc;
+}
+#endif  // __HIP_DEVICE_COMPILE__
+
+}  // namespace capy
