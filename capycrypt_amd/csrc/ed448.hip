@@ -312,7 +312,8 @@ static bool harden(bool secret)
 // crossover is at ~10 000 items for variable base / double-scalar and ~5 000 for fixed base (profiles/r02_ed448_wave.txt),
 // hence a threshold of 8192 for those.  Fixed base, re-measured with the division-step inversion of r03 (lane kernel
 // 0.46 -> 0.30 ms at one wave per SIMD, wave kernel 0.147 -> 0.119 ms; profiles/r03_ed448_gcd_inversion.txt): the
-// crossover is ~3000 items indexed and ~6500 with constant-address lookups, hence 5/16 and 3/4 of the threshold.
+// crossover is ~3000 items indexed and ~6500 with constant-address lookups, hence 5/16 and 3/4 of the threshold; with
+// the constant-address lookups on the matrix cores (ed448_fb7.h: 0.52 ms at one wave per SIMD) ~3800, hence 7/16.
 // capy_ed448_set_wave_max() / CAPY_ED448_WAVE_MAX override the threshold (0 = never).
 static std::atomic<long> g_wave_max{-1};
 static size_t wave_max_items()
@@ -481,7 +482,7 @@ static int fb_launch(size_t n, const uint8_t *scalars, uint8_t *out, hipStream_t
 {
     if (!n) return CAPY_OK;
     const bool ct = harden(secret);
-    const bool small = n <= (ct ? wave_max_items() * 3 / 4 : wave_max_items() * 5 / 16);
+    const bool small = n <= (ct ? (CAPY_ED448_FBCT_MFMA ? wave_max_items() * 7 / 16 : wave_max_items() * 3 / 4) : wave_max_items() * 5 / 16);
     if (ct && !small && CAPY_ED448_FBCT_MFMA) {
         // every byte of the window's table row is read per window by every wave and the wanted entry is picked by a
         // one-hot matrix product on the matrix cores: no address depends on the scalar (ed448_fb7.h)

@@ -62,14 +62,14 @@ CAPY_HD inline Fe load_fe(const uint32_t *src)
 constexpr int VB_PF_DWORDS = 16 * 64 * 4;  // one cached point (64 dwords) per lane
 constexpr int FB_PF_DWORDS = 12 * 64 * 4;  // one affine cached entry (48 dwords) per lane
 #if defined(__HIP_DEVICE_COMPILE__)
-template <int QUADS>
+template <int QUADS, int SRC_STRIDE_DWORDS = 4>  // piece q of a lane is read from src + q * SRC_STRIDE_DWORDS
 __device__ __forceinline__ void lds_prefetch(uint32_t *lds, const uint32_t *src)
 {
     // the staging area may still be being read (ds_read of the previous entry): let those reads land first
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
 #pragma unroll
     for (int q = 0; q < QUADS; q++)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 4 * q),
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + SRC_STRIDE_DWORDS * q),
                                          (__attribute__((address_space(3))) void *)(lds + q * 256), 16, 0, 0);
 }
 // the requested entry has arrived.  The compiler puts this wait in front of an LDS read that follows the request in

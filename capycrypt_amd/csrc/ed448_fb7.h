@@ -39,20 +39,32 @@ static_assert(Fb7Win::HALF == FB7_K, "one MFMA covers the 64 non-zero magnitudes
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef int fb7_v4i __attribute__((ext_vector_type(4)));
 
+// row `row` of the table on its way into the hand-over area (12 x 1 KiB, no VGPRs; ed448_algo.h: lds_prefetch)
+__device__ __forceinline__ void fb7_request_row(const uint8_t *__restrict__ gt7, int row, uint32_t *xpose)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    lds_prefetch<FB7_GROUPS, 256>(xpose, reinterpret_cast<const uint32_t *>(gt7) + ((size_t)row * FB7_GROUPS * 64 + lane) * 4);
+}
+
 // the affine cached entry  sign(digit) * |digit| * 2^(7 row) * G  for every lane's own digit, selected by the matrix cores
-__device__ __forceinline__ void fb7_select(const uint8_t *__restrict__ gt7, int row, int digit, uint32_t *xpose, Fe &x2, Fe &y2, Fe &td2)
+__device__ __forceinline__ void fb7_select(const uint8_t *__restrict__ gt7, int row, int next_row, int digit, uint32_t *xpose, Fe &x2, Fe &y2,
+                                           Fe &td2)
 {
     const uint32_t lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
     const uint32_t neg = (uint32_t)(digit >> 31);            // all ones for a negative digit
     const uint32_t mag = ((uint32_t)digit ^ neg) - neg;      // |digit|, 0 .. 64
-    // A operands: this row's 12 byte groups (the address depends on the row only)
-    const uint4 *rowp = reinterpret_cast<const uint4 *>(gt7) + ((size_t)row * FB7_GROUPS) * 64 + lane;
+    // A operands: this row's 12 byte groups (the address depends on the row only).  They were requested memory -> LDS
+    // (fb7_request_row) before the previous addition and sit in the hand-over area, which is free until the first
+    // result is written below
     fb7_v4i a[FB7_GROUPS];
+    lds_prefetch_wait();
 #pragma unroll
     for (int mb = 0; mb < FB7_GROUPS; mb++) {
-        const uint4 v = rowp[mb * 64];
+        const uint4 v = *reinterpret_cast<const uint4 *>(xpose + (mb * 64 + lane) * 4);
         a[mb] = fb7_v4i{(int)v.x, (int)v.y, (int)v.z, (int)v.w};
     }
+    (void)row;
+    __syncthreads();  // every lane has its operands before the area is overwritten
     // B operands: one-hot bytes.  Lane (g, c) holds, for the item group ib, the k-slots 16 g .. 16 g + 15 of item 16 ib + c
 #pragma unroll
     for (int ib = 0; ib < 4; ib++) {
@@ -62,13 +74,22 @@ __device__ __forceinline__ void fb7_select(const uint8_t *__restrict__ gt7, int 
         fb7_v4i b;
 #pragma unroll
         for (int q = 0; q < 4; q++) b[q] = (int)(one & (0u - (uint32_t)((t >> 2) == (uint32_t)q)));
+        // four products in flight before the first is packed (a result is readable ~8 cycles after its issue: packed
+        // one by one every MFMA would be followed by that many idle cycles)
 #pragma unroll
-        for (int mb = 0; mb < FB7_GROUPS; mb++) {
-            const fb7_v4i d = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[mb], b, fb7_v4i{0, 0, 0, 0}, 0, 0, 0);
-            // bytes 4 g .. 4 g + 3 of group mb = limb dword 4 mb + g of item 16 ib + c
-            const uint32_t lo = __builtin_amdgcn_perm((uint32_t)d[1], (uint32_t)d[0], 0x0c0c0400u);
-            const uint32_t hi = __builtin_amdgcn_perm((uint32_t)d[3], (uint32_t)d[2], 0x0c0c0400u);
-            xpose[(16 * ib + c) * FB7_XPOSE_STRIDE + 4 * mb + g] = (hi << 16) | lo;
+        for (int mb0 = 0; mb0 < FB7_GROUPS; mb0 += 4) {
+            fb7_v4i d[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) d[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[mb0 + j], b, fb7_v4i{0, 0, 0, 0}, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                // bytes 4 g .. 4 g + 3 of group mb = limb dword 4 mb + g of item 16 ib + c
+                const uint32_t lo = __builtin_amdgcn_perm((uint32_t)d[j][1], (uint32_t)d[j][0], 0x0c0c0400u);
+                const uint32_t hi = __builtin_amdgcn_perm((uint32_t)d[j][3], (uint32_t)d[j][2], 0x0c0c0400u);
+                xpose[(16 * ib + c) * FB7_XPOSE_STRIDE + 4 * (mb0 + j) + g] = (hi << 16) | lo;
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     __syncthreads();  // one wave per block: orders the LDS writes above before the reads below
@@ -83,6 +104,7 @@ __device__ __forceinline__ void fb7_select(const uint8_t *__restrict__ gt7, int 
         td2.l[4 * q] = vt.x, td2.l[4 * q + 1] = vt.y, td2.l[4 * q + 2] = vt.z, td2.l[4 * q + 3] = vt.w;
     }
     __syncthreads();  // the next window's writes come after these reads
+    if (next_row >= 0) fb7_request_row(gt7, next_row, xpose);  // wave-uniform; lands while the addition runs
     y2.l[0] |= (uint32_t)(mag == 0);  // digit 0 selected nothing: (0, 0, 0) -> (0, 1, 0), the identity
     // -(x, y) = (-x, y): negate x and d x y under the sign mask (limb-wise select, no branch)
     const Fe nx = fe_neg_nr(x2), nt = fe_neg_nr(td2);
@@ -100,11 +122,12 @@ __device__ __forceinline__ Pt fb7_scalarmul(const uint8_t *k_be, const uint8_t *
     sc_from_be(k, k_be);
     const uint32_t top = sc_recode_signed<FB7_WBITS>(w, k);
     Fe x2, y2, td2;
-    fb7_select(gt7, Fb7Win::NWIN, (int)top, xpose, x2, y2, td2);
+    fb7_request_row(gt7, Fb7Win::NWIN, xpose);
+    fb7_select(gt7, Fb7Win::NWIN, 0, (int)top, xpose, x2, y2, td2);
     Pt acc = pt_add_affine_cached(pt_identity(), x2, y2, td2);
 #pragma unroll 1
     for (int i = 0; i < Fb7Win::NWIN; i++) {
-        fb7_select(gt7, i, sc_next_digit_lsb<FB7_WBITS>(w), xpose, x2, y2, td2);
+        fb7_select(gt7, i, i + 1 < Fb7Win::NWIN ? i + 1 : -1, sc_next_digit_lsb<FB7_WBITS>(w), xpose, x2, y2, td2);
         acc = pt_add_affine_cached(acc, x2, y2, td2);
     }
     return acc;

@@ -197,7 +197,7 @@ int capy_ed448_set_hardened(int mode);
 /* Tuning / A-B switch (process-wide): batches of up to max_items scalar multiplications take the one-item-per-wave
  * kernels (csrc/ed448_wave.h: a field element spread over 16 lanes, the four coordinates of a point in the four rows of
  * a wave; 6x / 2.5x lower latency than one item per lane for variable / fixed base, less throughput; fixed-base
- * batches switch at 5/16 of the value, with constant-address lookups at 3/4).  0 = never, negative = the built-in
+ * batches switch at 5/16 of the value, with constant-address lookups at 7/16).  0 = never, negative = the built-in
  * default (8192).  Results are bit-identical either way; the constant-address (hardened) forms exist for both. */
 int capy_ed448_set_wave_max(long max_items);
 
