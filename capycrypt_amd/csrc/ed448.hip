@@ -29,12 +29,19 @@ __attribute__((amdgpu_num_vgpr(CAPY_ED448_NUMVGPR)))
 // Table entries fetched ahead through LDS (ed448_algo.h: lds_prefetch) in the lane-per-item kernels that run at ONE wave
 // per SIMD (the two-items-per-lane kernels run two, which hide each other's waits).  Measured at 65 536 items
 // (profiles/r03_ed448_prefetch.txt): fixed base 0.327 -> 0.299 ms, on by default; variable base 2.886 -> 2.984 ms (the
-// loop's register allocation gets worse: 96 instead of 44 spilled VGPRs), off by default.
+// loop's register allocation gets worse: 96 instead of 44 spilled VGPRs; with the entry's operands read from LDS one by
+// one inside the addition 55, and 2.72 ms either way), off by default.
 #ifndef CAPY_ED448_PREFETCH_FB
 #define CAPY_ED448_PREFETCH_FB 1
 #endif
 #ifndef CAPY_ED448_PREFETCH_VB
 #define CAPY_ED448_PREFETCH_VB 0
+#endif
+// double_scalarmul (verify): both parts fetch ahead.  With the entry's operands read from LDS one by one inside the
+// addition the kernel spills 123 instead of 172 VGPRs: 2^16 verifications 3.65 -> 3.54 ms (the variable-base kernel alone:
+// 2.72 ms either way at one wave per SIMD, 4.80 -> 4.91 at two)
+#ifndef CAPY_ED448_PREFETCH_DSM
+#define CAPY_ED448_PREFETCH_DSM 1
 #endif
 __global__ __launch_bounds__(64, CAPY_ED448_WAVES) void vb_kernel(uint64_t n, const uint8_t *scalars_be, uint64_t scalar_stride,
                                                 const uint8_t *points_xy, uint64_t point_stride, uint8_t *out_xy,
@@ -197,10 +204,8 @@ __global__ __launch_bounds__(64, CAPY_ED448_WAVES) void dsm_kernel(uint64_t n, c
 {
     const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
     if (i >= n) return;
-#if CAPY_ED448_PREFETCH_VB
-    __shared__ uint32_t pf[VB_PF_DWORDS];
-#elif CAPY_ED448_PREFETCH_FB
-    __shared__ uint32_t pf[FB_PF_DWORDS];
+#if CAPY_ED448_PREFETCH_DSM
+    __shared__ uint32_t pf[VB_PF_DWORDS];  // serves the variable-base part, then the fixed-base part
 #else
     uint32_t *const pf = nullptr;
 #endif

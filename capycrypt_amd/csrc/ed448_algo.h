@@ -56,9 +56,6 @@ CAPY_HD inline Fe load_fe(const uint32_t *src)
 // before the current addition (fixed base) and read from LDS when it is needed; the compiler's vmcnt wait sits in
 // front of that read.  Piece q (16 bytes) of lane l lands at dword (q * 64 + l) * 4 of the wave's staging area.
 // `lds` = nullptr (host build, constant-address forms, one-item-per-wave kernels) keeps the direct loads.
-#ifndef CAPY_ED448_PREFETCH_VB_IN_DSM
-#define CAPY_ED448_PREFETCH_VB_IN_DSM 0  // the staging area of double_scalarmul serves its fixed-base part only
-#endif
 constexpr int VB_PF_DWORDS = 16 * 64 * 4;  // one cached point (64 dwords) per lane
 constexpr int FB_PF_DWORDS = 12 * 64 * 4;  // one affine cached entry (48 dwords) per lane
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -251,10 +248,29 @@ CAPY_HD_INLINE Pt vb_scalarmul(const uint8_t *k_be, const Pt &P, uint32_t *tab, 
             CAPY_UNROLL(CAPY_ED448_DBL_UNROLL)
             for (int j = 0; j < WBITS; j++) acc = pt_dbl<true>(acc);
             lds_prefetch_wait();
-            Fe X2 = lds_load_fe(lds, 0), Y2 = lds_load_fe(lds, 1), Z2 = lds_load_fe(lds, 2), Td2 = lds_load_fe(lds, 3);
-            X2 = fe_select(neg, X2, fe_neg_nr(X2));
-            Td2 = fe_select(neg, Td2, fe_neg_nr(Td2));
-            acc = pt_add_cached(acc, X2, Y2, Z2, Td2);
+            // pt_add_cached with every operand of the entry read from LDS right before its multiplication (16 live
+            // registers for the entry instead of 64: the doubling loop around this keeps 256 VGPRs busy)
+            {
+                const Pt p = acc;
+                Fe Td2 = lds_load_fe(lds, 3);
+                Td2 = fe_select(neg, Td2, fe_neg_nr(Td2));
+                const Fe C = fe_mul(p.T, Td2);
+                __builtin_amdgcn_sched_barrier(0);
+                const Fe D = fe_mul(p.Z, lds_load_fe(lds, 2));
+                __builtin_amdgcn_sched_barrier(0);
+                const Fe F = fe_sub_nr(D, C), G = fe_add_nr(D, C);
+                Fe X2 = lds_load_fe(lds, 0);
+                X2 = fe_select(neg, X2, fe_neg_nr(X2));
+                const Fe Y2 = lds_load_fe(lds, 1);
+                const Fe A = fe_mul(p.X, X2), B = fe_mul(p.Y, Y2);
+                Fe E = fe_mul(fe_add_nr(p.X, p.Y), fe_add_nr(X2, Y2));
+                E = fe_sub(fe_sub_nr(E, A), B);
+                const Fe H = fe_sub_nr(B, A);
+                acc.X = fe_mul(E, F);
+                acc.Y = fe_mul(G, H);
+                acc.Z = fe_mul(F, G);
+                acc.T = fe_mul(E, H);
+            }
         }
         return acc;
     }
@@ -376,7 +392,7 @@ CAPY_HD_INLINE Pt fb_scalarmul(const uint8_t *k_be, const uint32_t *gtab, uint32
 CAPY_HD_INLINE Pt double_scalarmul(const uint8_t *a_be, const uint8_t *b_be, const Pt &P, uint32_t *tab,
                                    const uint32_t *gtab, uint32_t *lds = nullptr)
 {
-    Pt acc = vb_scalarmul(b_be, P, tab, CAPY_ED448_PREFETCH_VB_IN_DSM ? lds : nullptr);
+    Pt acc = vb_scalarmul(b_be, P, tab, lds);
     uint32_t ka[14], wa[15];
     sc_from_be(ka, a_be);
     const uint32_t topa = sc_recode_signed<FB_WBITS>(wa, ka);

@@ -47,8 +47,8 @@ __device__ __forceinline__ void fb7_request_row(const uint8_t *__restrict__ gt7,
 }
 
 // the affine cached entry  sign(digit) * |digit| * 2^(7 row) * G  for every lane's own digit, selected by the matrix cores
-__device__ __forceinline__ void fb7_select(const uint8_t *__restrict__ gt7, int row, int next_row, int digit, uint32_t *xpose, Fe &x2, Fe &y2,
-                                           Fe &td2)
+// (the row itself was requested by fb7_request_row; next_row >= 0: request that one before returning)
+__device__ __forceinline__ void fb7_select(const uint8_t *__restrict__ gt7, int next_row, int digit, uint32_t *xpose, Fe &x2, Fe &y2, Fe &td2)
 {
     const uint32_t lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
     const uint32_t neg = (uint32_t)(digit >> 31);            // all ones for a negative digit
@@ -63,7 +63,6 @@ __device__ __forceinline__ void fb7_select(const uint8_t *__restrict__ gt7, int 
         const uint4 v = *reinterpret_cast<const uint4 *>(xpose + (mb * 64 + lane) * 4);
         a[mb] = fb7_v4i{(int)v.x, (int)v.y, (int)v.z, (int)v.w};
     }
-    (void)row;
     __syncthreads();  // every lane has its operands before the area is overwritten
     // B operands: one-hot bytes.  Lane (g, c) holds, for the item group ib, the k-slots 16 g .. 16 g + 15 of item 16 ib + c
 #pragma unroll
@@ -123,11 +122,11 @@ __device__ __forceinline__ Pt fb7_scalarmul(const uint8_t *k_be, const uint8_t *
     const uint32_t top = sc_recode_signed<FB7_WBITS>(w, k);
     Fe x2, y2, td2;
     fb7_request_row(gt7, Fb7Win::NWIN, xpose);
-    fb7_select(gt7, Fb7Win::NWIN, 0, (int)top, xpose, x2, y2, td2);
+    fb7_select(gt7, 0, (int)top, xpose, x2, y2, td2);
     Pt acc = pt_add_affine_cached(pt_identity(), x2, y2, td2);
 #pragma unroll 1
     for (int i = 0; i < Fb7Win::NWIN; i++) {
-        fb7_select(gt7, i, i + 1 < Fb7Win::NWIN ? i + 1 : -1, sc_next_digit_lsb<FB7_WBITS>(w), xpose, x2, y2, td2);
+        fb7_select(gt7, i + 1 < Fb7Win::NWIN ? i + 1 : -1, sc_next_digit_lsb<FB7_WBITS>(w), xpose, x2, y2, td2);
         acc = pt_add_affine_cached(acc, x2, y2, td2);
     }
     return acc;
