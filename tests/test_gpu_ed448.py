@@ -593,7 +593,8 @@ def test_hardened_mode_is_bit_identical(capy, O):
     on the constant-address kernels (every row of the window table read per window, no address depends on a scalar),
     mode 3 the raw multiplications as well, mode 0 none.  Every result must be the same in all three and equal the
     oracle's: raw operations, key pairs, signatures, ECDHIES -- with the one-item-per-wave kernels and without (the
-    autouse fixture), i.e. through wave::*<true> and vb_ct / fb_ct (fb2_kernel<true>: test_hardened_pair_kernels_match)."""
+    autouse fixture), i.e. through wave::*<true> and vb_ct_kernel / fb_ct7_kernel (the fixed base with its lookups on the
+    matrix cores, csrc/ed448_fb7.h; a full-size ragged batch of it: test_hardened_pair_kernels_match)."""
     rng = random.Random(0xC7)
     n = 130
     ks = [rng.randbytes(56) for _ in range(n)]
@@ -653,7 +654,8 @@ def test_scalar_star_modes_match_oracle(capy, O):
 
 def test_hardened_pair_kernels_match(capy, O, ed448_kernel_family):
     """The kernels of batches from 262 144 items: two items per lane sharing one inversion (vb2_kernel, fb2_kernel<false>)
-    against their constant-address counterparts (vb_ct_kernel, fb2_kernel<true>).  CAPY_ED448_PAIR cannot be switched at
+    against their constant-address counterparts (vb_ct_kernel, fb_ct7_kernel: 7-bit windows selected by a one-hot matrix
+    product, every one of the 262 214 results compared).  CAPY_ED448_PAIR cannot be switched at
     run time, so a batch of the real threshold size (with a ragged last wave) runs once in mode 0 and once in mode 3 and
     must agree item by item; a sample is checked against the oracle."""
     import ctypes as C
