@@ -768,3 +768,34 @@ def test_wave_kernels_equal_lane_kernels_on_edge_cases(capy, O, ed448_kernel_fam
     for i in (0, 1, 3, 6, 11, n - 1):
         assert results[1][0][i] == O.ed448_scalarmul(kb[i], pts[i]), i
         assert results[1][1][i] == O.ed448_basemul(kb[i]), i
+
+
+def test_matrix_core_fixed_base_on_structured_scalars(capy, O, ed448_kernel_family):
+    """csrc/ed448_fb7.h: the hardened fixed base selects its table entries with a one-hot matrix product over 7-bit signed
+    windows.  Scalars that put every window at its extremes -- the same 7-bit pattern everywhere (0, 1, 63, 64, 65, 127),
+    one window at a time at 64 (digit -64 and a carry), at 63, or cleared in an all-ones scalar, repeated bytes, values
+    around multiples of the group order, 2^448 - 1 -- must give the indexed kernel's and the oracle's points."""
+    from capycrypt_amd import _lib
+
+    if ed448_kernel_family != 0:
+        pytest.skip("forces the lane-per-item kernels itself")
+    lib = _lib.lib()
+    R = (1 << 446) - 0x8335dc163bb124b65129c96fde933d8d723a70aadc873d6d54a7bb0d
+    ks = [0, 1, 2, 63, 64, 65, 127, 128, (1 << 448) - 1, 1 << 447, (1 << 447) - 1, R, R - 1, R + 1, 2 * R, 3 * R + 5]
+    ks += [sum(d << (7 * i) for i in range(64)) & ((1 << 448) - 1) for d in (0, 1, 63, 64, 65, 127)]
+    for i in range(64):
+        ks += [64 << (7 * i), 63 << (7 * i), ((1 << 448) - 1) ^ (127 << (7 * i))]
+    ks += [int.from_bytes(bytes([b]) * 56, "big") for b in (0x55, 0xAA, 0x7F, 0x80, 0xFE, 0x01)]
+    kb = [k.to_bytes(56, "big") for k in ks]
+    try:
+        _lib.check(lib.capy_ed448_set_wave_max(0))
+        capy.ops.ed448_set_hardened(3)
+        hard = capy.ops.ed448_basemul_batch(kb)
+        capy.ops.ed448_set_hardened(0)
+        plain = capy.ops.ed448_basemul_batch(kb)
+    finally:
+        capy.ops.ed448_set_hardened(1)
+        _lib.check(lib.capy_ed448_set_wave_max(-1))
+    assert hard == plain
+    for i in list(range(0, 22)) + list(range(22, len(ks), 17)):
+        assert hard[i] == O.ed448_basemul(kb[i]), hex(ks[i])
