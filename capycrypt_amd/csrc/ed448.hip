@@ -95,6 +95,43 @@ __global__ __launch_bounds__(64, CAPY_ED448_WAVES) void fb_ct7_kernel(uint64_t n
 #endif
 }
 
+// the same with two items per lane sharing one inversion (as fb2_kernel): lane l takes the items base + l and
+// base + 64 + l of the wave's 128.  The first result waits in global scratch (park: 48 dwords per lane, 16-byte pieces
+// interleaved across the wave's lanes) -- the LDS is taken by the hand-over area and 48 more VGPRs would spill.
+__global__ __launch_bounds__(64, CAPY_ED448_WAVES) void fb_ct7_pair_kernel(uint64_t n, const uint8_t *scalars_be, uint8_t *out_xy,
+                                                         const uint8_t *gt7, uint32_t *park)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ uint32_t xpose[64 * FB7_XPOSE_STRIDE];
+    const uint64_t base = (uint64_t)blockIdx.x * 128 + threadIdx.x;
+    const uint64_t i0 = base < n ? base : n - 1, i1 = base + 64 < n ? base + 64 : i0;
+    uint4 *mine = reinterpret_cast<uint4 *>(park) + (uint64_t)blockIdx.x * 12 * 64 + threadIdx.x;
+    {
+        const Pt r0 = fb7_scalarmul(scalars_be + i0 * 56, gt7, xpose);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            mine[q * 64] = uint4{r0.X.l[4 * q], r0.X.l[4 * q + 1], r0.X.l[4 * q + 2], r0.X.l[4 * q + 3]};
+            mine[(4 + q) * 64] = uint4{r0.Y.l[4 * q], r0.Y.l[4 * q + 1], r0.Y.l[4 * q + 2], r0.Y.l[4 * q + 3]};
+            mine[(8 + q) * 64] = uint4{r0.Z.l[4 * q], r0.Z.l[4 * q + 1], r0.Z.l[4 * q + 2], r0.Z.l[4 * q + 3]};
+        }
+    }
+    const Pt r1 = fb7_scalarmul(scalars_be + i1 * 56, gt7, xpose);
+    Pt r0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint4 vx = mine[q * 64], vy = mine[(4 + q) * 64], vz = mine[(8 + q) * 64];
+        r0.X.l[4 * q] = vx.x, r0.X.l[4 * q + 1] = vx.y, r0.X.l[4 * q + 2] = vx.z, r0.X.l[4 * q + 3] = vx.w;
+        r0.Y.l[4 * q] = vy.x, r0.Y.l[4 * q + 1] = vy.y, r0.Y.l[4 * q + 2] = vy.z, r0.Y.l[4 * q + 3] = vy.w;
+        r0.Z.l[4 * q] = vz.x, r0.Z.l[4 * q + 1] = vz.y, r0.Z.l[4 * q + 2] = vz.z, r0.Z.l[4 * q + 3] = vz.w;
+    }
+    r0.T = fe_zero();  // not needed for the conversion
+    if (base + 64 < n)
+        pt_pair_to_affine_bytes(out_xy + base * 112, out_xy + (base + 64) * 112, r0, r1);
+    else if (base < n)
+        pt_to_affine_bytes(out_xy + base * 112, r0);
+#endif
+}
+
 // the linear table (rows x 65 affine cached entries of 48 limb dwords) re-laid as MFMA A operands (ed448_fb7.h)
 __global__ void gtab7_pack_kernel(const uint32_t *lin, uint32_t *gt7_words)
 {
@@ -494,7 +531,16 @@ static int fb_launch(size_t n, const uint8_t *scalars, uint8_t *out, hipStream_t
         const uint8_t *gt7 = nullptr;
         const int rc7 = ensure_gtab7(&gt7);
         if (rc7) return rc7;
-        hipLaunchKernelGGL(fb_ct7_kernel, grid64(n), dim3(64), 0, s, (uint64_t)n, scalars, out, gt7);
+        if (n >= pair_min_items()) {
+            const size_t blocks = (n + 127) / 128;
+            CAPY_WS(park, uint32_t *, s, WS_TABLE, blocks * 64 * 48 * 4);
+            hipLaunchKernelGGL(fb_ct7_pair_kernel, dim3((unsigned)blocks), dim3(64), 0, s, (uint64_t)n, scalars, out, gt7, park);
+            // the parked PROJECTIVE results of secret multiples must not outlive the call (a projective representation
+            // of [k]G says more about k than the affine point does)
+            CAPY_HIP(hipMemsetAsync(park, 0, blocks * 64 * 48 * 4, s));
+        } else {
+            hipLaunchKernelGGL(fb_ct7_kernel, grid64(n), dim3(64), 0, s, (uint64_t)n, scalars, out, gt7);
+        }
         CAPY_HIP(hipGetLastError());
         return CAPY_OK;
     }
