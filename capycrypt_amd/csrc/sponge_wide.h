@@ -35,6 +35,10 @@ __device__ __forceinline__ uint32_t xor_and(uint32_t a, uint32_t b, uint32_t c)
 // bitwise select: (m & a) | (~m & b), one v_bitop3_b32 (truth table 0xCA with the mask as first operand)
 __device__ __forceinline__ uint32_t wide_sel(uint32_t m, uint32_t a, uint32_t b) { return __builtin_amdgcn_bitop3_b32(m, a, b, 0xCA); }
 
+// rho as two 64-bit shifts (1) or as selects around v_alignbit_b32 (0): see wide_round
+#ifndef CAPY_WIDE_RHO_SHIFT64
+#define CAPY_WIDE_RHO_SHIFT64 1
+#endif
 struct WideIdx {
     uint32_t up[4];                 // byte index of GPU lane (x, y+k), k = 1..4
     uint32_t b0, b1, b2;            // pi sources of B[x], B[x+1], B[x+2] in row y
@@ -88,9 +92,15 @@ __device__ __forceinline__ WideIdx wide_setup()
     w.b1 = src(x + 1, y);
     w.b2 = src(x + 2, y);
     const uint32_t r = wide_rho(i);
+#if CAPY_WIDE_RHO_SHIFT64
+    w.sh = r;                   // left shift amount
+    w.m_swap = (64 - r) & 63;   // right shift amount (0 for r = 0: v | v)
+    w.m_zero = 0;
+#else
     w.sh = (32 - (r & 31)) & 31;
     w.m_swap = r >= 32 ? ~0u : 0u;
     w.m_zero = (r & 31) == 0 ? ~0u : 0u;
+#endif
     w.m_l0 = i == 0 ? ~0u : 0u;
     w.self = 4 * (base + i);
     return w;
@@ -116,10 +126,19 @@ __device__ __forceinline__ void wide_round(uint32_t &lo, uint32_t &hi, const Wid
     const uint32_t rl = __builtin_amdgcn_alignbit(pl, ph, 31), rh = __builtin_amdgcn_alignbit(ph, pl, 31);  // rol 1
     uint32_t el = xor3(lo, ml, rl), eh = xor3(hi, mh, rh);
     // rho: rotate left by this lane's own offset
+#if CAPY_WIDE_RHO_SHIFT64
+    // two 64-bit shifts and two ORs (the shifter takes the amount mod 64, so an offset of 0 gives v | v); the 32-bit form
+    // below needs two selects before and two after its two alignbits
+    const uint64_t v = ((uint64_t)eh << 32) | el;
+    const uint64_t rot = (v << w.sh) | (v >> w.m_swap);
+    el = (uint32_t)rot;
+    eh = (uint32_t)(rot >> 32);
+#else
     const uint32_t a = wide_sel(w.m_swap, eh, el), b = wide_sel(w.m_swap, el, eh);
     const uint32_t ra = __builtin_amdgcn_alignbit(a, b, w.sh), rb = __builtin_amdgcn_alignbit(b, a, w.sh);
     el = wide_sel(w.m_zero, a, ra);
     eh = wide_sel(w.m_zero, b, rb);
+#endif
     // pi + chi (the gathers read lanes 0..24 / 32..56 only, so a mirroring lane ends the round with its original's state)
     const uint32_t b0l = wide_bperm(w.b0, el), b1l = wide_bperm(w.b1, el), b2l = wide_bperm(w.b2, el);
     const uint32_t b0h = wide_bperm(w.b0, eh), b1h = wide_bperm(w.b1, eh), b2h = wide_bperm(w.b2, eh);
