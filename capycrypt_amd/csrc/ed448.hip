@@ -87,7 +87,7 @@ __global__ __launch_bounds__(64, CAPY_ED448_WAVES) void fb_ct7_kernel(uint64_t n
                                                     const uint8_t *gt7)
 {
 #if defined(__HIP_DEVICE_COMPILE__)  // (the MFMA builtins exist in the device pass only)
-    __shared__ uint32_t xpose[64 * FB7_XPOSE_STRIDE];
+    __shared__ uint32_t xpose[FB7_LDS_DWORDS];
     const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
     const uint64_t src = i < n ? i : n - 1;
     const Pt r = fb7_scalarmul(scalars_be + src * 56, gt7, xpose);
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(64, CAPY_ED448_WAVES) void fb_ct7_pair_kernel(uint6
                                                          const uint8_t *gt7, uint32_t *park)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    __shared__ uint32_t xpose[64 * FB7_XPOSE_STRIDE];
+    __shared__ uint32_t xpose[FB7_LDS_DWORDS];
     const uint64_t base = (uint64_t)blockIdx.x * 128 + threadIdx.x;
     const uint64_t i0 = base < n ? base : n - 1, i1 = base + 64 < n ? base + 64 : i0;
     uint4 *mine = reinterpret_cast<uint4 *>(park) + (uint64_t)blockIdx.x * 12 * 64 + threadIdx.x;
@@ -135,13 +135,14 @@ __global__ __launch_bounds__(64, CAPY_ED448_WAVES) void fb_ct7_pair_kernel(uint6
 // the linear table (rows x 65 affine cached entries of 48 limb dwords) re-laid as MFMA A operands (ed448_fb7.h)
 __global__ void gtab7_pack_kernel(const uint32_t *lin, uint32_t *gt7_words)
 {
-    const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;  // output dword: ((row * 12 + mb) * 64 + lane) * 4 + sq
+    const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;  // output dword: (((row * KBLOCKS + kb) * 12 + mb) * 64 + lane) * 4 + sq
     if (o >= FB7_TABLE_BYTES / 4) return;
-    const uint32_t sq = o & 3, lane = (o >> 2) & 63, rm = o >> 8, mb = rm % FB7_GROUPS, row = rm / FB7_GROUPS;
+    const uint32_t sq = o & 3, lane = (o >> 2) & 63, rm = o >> 8, mb = rm % FB7_GROUPS, rk = rm / FB7_GROUPS;
+    const uint32_t kb = rk % FB7_KBLOCKS, row = rk / FB7_KBLOCKS;
     const uint32_t g = lane >> 4, c = lane & 15, bi = 16 * mb + c;
     uint32_t v = 0;
     for (uint32_t t = 0; t < 4; t++) {
-        const uint32_t entry = 16 * g + 4 * sq + t + 1;
+        const uint32_t entry = 64 * kb + 16 * g + 4 * sq + t + 1;
         const uint32_t w = lin[((size_t)row * FB7_ENTRIES + entry) * FB_ENTRY_DWORDS + bi / 4];
         v |= ((w >> (8 * (bi & 3))) & 0xffu) << (8 * t);
     }

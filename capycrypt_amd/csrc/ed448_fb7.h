@@ -20,21 +20,29 @@
 // Table (built once per device from the ordinary affine cached entries, ed448.hip: build_gtab7): for row r (window r of
 // the recoded scalar, row 64 = the recoding carry), byte group mb, lane l = 16 g + c, slot s:
 //   gt7[((r * 12 + mb) * 64 + l) * 16 + s] = byte 16 mb + c of entry (16 g + s + 1) * 2^(7 r) * G      (798 720 bytes)
+// (with 8-bit windows: ((r * 2 + kb) * 12 + mb) and entry 64 kb + 16 g + s + 1, 1 400 832 bytes)
 // which is exactly the A operand of the instruction for (r, mb): one 16-byte load per lane.
 #pragma once
 #include "ed448_algo.h"
 
 namespace capy {
 
-constexpr int FB7_WBITS = 7;
+// CAPY_ED448_FB7_WBITS = 7 (default) or 8: 8-bit windows take two MFMAs per product (128 magnitudes = two K blocks of 64,
+// the second accumulating onto the first) for 57 additions instead of 65; measured in profiles/r03_ed448_fb7_mfma.txt
+#ifndef CAPY_ED448_FB7_WBITS
+#define CAPY_ED448_FB7_WBITS 7
+#endif
+constexpr int FB7_WBITS = CAPY_ED448_FB7_WBITS;
+static_assert(FB7_WBITS == 7 || FB7_WBITS == 8, "one or two K blocks of 64 entries");
 using Fb7Win = Win<FB7_WBITS>;
-constexpr int FB7_ROWS = Fb7Win::NWIN + 1;    // 64 windows + the recoding carry
-constexpr int FB7_ENTRIES = Fb7Win::ENTRIES;  // 65: 0 .. 64 times the row's base point (the linear table build_gtab7 starts from)
-constexpr int FB7_K = 64;                     // entries an MFMA sees: 1 .. 64 times the base point
+constexpr int FB7_ROWS = Fb7Win::NWIN + 1;    // the windows + the recoding carry
+constexpr int FB7_ENTRIES = Fb7Win::ENTRIES;  // 0 .. 2^(W-1) times the row's base point (the linear table build_gtab7 starts from)
+constexpr int FB7_KBLOCKS = Fb7Win::HALF / 64;  // MFMAs per product: each sees 64 entries
 constexpr int FB7_GROUPS = 12;                // 192 bytes per entry / 16
-constexpr size_t FB7_TABLE_BYTES = (size_t)FB7_ROWS * FB7_GROUPS * 64 * 16;
+constexpr size_t FB7_TABLE_BYTES = (size_t)FB7_ROWS * FB7_KBLOCKS * FB7_GROUPS * 64 * 16;
 constexpr int FB7_XPOSE_STRIDE = 68;          // dwords per item in the LDS hand-over (48 used)
-static_assert(Fb7Win::HALF == FB7_K, "one MFMA covers the 64 non-zero magnitudes of a 7-bit signed digit");
+// the LDS area serves as the staging of the next row (KBLOCKS x 12 KiB) and then as the hand-over (64 x 68 dwords)
+constexpr int FB7_LDS_DWORDS = FB7_KBLOCKS * FB7_GROUPS * 256 > 64 * FB7_XPOSE_STRIDE ? FB7_KBLOCKS * FB7_GROUPS * 256 : 64 * FB7_XPOSE_STRIDE;
 
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef int fb7_v4i __attribute__((ext_vector_type(4)));
@@ -43,7 +51,8 @@ typedef int fb7_v4i __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void fb7_request_row(const uint8_t *__restrict__ gt7, int row, uint32_t *xpose)
 {
     const uint32_t lane = threadIdx.x & 63;
-    lds_prefetch<FB7_GROUPS, 256>(xpose, reinterpret_cast<const uint32_t *>(gt7) + ((size_t)row * FB7_GROUPS * 64 + lane) * 4);
+    lds_prefetch<FB7_KBLOCKS * FB7_GROUPS, 256>(xpose, reinterpret_cast<const uint32_t *>(gt7) +
+                                                          ((size_t)row * FB7_KBLOCKS * FB7_GROUPS * 64 + lane) * 4);
 }
 
 // the affine cached entry  sign(digit) * |digit| * 2^(7 row) * G  for every lane's own digit, selected by the matrix cores
@@ -56,30 +65,40 @@ __device__ __forceinline__ void fb7_select(const uint8_t *__restrict__ gt7, int 
     // A operands: this row's 12 byte groups (the address depends on the row only).  They were requested memory -> LDS
     // (fb7_request_row) before the previous addition and sit in the hand-over area, which is free until the first
     // result is written below
-    fb7_v4i a[FB7_GROUPS];
+    fb7_v4i a[FB7_KBLOCKS][FB7_GROUPS];
     lds_prefetch_wait();
 #pragma unroll
-    for (int mb = 0; mb < FB7_GROUPS; mb++) {
-        const uint4 v = *reinterpret_cast<const uint4 *>(xpose + (mb * 64 + lane) * 4);
-        a[mb] = fb7_v4i{(int)v.x, (int)v.y, (int)v.z, (int)v.w};
-    }
+    for (int kb = 0; kb < FB7_KBLOCKS; kb++)
+#pragma unroll
+        for (int mb = 0; mb < FB7_GROUPS; mb++) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(xpose + ((kb * FB7_GROUPS + mb) * 64 + lane) * 4);
+            a[kb][mb] = fb7_v4i{(int)v.x, (int)v.y, (int)v.z, (int)v.w};
+        }
     __syncthreads();  // every lane has its operands before the area is overwritten
-    // B operands: one-hot bytes.  Lane (g, c) holds, for the item group ib, the k-slots 16 g .. 16 g + 15 of item 16 ib + c
+    // B operands: one-hot bytes.  Lane (g, c) holds, for the item group ib and the K block kb, the k-slots
+    // 64 kb + 16 g .. + 15 of item 16 ib + c
 #pragma unroll
     for (int ib = 0; ib < 4; ib++) {
         const uint32_t m = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4 * (16 * ib + c)), (int)mag);
-        const uint32_t t = m - 1u - 16u * g;                  // slot within my 16, if < 16 (wraps to a huge value otherwise)
-        const uint32_t one = 1u << ((t & 3u) * 8u);
-        fb7_v4i b;
+        fb7_v4i b[FB7_KBLOCKS];
 #pragma unroll
-        for (int q = 0; q < 4; q++) b[q] = (int)(one & (0u - (uint32_t)((t >> 2) == (uint32_t)q)));
+        for (int kb = 0; kb < FB7_KBLOCKS; kb++) {
+            const uint32_t t = m - 1u - 64u * kb - 16u * g;  // slot within my 16, if < 16 (wraps to a huge value otherwise)
+            const uint32_t one = 1u << ((t & 3u) * 8u);
+#pragma unroll
+            for (int q = 0; q < 4; q++) b[kb][q] = (int)(one & (0u - (uint32_t)((t >> 2) == (uint32_t)q)));
+        }
         // four products in flight before the first is packed (a result is readable ~8 cycles after its issue: packed
         // one by one every MFMA would be followed by that many idle cycles)
 #pragma unroll
         for (int mb0 = 0; mb0 < FB7_GROUPS; mb0 += 4) {
             fb7_v4i d[4];
 #pragma unroll
-            for (int j = 0; j < 4; j++) d[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[mb0 + j], b, fb7_v4i{0, 0, 0, 0}, 0, 0, 0);
+            for (int j = 0; j < 4; j++) d[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[0][mb0 + j], b[0], fb7_v4i{0, 0, 0, 0}, 0, 0, 0);
+            if constexpr (FB7_KBLOCKS == 2) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) d[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[1][mb0 + j], b[1], d[j], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < 4; j++) {
