@@ -190,8 +190,10 @@ int capy_ed448_double_scalarmul_batch(size_t n, const uint8_t *a_be, const uint8
  *          the library takes to be public, keep the indexed kernels.
  *   mode 3: also the raw scalarmul / basemul calls (for callers that pass secrets through them).
  *   mode 0: indexed kernels everywhere (benchmarks; single-tenant devices).   mode 2: raw calls only.
- * Cost (profiles/r03_ed448_hardened.txt): variable base 1.3x, fixed base 2.3x (90 additions instead of 39: a table that
- * must be read in full cannot have 12-bit windows), sign / key pair accordingly. */
+ * Cost against the indexed kernels (profiles/r03_ed448_hardened.txt, r03_ed448_fb7_mfma.txt): variable base 1.2-1.3x;
+ * fixed base 1.7x (65 additions instead of 39: the batched kernel picks its 7-bit-window table entries with a one-hot
+ * byte matrix product on the matrix cores, csrc/ed448_fb7.h), 1.5x for the one-item-per-wave kernels of small batches;
+ * key pair 1.6x, sign 1.4x. */
 int capy_ed448_set_hardened(int mode);
 
 /* Tuning / A-B switch (process-wide): batches of up to max_items scalar multiplications take the one-item-per-wave
