@@ -1,3 +1,6 @@
+"""KMACXOF256 tag / sign / verify of n x L-byte messages (L = 64, 1 KiB, 16 KiB; n = 1 .. 2048) on device buffers, ms per
+call, under the automatic kernel choice and with the wave-per-item sponge kernels forced (debug bit 5); the outputs of
+both runs must agree.  Run from the repo root on the GPU box: python tools/bench_sign_small.py"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.getcwd())
 import torch

@@ -1,3 +1,6 @@
+"""Variable-base and fixed-base scalar multiplication over N items (default 2^18; indexed kernels), ms per call and M/s,
+plus a consistency check ([k]G by both kernels).  Also the workload of the Ed448 counter passes (rocprofv3 --pmc ... --
+python3 tools/time_ed448.py).  Run from the repo root."""
 import sys, os, ctypes as C
 sys.path.insert(0, os.getcwd())
 import torch

@@ -1,3 +1,5 @@
+"""Five single-item sign calls and five verify calls (1 KiB message, D512, default hardened mode) for a kernel trace:
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/trace_sign -o t -- python3 tools/trace_one_sign.py"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.getcwd())
 import torch
