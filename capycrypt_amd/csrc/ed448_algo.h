@@ -127,6 +127,10 @@ CAPY_HD inline Pt vb_add_digit(const Pt &acc, const uint32_t *tab, int digit)
 // The hardened form uses its own, narrower windows: every row is read per window, so fewer rows (9 instead of 17)
 // outweigh the extra windows (112 instead of 90): CAPY_ED448_CT_WBITS = 4 measured against 5 in
 // profiles/r02_ed448_hardened.txt.
+#ifndef CAPY_ED448_CT_SCAN_UNROLL
+#define CAPY_ED448_CT_SCAN_UNROLL 1  // rows of the per-item table per trip of the scan loop (2 / 4 measured: 3.27 -> 6.6 / 5.9 ms
+                                     // at 65 536 items, the 64 extra registers per row in flight spill)
+#endif
 #ifndef CAPY_ED448_CT_WBITS
 #define CAPY_ED448_CT_WBITS 4
 #endif
@@ -193,7 +197,7 @@ CAPY_HD inline Pt vb_add_digit_ct(const Pt &acc, const CtTable &t, int digit)
     // row 0 (the identity, digit 0) is not read: a digit of 0 matches no row and leaves zeros, which become the cached
     // identity (0, 1, 1, 0) below -- one ninth less to scan (the scan is what the hardened variable base adds: its
     // per-item tables make 2^18 multiplications read ~60 GB)
-#pragma unroll 1
+    CAPY_UNROLL(CAPY_ED448_CT_SCAN_UNROLL)
     for (uint32_t j = 1; j < (uint32_t)CtWin::ENTRIES; j++) {
         const uint32_t m = ct_mask(j == idx);
 #pragma unroll
