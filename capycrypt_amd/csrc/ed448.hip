@@ -748,12 +748,12 @@ static int key_decrypt_dev(int d, size_t n, const KeyView &pw, const uint8_t *z_
 static int up(DevBuf &b, const void *src, size_t bytes)
 {
     CAPY_HIP(b.alloc(bytes));
-    if (bytes) CAPY_HIP(hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
+    CAPY_HIP(b.put(src, bytes));
     return CAPY_OK;
 }
 static int down(void *dst, const DevBuf &b, size_t bytes)
 {
-    if (bytes) CAPY_HIP(hipMemcpy(dst, b.p, bytes, hipMemcpyDeviceToHost));
+    CAPY_HIP(b.get(dst, bytes));
     return CAPY_OK;
 }
 

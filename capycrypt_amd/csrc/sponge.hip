@@ -345,6 +345,53 @@ void devbuf_give(void *p, size_t cap)
     }
 }
 
+// ---- the per-thread arena of small DevBufs (common.h): 256 KiB of pinned, device-mapped, portable host memory, bump
+// allocated in 256-byte steps, reset when the last buffer of a call has been given back
+namespace {
+struct HostArena {
+    char *host = nullptr, *dev = nullptr;
+    size_t used = 0, live = 0;
+    bool tried = false;
+    static constexpr size_t SIZE = 256 * 1024;
+    ~HostArena()
+    {
+        if (host) (void)hipHostFree(host);
+    }
+};
+thread_local HostArena t_arena;
+}  // namespace
+void *arena_take(size_t bytes, void **host)
+{
+    HostArena &a = t_arena;
+    if (!a.tried) {
+        a.tried = true;
+        const char *e = getenv("CAPY_HOST_ARENA");
+        if (!(e && e[0] == '0')) {
+            void *h = nullptr, *d = nullptr;
+            if (hipHostMalloc(&h, HostArena::SIZE, hipHostMallocMapped | hipHostMallocPortable) == hipSuccess &&
+                hipHostGetDevicePointer(&d, h, 0) == hipSuccess) {
+                a.host = (char *)h;
+                a.dev = (char *)d;
+            } else {
+                (void)hipGetLastError();
+                if (h) (void)hipHostFree(h);
+            }
+        }
+    }
+    const size_t step = (bytes + 255) & ~(size_t)255;
+    if (!a.host || a.used + step > HostArena::SIZE) return nullptr;
+    *host = a.host + a.used;
+    void *d = a.dev + a.used;
+    a.used += step;
+    a.live++;
+    return d;
+}
+void arena_give()
+{
+    HostArena &a = t_arena;
+    if (a.live && --a.live == 0) a.used = 0;
+}
+
 // Secret intermediates (z||pw, ke||ka, the Schnorr secret s and nonce k, the ECDH point W) sit in pooled scratch that
 // later, unrelated calls reuse: zero them on the same stream once the call's last reader has been enqueued.
 void workspace_scrub(hipStream_t stream, WsSlot slot, size_t bytes)
@@ -1284,6 +1331,16 @@ static hipError_t bulk_copy(void *dst, const void *src, size_t n, hipMemcpyKind 
     return e;
 }
 
+// n rows of `row` bytes, `stride` apart in the buffer, to a dense host array
+static hipError_t copy_rows_out(uint8_t *dst, size_t row, const DevBuf &b, size_t stride, size_t n)
+{
+    if (!b.host) return hipMemcpy2D(dst, row, b.p, stride, row, n, hipMemcpyDeviceToHost);
+    const hipError_t e = hipStreamSynchronize(nullptr);
+    if (e != hipSuccess) return e;
+    for (size_t i = 0; i < n; i++) memcpy(dst + i * row, static_cast<const char *>(b.host) + i * stride, row);
+    return hipSuccess;
+}
+
 // ------------------------------------------------------------------ PackedBatch
 int PackedBatch::upload(size_t n, const uint8_t *host_msgs, const uint64_t *host_offsets)
 {
@@ -1335,15 +1392,15 @@ int PackedBatch::upload(size_t n, const uint8_t *host_msgs, const uint64_t *host
         std::vector<uint32_t> spread(n);
         for (size_t k = 0; k < n; k++) spread[order_spread((uint32_t)k, n)] = h_order[k];
         CAPY_HIP(order.alloc(n * 4));
-        CAPY_HIP(hipMemcpy(order.p, spread.data(), n * 4, hipMemcpyHostToDevice));
+        CAPY_HIP(order.put(spread.data(), n * 4));
     }
     CAPY_HIP(msgs.alloc(total + 16));
-    if (total) CAPY_HIP(bulk_copy(msgs.p, src, total, hipMemcpyHostToDevice));
+    if (total) CAPY_HIP(msgs.host ? msgs.put(src, total) : bulk_copy(msgs.p, src, total, hipMemcpyHostToDevice));
     if (!uniform) {  // a uniform batch is described by (length, stride) alone
         CAPY_HIP(starts.alloc((n + 1) * 8));
         CAPY_HIP(lens.alloc((n ? n : 1) * 8));
-        CAPY_HIP(hipMemcpy(starts.p, h_starts.data(), (n + 1) * 8, hipMemcpyHostToDevice));
-        CAPY_HIP(hipMemcpy(lens.p, h_lens.data(), (n ? n : 1) * 8, hipMemcpyHostToDevice));
+        CAPY_HIP(starts.put(h_starts.data(), (n + 1) * 8));
+        CAPY_HIP(lens.put(h_lens.data(), (n ? n : 1) * 8));
     }
     return CAPY_OK;
 }
@@ -1352,11 +1409,11 @@ int PackedBatch::download(size_t n, uint8_t *host_msgs, const uint64_t *host_off
 {
     if (!n || !total) return CAPY_OK;
     if (!repacked) {
-        CAPY_HIP(bulk_copy(host_msgs + host_offsets[0], msgs.p, total, hipMemcpyDeviceToHost));
+        CAPY_HIP(msgs.host ? msgs.get(host_msgs + host_offsets[0], total) : bulk_copy(host_msgs + host_offsets[0], msgs.p, total, hipMemcpyDeviceToHost));
         return CAPY_OK;
     }
     std::vector<uint8_t> staging(total);
-    CAPY_HIP(bulk_copy(staging.data(), msgs.p, total, hipMemcpyDeviceToHost));
+    CAPY_HIP(msgs.host ? msgs.get(staging.data(), total) : bulk_copy(staging.data(), msgs.p, total, hipMemcpyDeviceToHost));
     for (size_t i = 0; i < n; i++)
         if (h_lens[i]) memcpy(host_msgs + host_offsets[i], staging.data() + h_starts[i], h_lens[i]);
     return CAPY_OK;
@@ -1370,7 +1427,7 @@ int PackedKeys::upload(size_t n, const uint8_t *keys, size_t key_len, const uint
         total = (uint64_t)n * key_len;
         if (total && !keys) return fail(CAPY_ERR_ARG, "null key buffer");
         CAPY_HIP(data.alloc(total));
-        if (total) CAPY_HIP(hipMemcpy(data.p, keys, total, hipMemcpyHostToDevice));
+        if (total) CAPY_HIP(data.put(keys, total));
         view = fixed_keys(data.as<uint8_t>(), key_len, key_len);
         return CAPY_OK;
     }
@@ -1383,9 +1440,9 @@ int PackedKeys::upload(size_t n, const uint8_t *keys, size_t key_len, const uint
     total = rel[n];
     if (total && !keys) return fail(CAPY_ERR_ARG, "null key buffer");
     CAPY_HIP(data.alloc(total));
-    if (total) CAPY_HIP(hipMemcpy(data.p, keys + offsets[0], total, hipMemcpyHostToDevice));
+    if (total) CAPY_HIP(data.put(keys + offsets[0], total));
     CAPY_HIP(offs.alloc((n + 1) * 8));
-    CAPY_HIP(hipMemcpy(offs.p, rel.data(), (n + 1) * 8, hipMemcpyHostToDevice));
+    CAPY_HIP(offs.put(rel.data(), (n + 1) * 8));
     view = KeyView();
     view.keys = data.as<uint8_t>();
     view.key_offsets = offs.as<uint64_t>();
@@ -1518,7 +1575,7 @@ int capy_sha3_batch(int d, size_t n, const uint8_t *msgs, const uint64_t *offset
     CAPY_HIP(out.alloc(n * dl));
     rc = sha3_launch(d, n, view_of(b), out.as<uint8_t>(), dl, nullptr);
     if (rc) return rc;
-    CAPY_HIP(hipMemcpy(digests, out.p, n * dl, hipMemcpyDeviceToHost));
+    CAPY_HIP(out.get(digests, n * dl));
     return CAPY_OK;
 }
 
@@ -1569,7 +1626,7 @@ int capy_cshake_batch(int d, size_t n, const uint8_t *xs, const uint64_t *offset
     rc = cshake_launch(d, n, view_of(b), l_bits, fn_name, fn_len, custom, custom_len, out.as<uint8_t>(), os, nullptr,
                        empty_ns);
     if (rc) return rc;
-    if (ol) CAPY_HIP(hipMemcpy2D(outs, ol, out.p, os, ol, n, hipMemcpyDeviceToHost));
+    if (ol) CAPY_HIP(copy_rows_out(outs, ol, out, os, n));
     return CAPY_OK;
 }
 
@@ -1628,7 +1685,7 @@ int capy_kmac_xof_batch(int d, size_t n, const uint8_t *keys, size_t key_len, co
     CAPY_HIP(out.alloc(n * os));
     rc = kmac_launch(d, n, k.view, view_of(b), true, custom, custom_len, 0, out.as<uint8_t>(), os, ol, nullptr, nullptr);
     if (rc) return rc;
-    if (ol) CAPY_HIP(hipMemcpy2D(outs, ol, out.p, os, ol, n, hipMemcpyDeviceToHost));
+    if (ol) CAPY_HIP(copy_rows_out(outs, ol, out, os, n));
     return CAPY_OK;
 }
 
@@ -1689,8 +1746,8 @@ static int sha3_crypt_host(bool encrypt, int d, size_t n, const uint8_t *pws, si
     CAPY_HIP(dz.alloc(n * 512));
     CAPY_HIP(dtag.alloc(n * 64));
     CAPY_HIP(dst.alloc(n * 4));
-    CAPY_HIP(hipMemcpy(dz.p, zs, n * 512, hipMemcpyHostToDevice));
-    if (!encrypt) CAPY_HIP(hipMemcpy(dtag.p, tags, n * 64, hipMemcpyHostToDevice));
+    CAPY_HIP(dz.put(zs, n * 512));
+    if (!encrypt) CAPY_HIP(dtag.put(tags, n * 64));
     rc = sha3_crypt_dev(encrypt, d, n, dpw.view, dpw.total, dz.as<uint8_t>(), view_of(b), dtag.as<uint8_t>(),
                         dst.as<int32_t>(), nullptr, ke_custom, ka_custom);
     if (rc) return rc;
@@ -1698,9 +1755,9 @@ static int sha3_crypt_host(bool encrypt, int d, size_t n, const uint8_t *pws, si
     rc = b.download(n, msgs, offsets);
     if (rc) return rc;
     if (encrypt)
-        CAPY_HIP(hipMemcpy(tags, dtag.p, n * 64, hipMemcpyDeviceToHost));
+        CAPY_HIP(dtag.get(tags, n * 64));
     else
-        CAPY_HIP(hipMemcpy(status, dst.p, n * 4, hipMemcpyDeviceToHost));
+        CAPY_HIP(dst.get(status, n * 4));
     return CAPY_OK;
 }
 
