@@ -23,14 +23,14 @@ int fail(int code, const std::string &msg);
 
 // RAII device allocation for the host-pointer entry points, served from a per-thread cache of blocks (sponge.hip:
 // devbuf_take / devbuf_give) so that repeated calls neither allocate nor free (= synchronise).
-// SMALL buffers (<= ARENA_MAX_BUF) come from the thread's ARENA instead: one block of pinned host memory that the device
+// Buffers of up to ARENA_MAX_BUF bytes come from the thread's ARENA instead: one block of pinned host memory that the device
 // maps.  The kernels read such inputs from it and write such outputs to it directly, so a small call makes no copy
 // calls at all -- filling it is a memcpy, reading a result is one stream synchronisation and a memcpy (r03: a KMAC tag
 // of one 1 KiB message took 112 us through this ABI against 38 us on device buffers, the difference being five small
 // synchronous hipMemcpy).  CAPY_HOST_ARENA=0 switches it off.  `host` is the CPU's address of an arena buffer.
 void *devbuf_take(size_t bytes, size_t *cap);  // nullptr on allocation failure
 void devbuf_give(void *p, size_t cap);
-constexpr size_t ARENA_MAX_BUF = 16384;
+constexpr size_t ARENA_MAX_BUF = (1 << 20) + 16;  // measured 16 KiB / 64 KiB / 1 MiB: profiles/r03_small_calls.txt
 void *arena_take(size_t bytes, void **host);  // device address, or nullptr: does not fit / no arena
 void arena_give();                            // the last buffer given back resets the arena
 struct DevBuf {

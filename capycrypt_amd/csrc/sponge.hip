@@ -345,14 +345,14 @@ void devbuf_give(void *p, size_t cap)
     }
 }
 
-// ---- the per-thread arena of small DevBufs (common.h): 256 KiB of pinned, device-mapped, portable host memory, bump
+// ---- the per-thread arena of small DevBufs (common.h): 8 MiB of pinned, device-mapped, portable host memory, bump
 // allocated in 256-byte steps, reset when the last buffer of a call has been given back
 namespace {
 struct HostArena {
     char *host = nullptr, *dev = nullptr;
     size_t used = 0, live = 0;
     bool tried = false;
-    static constexpr size_t SIZE = 256 * 1024;
+    static constexpr size_t SIZE = 8 * 1024 * 1024;
     ~HostArena()
     {
         if (host) (void)hipHostFree(host);

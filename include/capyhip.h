@@ -19,7 +19,7 @@
  *   points       affine (x, y), 2 x 56-byte little-endian canonical field elements (x first)
  *   return       0 = ok, <0 = CAPY_ERR_*; capy_last_error() gives the text (thread local)
  *   host forms   (no _dev suffix) take and return HOST buffers and block until the results are there.  Buffers of up to
- *                16 KiB go through a per-thread arena of pinned, device-mapped host memory (no copy calls: the kernels
+ *                1 MiB go through a per-thread arena of pinned, device-mapped host memory (no copy calls: the kernels
  *                read and write it directly; CAPY_HOST_ARENA=0 switches it off), larger ones through cached staging
  *                blocks on the device.
  *   *_dev        same operation on buffers already resident in device memory, enqueued on `stream`
