@@ -293,7 +293,12 @@ void *workspace(hipStream_t stream, WsSlot slot, size_t bytes)
     return e->ptr[slot];
 }
 
-void workspace_release() { g_ws_list.release(); }
+void arena_release();
+void workspace_release()
+{
+    g_ws_list.release();
+    arena_release();
+}
 
 // Device blocks of the host-buffer entry points (DevBuf: message / key / output staging).  r02 paid a hipMalloc and a
 // hipFree -- a device synchronisation -- per buffer per call; now a finished call's blocks wait in a per-thread cache
@@ -385,6 +390,16 @@ void *arena_take(size_t bytes, void **host)
     a.used += step;
     a.live++;
     return d;
+}
+void arena_release()  // capy_release_workspace(): the pinned block goes back too (no call of this thread is in flight)
+{
+    HostArena &a = t_arena;
+    if (a.host && a.live == 0) {
+        (void)hipHostFree(a.host);
+        a.host = a.dev = nullptr;
+        a.used = 0;
+        a.tried = false;
+    }
 }
 void arena_give()
 {
