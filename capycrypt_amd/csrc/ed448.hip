@@ -83,6 +83,8 @@ __global__ __launch_bounds__(64, CAPY_ED448_WAVES) void fb_ct_kernel(uint64_t n,
 
 // hardened fixed base with the table lookups on the matrix cores (ed448_fb7.h).  All 64 lanes stay in the loop (an MFMA
 // wants the whole wave): the lanes past the end of the batch repeat the last item and do not store.
+// TW: the table is the twisted one (7M additions on E', back through the dual isogeny: ed448_dev.h)
+template <bool TW>
 __global__ __launch_bounds__(64, CAPY_ED448_WAVES) void fb_ct7_kernel(uint64_t n, const uint8_t *scalars_be, uint8_t *out_xy,
                                                     const uint8_t *gt7)
 {
@@ -90,14 +92,20 @@ __global__ __launch_bounds__(64, CAPY_ED448_WAVES) void fb_ct7_kernel(uint64_t n
     __shared__ uint32_t xpose[FB7_LDS_DWORDS];
     const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
     const uint64_t src = i < n ? i : n - 1;
-    const Pt r = fb7_scalarmul(scalars_be + src * 56, gt7, xpose);
-    if (i < n) pt_to_affine_bytes(out_xy + i * 112, r);
+    const Pt r = fb7_scalarmul<TW>(scalars_be + src * 56, gt7, xpose);
+    if (i < n) {
+        if constexpr (TW)
+            pt_tw_to_affine_bytes(out_xy + i * 112, r);
+        else
+            pt_to_affine_bytes(out_xy + i * 112, r);
+    }
 #endif
 }
 
 // the same with two items per lane sharing one inversion (as fb2_kernel): lane l takes the items base + l and
 // base + 64 + l of the wave's 128.  The first result waits in global scratch (park: 48 dwords per lane, 16-byte pieces
 // interleaved across the wave's lanes) -- the LDS is taken by the hand-over area and 48 more VGPRs would spill.
+template <bool TW>
 __global__ __launch_bounds__(64, CAPY_ED448_WAVES) void fb_ct7_pair_kernel(uint64_t n, const uint8_t *scalars_be, uint8_t *out_xy,
                                                          const uint8_t *gt7, uint32_t *park)
 {
@@ -107,7 +115,7 @@ __global__ __launch_bounds__(64, CAPY_ED448_WAVES) void fb_ct7_pair_kernel(uint6
     const uint64_t i0 = base < n ? base : n - 1, i1 = base + 64 < n ? base + 64 : i0;
     uint4 *mine = reinterpret_cast<uint4 *>(park) + (uint64_t)blockIdx.x * 12 * 64 + threadIdx.x;
     {
-        const Pt r0 = fb7_scalarmul(scalars_be + i0 * 56, gt7, xpose);
+        const Pt r0 = fb7_scalarmul<TW>(scalars_be + i0 * 56, gt7, xpose);
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             mine[q * 64] = uint4{r0.X.l[4 * q], r0.X.l[4 * q + 1], r0.X.l[4 * q + 2], r0.X.l[4 * q + 3]};
@@ -115,7 +123,7 @@ __global__ __launch_bounds__(64, CAPY_ED448_WAVES) void fb_ct7_pair_kernel(uint6
             mine[(8 + q) * 64] = uint4{r0.Z.l[4 * q], r0.Z.l[4 * q + 1], r0.Z.l[4 * q + 2], r0.Z.l[4 * q + 3]};
         }
     }
-    const Pt r1 = fb7_scalarmul(scalars_be + i1 * 56, gt7, xpose);
+    const Pt r1 = fb7_scalarmul<TW>(scalars_be + i1 * 56, gt7, xpose);
     Pt r0;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
@@ -125,10 +133,17 @@ __global__ __launch_bounds__(64, CAPY_ED448_WAVES) void fb_ct7_pair_kernel(uint6
         r0.Z.l[4 * q] = vz.x, r0.Z.l[4 * q + 1] = vz.y, r0.Z.l[4 * q + 2] = vz.z, r0.Z.l[4 * q + 3] = vz.w;
     }
     r0.T = fe_zero();  // not needed for the conversion
-    if (base + 64 < n)
-        pt_pair_to_affine_bytes(out_xy + base * 112, out_xy + (base + 64) * 112, r0, r1);
-    else if (base < n)
-        pt_to_affine_bytes(out_xy + base * 112, r0);
+    if (base + 64 < n) {
+        if constexpr (TW)
+            pt_tw_pair_to_affine_bytes(out_xy + base * 112, out_xy + (base + 64) * 112, r0, r1);
+        else
+            pt_pair_to_affine_bytes(out_xy + base * 112, out_xy + (base + 64) * 112, r0, r1);
+    } else if (base < n) {
+        if constexpr (TW)
+            pt_tw_to_affine_bytes(out_xy + base * 112, r0);
+        else
+            pt_to_affine_bytes(out_xy + base * 112, r0);
+    }
 #endif
 }
 
@@ -149,6 +164,7 @@ __global__ void gtab7_pack_kernel(const uint32_t *lin, uint32_t *gt7_words)
     gt7_words[o] = v;
 }
 
+template <bool TW>  // TW: gtab is the twisted table (7M additions on E', back through the dual isogeny: ed448_dev.h)
 __global__ __launch_bounds__(64, CAPY_ED448_WAVES) void fb_kernel(uint64_t n, const uint8_t *scalars_be, uint8_t *out_xy,
                                                 const uint32_t *gtab)
 {
@@ -159,7 +175,11 @@ __global__ __launch_bounds__(64, CAPY_ED448_WAVES) void fb_kernel(uint64_t n, co
 #else
     uint32_t *const pf = nullptr;
 #endif
-    pt_to_affine_bytes(out_xy + i * 112, fb_scalarmul(scalars_be + i * 56, gtab, pf));
+    const Pt r = fb_scalarmul<TW>(scalars_be + i * 56, gtab, pf);
+    if constexpr (TW)
+        pt_tw_to_affine_bytes(out_xy + i * 112, r);
+    else
+        pt_to_affine_bytes(out_xy + i * 112, r);
 }
 
 // Two items per lane sharing one inversion (pt_pair_to_affine_bytes): a wave takes 128 consecutive items, lane l the
@@ -214,10 +234,11 @@ __global__ __launch_bounds__(64, CAPY_ED448_WAVES) void vb2_kernel(uint64_t n, c
     }
 }
 
-template <bool CT>  // CT: gtab is the hardened table
+template <bool CT, bool TW = false>  // CT: gtab is the hardened 5-bit table (VALU scan); TW (indexed only): the twisted table
 __global__ __launch_bounds__(64, CAPY_ED448_WAVES) void fb2_kernel(uint64_t n, const uint8_t *scalars_be, uint8_t *out_xy,
                                                  const uint32_t *gtab)
 {
+    static_assert(!(CT && TW), "the VALU-scan table stays on E");
     __shared__ PtXYZ parked;
     const uint64_t base = (uint64_t)blockIdx.x * 128 + threadIdx.x;
     if (base >= n) return;
@@ -225,14 +246,23 @@ __global__ __launch_bounds__(64, CAPY_ED448_WAVES) void fb2_kernel(uint64_t n, c
 #pragma unroll 1
     for (int j = 0; j < 2; j++) {
         const uint64_t i = (j == 1 && base + 64 < n) ? base + 64 : base;
-        r = CT ? fb_scalarmul_ct(scalars_be + i * 56, gtab) : fb_scalarmul(scalars_be + i * 56, gtab);
+        if constexpr (CT)
+            r = fb_scalarmul_ct(scalars_be + i * 56, gtab);
+        else
+            r = fb_scalarmul<TW>(scalars_be + i * 56, gtab);
         if (j == 0) park_xyz(parked, r);
     }
     const Pt r0 = unpark_xyz(parked);
     if (base + 64 < n) {
-        pt_pair_to_affine_bytes(out_xy + base * 112, out_xy + (base + 64) * 112, r0, r);
+        if constexpr (TW)
+            pt_tw_pair_to_affine_bytes(out_xy + base * 112, out_xy + (base + 64) * 112, r0, r);
+        else
+            pt_pair_to_affine_bytes(out_xy + base * 112, out_xy + (base + 64) * 112, r0, r);
     } else {
-        pt_to_affine_bytes(out_xy + base * 112, r0);
+        if constexpr (TW)
+            pt_tw_to_affine_bytes(out_xy + base * 112, r0);
+        else
+            pt_to_affine_bytes(out_xy + base * 112, r0);
     }
 }
 
@@ -276,6 +306,20 @@ __global__ void gtab_pack_kernel(uint32_t n, const uint8_t *xy, uint32_t *gtab)
     store_fe(e, x);
     store_fe(e + 16, y);
     store_fe(e + 32, fe_mul_d(fe_mul(x, y)));
+}
+
+// the same for the twisted table: phi of the point, stored as (y' - x', y' + x', 2 d' x' y') (ed448_dev.h)
+__global__ void gtab_tw_pack_kernel(uint32_t n, const uint8_t *xy, uint32_t *gtab)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Fe x = fe_from_bytes(xy + (uint64_t)i * 112), y = fe_from_bytes(xy + (uint64_t)i * 112 + 56);
+    Fe ymx, ypx, td;
+    pt_tw_niels_from_affine(ymx, ypx, td, x, y);
+    uint32_t *e = gtab + (uint64_t)i * FB_ENTRY_DWORDS;
+    store_fe(e, ymx);
+    store_fe(e + 16, ypx);
+    store_fe(e + 32, td);
 }
 
 // out = 4 * in mod r  (56-byte BE in/out)   — `bytes_to_scalar(..).mul_mod(&Scalar::from(4))`
@@ -438,11 +482,17 @@ static const uint8_t *current_generator()  // caller holds g_gtab_mu
 static uint32_t *g_gtab_ct[64] = {nullptr};  // the hardened table (FBCT_WBITS-bit windows), built on first hardened use
 
 // rows x entries table of j * 2^(wbits row) * G in affine cached form, built by the variable-base kernel on G itself
-static int build_gtab(int rows, int entries, int wbits, uint32_t **slot)
+// twisted: the multiples of G4 = [1/4 mod r] G mapped to the 4-isogenous twisted curve (ed448_dev.h); only for a
+// generator of order r (generator_has_order_r)
+static int build_gtab(int rows, int entries, int wbits, uint32_t **slot, bool twisted = false)
 {
     const size_t n = (size_t)rows * entries;
     std::vector<uint8_t> sc(n * 56), pts(n * 112);
-    uint32_t pw[14] = {1};  // 2^(wbits row) mod r
+    // 2^(wbits row) mod r, times 1/4 mod r for the twisted table
+    static const uint32_t INV4[14] = {0xaad6113du, 0x48de30a4u, 0xa37163d5u, 0x085b309cu, 0x6bb58da4u, 0x7113b6d2u, 0xdf3288fau,
+                                      0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0x0fffffffu};
+    uint32_t pw[14] = {1};
+    if (twisted) memcpy(pw, INV4, sizeof(pw));
     for (int row = 0; row < rows; row++) {
         uint32_t acc[14] = {0};
         for (int j = 0; j < entries; j++) {
@@ -457,14 +507,18 @@ static int build_gtab(int rows, int entries, int wbits, uint32_t **slot)
     CAPY_HIP(dpts.alloc(pts.size()));
     CAPY_HIP(dout.alloc(n * 112));
     CAPY_HIP(dtab.alloc(n * VB_TABLE_DWORDS * 4));
-    CAPY_HIP(hipMemcpy(dsc.p, sc.data(), sc.size(), hipMemcpyHostToDevice));
-    CAPY_HIP(hipMemcpy(dpts.p, pts.data(), pts.size(), hipMemcpyHostToDevice));
+    CAPY_HIP(dsc.put(sc.data(), sc.size()));
+    CAPY_HIP(dpts.put(pts.data(), pts.size()));
     uint32_t *gt = nullptr;
     CAPY_HIP(hipMalloc((void **)&gt, n * FB_ENTRY_DWORDS * 4));
     hipLaunchKernelGGL(vb_kernel, grid64(n), dim3(64), 0, nullptr, (uint64_t)n, dsc.as<uint8_t>(), (uint64_t)56,
                        dpts.as<uint8_t>(), (uint64_t)112, dout.as<uint8_t>(), dtab.as<uint32_t>());
-    hipLaunchKernelGGL(gtab_pack_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, nullptr, (uint32_t)n,
-                       dout.as<uint8_t>(), gt);
+    if (twisted)
+        hipLaunchKernelGGL(gtab_tw_pack_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, nullptr, (uint32_t)n,
+                           dout.as<uint8_t>(), gt);
+    else
+        hipLaunchKernelGGL(gtab_pack_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, nullptr, (uint32_t)n,
+                           dout.as<uint8_t>(), gt);
     CAPY_HIP(hipGetLastError());
     CAPY_HIP(hipDeviceSynchronize());
     *slot = gt;
@@ -475,16 +529,55 @@ static int build_gtab(int rows, int entries, int wbits, uint32_t **slot)
 #ifndef CAPY_ED448_FBCT_MFMA
 #define CAPY_ED448_FBCT_MFMA 1  // 0: the VALU scan of fb_ct_kernel / fb2_kernel<true> for every lane-per-item hardened fixed base (A/B)
 #endif
+// The lane-per-item fixed-base kernels accumulate on the 4-isogenous twisted curve (7M instead of 8M per addition,
+// ed448_dev.h) when the generator in use has the prime order r -- the RFC 8032 base point does; a configured generator
+// that does not keeps tables and additions on E.  CAPY_ED448_FB_TWISTED=0 (compile time) keeps everything on E (A/B).
+#ifndef CAPY_ED448_FB_TWISTED
+#define CAPY_ED448_FB_TWISTED 1
+#endif
+static int g_gen_order_r = -1;  // -1 not yet known, 0 / 1; guarded by g_gtab_mu, reset by capy_ed448_set_generator
+static int generator_has_order_r(bool *yes)  // caller holds g_gtab_mu
+{
+    if (g_gen_order_r < 0) {
+        static const uint32_t R_WORDS[14] = {0xab5844f3u, 0x2378c292u, 0x8dc58f55u, 0x216cc272u, 0xaed63690u, 0xc44edb49u, 0x7cca23e9u,
+                                             0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0x3fffffffu};
+        uint8_t r_be[56], out[112];
+        sc_to_be(r_be, R_WORDS);
+        DevBuf dsc, dpt, dout, dtab;
+        CAPY_HIP(dsc.alloc(56));
+        CAPY_HIP(dpt.alloc(112));
+        CAPY_HIP(dout.alloc(112));
+        CAPY_HIP(dtab.alloc(VB_TABLE_DWORDS * 4));
+        CAPY_HIP(dsc.put(r_be, 56));
+        CAPY_HIP(dpt.put(current_generator(), 112));
+        hipLaunchKernelGGL(vb_kernel, dim3(1), dim3(64), 0, nullptr, (uint64_t)1, dsc.as<uint8_t>(), (uint64_t)56, dpt.as<uint8_t>(),
+                           (uint64_t)112, dout.as<uint8_t>(), dtab.as<uint32_t>());
+        CAPY_HIP(hipGetLastError());
+        CAPY_HIP(dout.get(out, 112));
+        bool ident = out[56] == 1;  // (0, 1): x all zero, y = 1 little-endian
+        for (int i = 0; i < 112; i++)
+            if (i != 56 && out[i] != 0) ident = false;
+        g_gen_order_r = ident ? 1 : 0;
+    }
+    *yes = CAPY_ED448_FB_TWISTED && g_gen_order_r == 1;
+    return CAPY_OK;
+}
+
 static uint8_t *g_gtab7[64] = {nullptr};
-static int ensure_gtab7(const uint8_t **out)
+static bool g_gtab7_twisted[64] = {false};
+static int ensure_gtab7(const uint8_t **out, bool *twisted)
 {
     int dev = 0;
     CAPY_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64) return fail(CAPY_ERR_ARG, "device index out of range");
     std::lock_guard<std::mutex> lk(g_gtab_mu);
     if (!g_gtab7[dev]) {
+        bool tw = false;
+        const int rco = generator_has_order_r(&tw);
+        if (rco) return rco;
+        g_gtab7_twisted[dev] = tw;
         uint32_t *lin = nullptr;
-        const int rc = build_gtab(FB7_ROWS, FB7_ENTRIES, FB7_WBITS, &lin);
+        const int rc = build_gtab(FB7_ROWS, FB7_ENTRIES, FB7_WBITS, &lin, tw);
         if (rc) return rc;
         uint8_t *gt7 = nullptr;
         if (hipMalloc((void **)&gt7, FB7_TABLE_BYTES) != hipSuccess) {
@@ -502,19 +595,28 @@ static int ensure_gtab7(const uint8_t **out)
         g_gtab7[dev] = gt7;
     }
     *out = g_gtab7[dev];
+    *twisted = g_gtab7_twisted[dev];
     return CAPY_OK;
 }
 
-static int ensure_gtab(const uint32_t **out, bool hardened_table = false)
+static uint32_t *g_gtab_tw[64] = {nullptr};  // the indexed 12-bit table on the twisted curve (lane-per-item fixed base)
+// twisted (in/out, indexed table only): ask for the twisted table; comes back false when the generator's order is not r
+static int ensure_gtab(const uint32_t **out, bool hardened_table = false, bool *twisted = nullptr)
 {
     int dev = 0;
     CAPY_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64) return fail(CAPY_ERR_ARG, "device index out of range");
     std::lock_guard<std::mutex> lk(g_gtab_mu);
-    uint32_t **slot = hardened_table ? &g_gtab_ct[dev] : &g_gtab[dev];
+    bool tw = false;
+    if (twisted && *twisted && !hardened_table) {
+        const int rco = generator_has_order_r(&tw);
+        if (rco) return rco;
+    }
+    if (twisted) *twisted = tw;
+    uint32_t **slot = hardened_table ? &g_gtab_ct[dev] : (tw ? &g_gtab_tw[dev] : &g_gtab[dev]);
     if (!*slot) {
         const int rc = hardened_table ? build_gtab(FBCT_ROWS, FBCT_ENTRIES, FBCT_WBITS, slot)
-                                      : build_gtab(FB_ROWS, FB_TAB_ENTRIES, FB_WBITS, slot);
+                                      : build_gtab(FB_ROWS, FB_TAB_ENTRIES, FB_WBITS, slot, tw);
         if (rc) return rc;
     }
     *out = *slot;
@@ -530,24 +632,32 @@ static int fb_launch(size_t n, const uint8_t *scalars, uint8_t *out, hipStream_t
         // every byte of the window's table row is read per window by every wave and the wanted entry is picked by a
         // one-hot matrix product on the matrix cores: no address depends on the scalar (ed448_fb7.h)
         const uint8_t *gt7 = nullptr;
-        const int rc7 = ensure_gtab7(&gt7);
+        bool tw = false;
+        const int rc7 = ensure_gtab7(&gt7, &tw);
         if (rc7) return rc7;
         if (n >= pair_min_items()) {
             const size_t blocks = (n + 127) / 128;
             CAPY_WS(park, uint32_t *, s, WS_TABLE, blocks * 64 * 48 * 4);
-            hipLaunchKernelGGL(fb_ct7_pair_kernel, dim3((unsigned)blocks), dim3(64), 0, s, (uint64_t)n, scalars, out, gt7, park);
+            if (tw)
+                hipLaunchKernelGGL(fb_ct7_pair_kernel<true>, dim3((unsigned)blocks), dim3(64), 0, s, (uint64_t)n, scalars, out, gt7, park);
+            else
+                hipLaunchKernelGGL(fb_ct7_pair_kernel<false>, dim3((unsigned)blocks), dim3(64), 0, s, (uint64_t)n, scalars, out, gt7, park);
             // the parked PROJECTIVE results of secret multiples must not outlive the call (a projective representation
             // of [k]G says more about k than the affine point does)
             CAPY_HIP(hipMemsetAsync(park, 0, blocks * 64 * 48 * 4, s));
+        } else if (tw) {
+            hipLaunchKernelGGL(fb_ct7_kernel<true>, grid64(n), dim3(64), 0, s, (uint64_t)n, scalars, out, gt7);
         } else {
-            hipLaunchKernelGGL(fb_ct7_kernel, grid64(n), dim3(64), 0, s, (uint64_t)n, scalars, out, gt7);
+            hipLaunchKernelGGL(fb_ct7_kernel<false>, grid64(n), dim3(64), 0, s, (uint64_t)n, scalars, out, gt7);
         }
         CAPY_HIP(hipGetLastError());
         return CAPY_OK;
     }
     const uint32_t *gt = nullptr;
-    // ct: every entry of the window's row of the 5-bit table is read per window: no address depends on the scalar
-    int rc = ensure_gtab(&gt, ct);
+    // ct: every entry of the window's row of the 5-bit table is read per window: no address depends on the scalar.
+    // The indexed lane-per-item kernels take the twisted table when the generator allows it
+    bool tw = !ct && !small;
+    int rc = ensure_gtab(&gt, ct, &tw);
     if (rc) return rc;
     const dim3 pair_grid((unsigned)((n + 127) / 128));
     if (small) {
@@ -557,13 +667,17 @@ static int fb_launch(size_t n, const uint8_t *scalars, uint8_t *out, hipStream_t
             hipLaunchKernelGGL(wave::fb_wave_kernel<false>, dim3((unsigned)n), dim3(64), 0, s, (uint64_t)n, scalars, out, gt);
     } else if (n >= pair_min_items()) {
         if (ct)
-            hipLaunchKernelGGL(fb2_kernel<true>, pair_grid, dim3(64), 0, s, (uint64_t)n, scalars, out, gt);
+            hipLaunchKernelGGL((fb2_kernel<true, false>), pair_grid, dim3(64), 0, s, (uint64_t)n, scalars, out, gt);
+        else if (tw)
+            hipLaunchKernelGGL((fb2_kernel<false, true>), pair_grid, dim3(64), 0, s, (uint64_t)n, scalars, out, gt);
         else
-            hipLaunchKernelGGL(fb2_kernel<false>, pair_grid, dim3(64), 0, s, (uint64_t)n, scalars, out, gt);
+            hipLaunchKernelGGL((fb2_kernel<false, false>), pair_grid, dim3(64), 0, s, (uint64_t)n, scalars, out, gt);
     } else if (ct) {
         hipLaunchKernelGGL(fb_ct_kernel, grid64(n), dim3(64), 0, s, (uint64_t)n, scalars, out, gt);
+    } else if (tw) {
+        hipLaunchKernelGGL(fb_kernel<true>, grid64(n), dim3(64), 0, s, (uint64_t)n, scalars, out, gt);
     } else {
-        hipLaunchKernelGGL(fb_kernel, grid64(n), dim3(64), 0, s, (uint64_t)n, scalars, out, gt);
+        hipLaunchKernelGGL(fb_kernel<false>, grid64(n), dim3(64), 0, s, (uint64_t)n, scalars, out, gt);
     }
     CAPY_HIP(hipGetLastError());
     return CAPY_OK;
@@ -858,10 +972,25 @@ static bool pt_order_divides_4(const uint8_t *xy)
     return fe_is_zero(q.X) && fe_is_zero(fe_sub(q.Y, q.Z));
 }
 
+// [r]P = (0, 1), computed on the host with the device code's variable-base algorithm (no GPU needed to refuse a point)
+static bool pt_has_order_r(const uint8_t *xy)
+{
+    static const uint32_t R_WORDS[14] = {0xab5844f3u, 0x2378c292u, 0x8dc58f55u, 0x216cc272u, 0xaed63690u, 0xc44edb49u, 0x7cca23e9u,
+                                         0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0x3fffffffu};
+    uint8_t r_be[56];
+    sc_to_be(r_be, R_WORDS);
+    std::vector<uint32_t> tab(VB_TABLE_DWORDS);
+    const Pt q = vb_scalarmul(r_be, pt_from_affine_bytes(xy), tab.data());
+    return fe_is_zero(q.X) && fe_is_zero(fe_sub(q.Y, q.Z));
+}
+
 int capy_ed448_set_generator(const uint8_t *xy)
 {
     if (xy && !pt_validate_bytes(xy)) return fail(CAPY_ERR_ARG, "generator is not a canonical point of the curve");
     if (xy && pt_order_divides_4(xy)) return fail(CAPY_ERR_ARG, "generator has order 1, 2 or 4");
+    // the fixed-base tables are built from scalars reduced mod r (and, on the twisted curve, from [1/4 mod r] G): both
+    // need a generator of the prime order r, as ExtendedPoint::generator() of any Ed448 library is
+    if (xy && !pt_has_order_r(xy)) return fail(CAPY_ERR_ARG, "generator does not have the prime order r (cofactor component)");
     std::lock_guard<std::mutex> lk(g_gtab_mu);
     const uint8_t *want = xy ? xy : G_XY;
     if (memcmp(current_generator(), want, 112) == 0) return CAPY_OK;
@@ -874,11 +1003,14 @@ int capy_ed448_set_generator(const uint8_t *xy)
         if (g_gtab[dev]) retired.push_back(g_gtab[dev]);
         if (g_gtab_ct[dev]) retired.push_back(g_gtab_ct[dev]);
         if (g_gtab7[dev]) retired.push_back(reinterpret_cast<uint32_t *>(g_gtab7[dev]));
+        if (g_gtab_tw[dev]) retired.push_back(g_gtab_tw[dev]);
         g_gtab[dev] = nullptr;
         g_gtab_ct[dev] = nullptr;
         g_gtab7[dev] = nullptr;
+        g_gtab_tw[dev] = nullptr;
     }
     memcpy(g_gen_xy, want, 112);
+    g_gen_order_r = -1;
     return CAPY_OK;
 }
 

@@ -296,16 +296,30 @@ CAPY_HD_INLINE Pt vb_scalarmul(const uint8_t *k_be, const Pt &P, uint32_t *tab, 
     return acc;
 }
 
-// acc += sign(digit) * G16[row][|digit|]   (affine cached entries: x, y, d*x*y)
+// acc + sign * entry for a fixed-base table entry (e0, e1, e2).  TW = false: the entry is (x, y, d x y) on E, its
+// negative (-x, y, -d x y), the addition pt_add_affine_cached (8M).  TW = true: the entry is (y - x, y + x, 2 d' x y)
+// on the twisted curve E' (ed448_dev.h), its negative swaps the first two and negates the third, the addition is
+// pt_madd_niels_tw (7M).  The whole accumulation then lives on E' and ends with pt_tw_to_affine_bytes.
+template <bool TW>
+CAPY_HD inline Pt fb_add_entry(const Pt &acc, bool neg, const Fe &e0, const Fe &e1, const Fe &e2)
+{
+    if constexpr (TW) {
+        const Fe ymx = fe_select(neg, e0, e1), ypx = fe_select(neg, e1, e0);
+        return pt_madd_niels_tw(acc, ymx, ypx, fe_select(neg, e2, fe_neg_nr(e2)));
+    } else {
+        return pt_add_affine_cached(acc, fe_select(neg, e0, fe_neg_nr(e0)), e1, fe_select(neg, e2, fe_neg_nr(e2)));
+    }
+}
+
+// acc += sign(digit) * G16[row][|digit|]
+template <bool TW = false>
 CAPY_HD inline Pt fb_add_digit(const Pt &acc, const uint32_t *gtab, int row, int digit)
 {
     const bool neg = digit < 0;
     const int idx = neg ? -digit : digit;
     const uint32_t *e = gtab + (row * FB_TAB_ENTRIES + idx) * FB_ENTRY_DWORDS;
-    Fe x2 = load_fe(e), y2 = load_fe(e + 16), td2 = load_fe(e + 32);
-    x2 = fe_select(neg, x2, fe_neg_nr(x2));
-    td2 = fe_select(neg, td2, fe_neg_nr(td2));
-    return pt_add_affine_cached(acc, x2, y2, td2);
+    const Fe e0 = load_fe(e), e1 = load_fe(e + 16), e2 = load_fe(e + 32);
+    return fb_add_entry<TW>(acc, neg, e0, e1, e2);
 }
 
 // Hardened fixed base: a second shared table with FBCT_WBITS-bit signed windows -- few enough entries per row to read ALL
@@ -360,6 +374,7 @@ CAPY_HD_INLINE Pt fb_scalarmul_ct(const uint8_t *k_be, const uint32_t *gtab)
 
 // acc += sum over the FbWin::NWIN windows of the recoded scalar w (the top digit is the caller's business); with lds the
 // entry of window i + 1 is on its way while window i is added
+template <bool TW = false>
 CAPY_HD_INLINE Pt fb_add_windows(Pt acc, uint32_t *w, const uint32_t *gtab, uint32_t *lds)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -370,31 +385,31 @@ CAPY_HD_INLINE Pt fb_add_windows(Pt acc, uint32_t *w, const uint32_t *gtab, uint
         for (int i = 0; i < FbWin::NWIN; i++) {
             const bool neg = digit < 0;
             lds_prefetch_wait();
-            Fe x2 = lds_load_fe(lds, 0), y2 = lds_load_fe(lds, 1), td2 = lds_load_fe(lds, 2);
-            x2 = fe_select(neg, x2, fe_neg_nr(x2));
-            td2 = fe_select(neg, td2, fe_neg_nr(td2));
+            const Fe e0 = lds_load_fe(lds, 0), e1 = lds_load_fe(lds, 1), e2 = lds_load_fe(lds, 2);
             if (i + 1 < FbWin::NWIN) {
                 digit = sc_next_digit_lsb<FB_WBITS>(w);
                 lds_prefetch<12>(lds, gtab + ((i + 1) * FB_TAB_ENTRIES + (digit < 0 ? -digit : digit)) * FB_ENTRY_DWORDS);
             }
-            acc = pt_add_affine_cached(acc, x2, y2, td2);
+            acc = fb_add_entry<TW>(acc, neg, e0, e1, e2);
         }
         return acc;
     }
 #endif
 #pragma unroll 1
-    for (int i = 0; i < FbWin::NWIN; i++) acc = fb_add_digit(acc, gtab, i, sc_next_digit_lsb<FB_WBITS>(w));
+    for (int i = 0; i < FbWin::NWIN; i++) acc = fb_add_digit<TW>(acc, gtab, i, sc_next_digit_lsb<FB_WBITS>(w));
     return acc;
 }
 
-// [k]G from the shared table gtab[FB_TABLE_DWORDS]; lds = the wave's FB_PF_DWORDS of staging (or nullptr)
+// [k]G from the shared table gtab[FB_TABLE_DWORDS]; lds = the wave's FB_PF_DWORDS of staging (or nullptr).
+// TW: gtab is the twisted table and the result a point of E' (see fb_add_entry)
+template <bool TW = false>
 CAPY_HD_INLINE Pt fb_scalarmul(const uint8_t *k_be, const uint32_t *gtab, uint32_t *lds = nullptr)
 {
     uint32_t k[14], w[15];
     sc_from_be(k, k_be);
     const uint32_t top = sc_recode_signed<FB_WBITS>(w, k);
-    const Pt acc = fb_add_digit(pt_identity(), gtab, FbWin::NWIN, (int)top);
-    return fb_add_windows(acc, w, gtab, lds);
+    const Pt acc = fb_add_digit<TW>(pt_identity(), gtab, FbWin::NWIN, (int)top);
+    return fb_add_windows<TW>(acc, w, gtab, lds);
 }
 
 // [a]G + [b]P: the variable-base window loop for [b]P, then [a]G added from the shared fixed-base table (39 mixed

@@ -891,6 +891,91 @@ CAPY_HD inline void pt_pair_to_affine_bytes(uint8_t *xy0, uint8_t *xy1, const Pt
     fe_to_bytes(xy1 + 56, fe_mul(p1.Y, zi1));
 }
 
+// ------------------------------------------------------------------ the fixed base on the 4-isogenous TWISTED curve (r03)
+// E : x^2 + y^2 = 1 + d x^2 y^2 (a = +1, d = -39081) has no 7-multiplication mixed addition: its numerators
+// y1 y2 - x1 x2 and x1 y2 + y1 x2 are a complex-number product (three multiplications at the least), so 8M with Z2 = 1.
+// E': -x^2 + y^2 = 1 + (d - 1) x^2 y^2 (a = -1) has one (madd-2008-hwcd-3, table entries in the form
+// (y - x, y + x, 2 d' x y)), and the two curves are 4-isogenous (Hamburg, "Decaf", section on isogenies):
+//   phi    : E  -> E',  (x, y) -> ( 2xy / (y^2 - x^2),  (y^2 + x^2) / (2 - y^2 - x^2) )
+//   phi^   : E' -> E,   (x, y) -> ( 2xy / (y^2 + x^2),  (y^2 - x^2) / (2 - y^2 + x^2) ),     phi^ o phi = [4]
+// (checked numerically against the oracle's group law; tests/test_ed448_host.py).  For a generator G of the prime order
+// r take G4 = [1/4 mod r] G: the table holds phi(j 2^(w i) G4), the digits are accumulated on E' with 7M additions, and
+// phi^ of the sum is [4][k] G4 = [k] G -- the same affine point, so the same bytes as the kernels that stay on E.
+// (A configured generator whose order is not r keeps the tables and additions on E.)
+constexpr uint32_t ED448_TW_D_ABS = 39082;  // d' = d - 1 = -39082
+
+// one entry of a twisted table from an affine point of E: phi, then (y' - x', y' + x', 2 d' x' y'), canonical limbs
+CAPY_HD inline void pt_tw_niels_from_affine(Fe &ymx, Fe &ypx, Fe &td, const Fe &x, const Fe &y)
+{
+    const Fe xx = fe_sqr(x), yy = fe_sqr(y);
+    const Fe dx = fe_sub(yy, xx);                                  // y^2 - x^2
+    const Fe dy = fe_sub(fe_sub(fe_add(fe_one(), fe_one()), yy), xx);  // 2 - y^2 - x^2
+    const Fe inv = fe_inv_out(fe_mul(dx, dy));
+    const Fe xy = fe_mul(x, y);
+    Fe xt = fe_mul(fe_add(xy, xy), fe_mul(inv, dy));               // 2xy / dx
+    Fe yt = fe_mul(fe_add(yy, xx), fe_mul(inv, dx));               // (y^2 + x^2) / dy
+    ymx = fe_sub(yt, xt);
+    ypx = fe_add(yt, xt);
+    const Fe t = fe_mul(xt, yt);
+    td = fe_neg(fe_mul_small(fe_add(t, t), ED448_TW_D_ABS));       // 2 d' x' y'
+    fe_canon(ymx);
+    fe_canon(ypx);
+    fe_canon(td);
+}
+
+// p + q on E', q given as (y2 - x2, y2 + x2, 2 d' x2 y2) with limbs <= 2^29 (table entries, the third possibly negated).
+// Bounds: E and F are weak-reduced so that every product stays below 2^58.7 (fe_mul).
+CAPY_HD inline Pt pt_madd_niels_tw(const Pt &p, const Fe &ymx2, const Fe &ypx2, const Fe &td2)
+{
+    const Fe A = fe_mul(fe_sub_nr(p.Y, p.X), ymx2);   // <= 2^29.6 x 2^28
+    const Fe B = fe_mul(fe_add_nr(p.Y, p.X), ypx2);
+    const Fe C = fe_mul(p.T, td2);                    // R x 2^29
+    const Fe D = fe_add_nr(p.Z, p.Z);                 // <= 2^29.01
+    const Fe E = fe_sub(B, A);                        // reduced
+    const Fe F = fe_sub(D, C);                        // reduced
+    const Fe G = fe_add_nr(D, C);                     // <= 2^29.6
+    const Fe H = fe_add_nr(B, A);                     // <= 2^29.01
+    Pt r;
+    r.X = fe_mul(E, F);
+    r.Y = fe_mul(G, H);                               // 2^29.6 x 2^29.01
+    r.Z = fe_mul(F, G);
+    r.T = fe_mul(E, H);
+    return r;
+}
+
+// numerators and denominators of phi^ for a point of E' in extended coordinates: x = nx / dx, y = ny / dy on E
+CAPY_HD inline void pt_tw_dual_fractions(const Pt &p, Fe &nx, Fe &dx, Fe &ny, Fe &dy)
+{
+    const Fe xx = fe_sqr(p.X), yy = fe_sqr(p.Y), zz = fe_sqr(p.Z);
+    const Fe xy = fe_mul(p.X, p.Y);
+    nx = fe_add(xy, xy);
+    dx = fe_add(yy, xx);
+    ny = fe_sub(yy, xx);
+    dy = fe_add(fe_sub(fe_add(zz, zz), yy), xx);
+}
+CAPY_HD inline void pt_tw_to_affine_bytes(uint8_t *xy, const Pt &p)
+{
+    Fe nx, dx, ny, dy;
+    pt_tw_dual_fractions(p, nx, dx, ny, dy);
+    const Fe inv = fe_inv_out(fe_mul(dx, dy));
+    fe_to_bytes(xy, fe_mul(nx, fe_mul(inv, dy)));
+    fe_to_bytes(xy + 56, fe_mul(ny, fe_mul(inv, dx)));
+}
+// two of them with one inversion
+CAPY_HD inline void pt_tw_pair_to_affine_bytes(uint8_t *xy0, uint8_t *xy1, const Pt &p0, const Pt &p1)
+{
+    Fe nx0, dx0, ny0, dy0, nx1, dx1, ny1, dy1;
+    pt_tw_dual_fractions(p0, nx0, dx0, ny0, dy0);
+    pt_tw_dual_fractions(p1, nx1, dx1, ny1, dy1);
+    const Fe m0 = fe_mul(dx0, dy0), m1 = fe_mul(dx1, dy1);
+    const Fe ti = fe_inv_out(fe_mul(m0, m1));
+    const Fe i0 = fe_mul(ti, m1), i1 = fe_mul(ti, m0);  // 1 / (dx0 dy0), 1 / (dx1 dy1)
+    fe_to_bytes(xy0, fe_mul(nx0, fe_mul(i0, dy0)));
+    fe_to_bytes(xy0 + 56, fe_mul(ny0, fe_mul(i0, dx0)));
+    fe_to_bytes(xy1, fe_mul(nx1, fe_mul(i1, dy1)));
+    fe_to_bytes(xy1 + 56, fe_mul(ny1, fe_mul(i1, dx1)));
+}
+
 // ------------------------------------------------------------------ scalars
 // 56 big-endian bytes -> 14 little-endian 32-bit words
 CAPY_HD inline void sc_from_be(uint32_t w[14], const uint8_t *in)

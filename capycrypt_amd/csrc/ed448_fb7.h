@@ -57,6 +57,8 @@ __device__ __forceinline__ void fb7_request_row(const uint8_t *__restrict__ gt7,
 
 // the affine cached entry  sign(digit) * |digit| * 2^(7 row) * G  for every lane's own digit, selected by the matrix cores
 // (the row itself was requested by fb7_request_row; next_row >= 0: request that one before returning)
+// TW: the table holds twisted entries (y - x, y + x, 2 d' x y): the identity is (1, 1, 0), a negative swaps the first two
+template <bool TW>
 __device__ __forceinline__ void fb7_select(const uint8_t *__restrict__ gt7, int next_row, int digit, uint32_t *xpose, Fe &x2, Fe &y2, Fe &td2)
 {
     const uint32_t lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
@@ -123,17 +125,34 @@ __device__ __forceinline__ void fb7_select(const uint8_t *__restrict__ gt7, int 
     }
     __syncthreads();  // the next window's writes come after these reads
     if (next_row >= 0) fb7_request_row(gt7, next_row, xpose);  // wave-uniform; lands while the addition runs
-    y2.l[0] |= (uint32_t)(mag == 0);  // digit 0 selected nothing: (0, 0, 0) -> (0, 1, 0), the identity
-    // -(x, y) = (-x, y): negate x and d x y under the sign mask (limb-wise select, no branch)
-    const Fe nx = fe_neg_nr(x2), nt = fe_neg_nr(td2);
+    const uint32_t is0 = (uint32_t)(mag == 0);  // digit 0 selected nothing: all zeros -> the identity entry
+    const Fe nt = fe_neg_nr(td2);
+    if constexpr (TW) {
+        x2.l[0] |= is0;  // (1, 1, 0)
+        y2.l[0] |= is0;
+        // -(x, y) = (-x, y): y - x and y + x change places, 2 d' x y changes sign (limb-wise selects, no branch)
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-        x2.l[i] = (nx.l[i] & neg) | (x2.l[i] & ~neg);
-        td2.l[i] = (nt.l[i] & neg) | (td2.l[i] & ~neg);
+        for (int i = 0; i < 16; i++) {
+            const uint32_t a = x2.l[i], b = y2.l[i];
+            x2.l[i] = (b & neg) | (a & ~neg);
+            y2.l[i] = (a & neg) | (b & ~neg);
+            td2.l[i] = (nt.l[i] & neg) | (td2.l[i] & ~neg);
+        }
+    } else {
+        y2.l[0] |= is0;  // (0, 1, 0)
+        // -(x, y) = (-x, y): negate x and d x y under the sign mask
+        const Fe nx = fe_neg_nr(x2);
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            x2.l[i] = (nx.l[i] & neg) | (x2.l[i] & ~neg);
+            td2.l[i] = (nt.l[i] & neg) | (td2.l[i] & ~neg);
+        }
     }
 }
 
 // [k]G: 65 mixed additions, every table byte of every row read by every wave
+// TW: on the twisted curve (7M additions; the result is a point of E', to be finished by pt_tw_to_affine_bytes)
+template <bool TW>
 __device__ __forceinline__ Pt fb7_scalarmul(const uint8_t *k_be, const uint8_t *__restrict__ gt7, uint32_t *xpose)
 {
     uint32_t k[14], w[15];
@@ -141,12 +160,12 @@ __device__ __forceinline__ Pt fb7_scalarmul(const uint8_t *k_be, const uint8_t *
     const uint32_t top = sc_recode_signed<FB7_WBITS>(w, k);
     Fe x2, y2, td2;
     fb7_request_row(gt7, Fb7Win::NWIN, xpose);
-    fb7_select(gt7, 0, (int)top, xpose, x2, y2, td2);
-    Pt acc = pt_add_affine_cached(pt_identity(), x2, y2, td2);
+    fb7_select<TW>(gt7, 0, (int)top, xpose, x2, y2, td2);
+    Pt acc = TW ? pt_madd_niels_tw(pt_identity(), x2, y2, td2) : pt_add_affine_cached(pt_identity(), x2, y2, td2);
 #pragma unroll 1
     for (int i = 0; i < Fb7Win::NWIN; i++) {
-        fb7_select(gt7, i + 1 < Fb7Win::NWIN ? i + 1 : -1, sc_next_digit_lsb<FB7_WBITS>(w), xpose, x2, y2, td2);
-        acc = pt_add_affine_cached(acc, x2, y2, td2);
+        fb7_select<TW>(gt7, i + 1 < Fb7Win::NWIN ? i + 1 : -1, sc_next_digit_lsb<FB7_WBITS>(w), xpose, x2, y2, td2);
+        acc = TW ? pt_madd_niels_tw(acc, x2, y2, td2) : pt_add_affine_cached(acc, x2, y2, td2);
     }
     return acc;
 }

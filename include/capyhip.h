@@ -157,7 +157,7 @@ int capy_ed448_scalarmul_batch_dev(size_t n, const uint8_t *scalars_be, const ui
                                    uint8_t *out_xy, void *stream);
 /* The point `ExtendedPoint::generator()` stands for.  Default: the RFC 8032 Ed448 base point -- an ASSUMPTION about the
  * absent curve crate; capy_ed448_set_generator(xy) replaces it (xy must pass the validation below
- * and must not be the identity or a point of order 2 or 4; NULL restores the default) for every later fixed-base
+ * and must have the prime order r -- [r] xy = (0, 1), checked on the host; NULL restores the default) for every later fixed-base
  * multiplication, key pair, signature and ECDHIES call of the process; the per-device fixed-base tables are rebuilt on
  * next use.  Calls already in flight finish on the old tables (retired, not freed); meant to be called once at start-up. */
 int capy_ed448_set_generator(const uint8_t *xy);

@@ -49,6 +49,38 @@ int ht_fe_inv_gcd_rounds(const uint8_t *a)
     }
     return 64;
 }
+// twisted-curve fixed base (ed448_dev.h): sum of the given affine points of E, each mapped by phi into the form
+// (y - x, y + x, 2 d' x y) and added on E' (the odd ones negated and their negatives passed in, to exercise the sign
+// handling of the kernels: swap the first two, negate the third), mapped back by phi^: must be 4 x the plain sum
+void ht_tw_sum(const uint8_t *pts_xy, int n, uint8_t *out_xy)
+{
+    Pt acc = pt_identity();
+    for (int i = 0; i < n; i++) {
+        Fe x = fe_from_bytes(pts_xy + 112 * i), y = fe_from_bytes(pts_xy + 112 * i + 56);
+        Fe ymx, ypx, td;
+        if (i & 1) x = fe_neg(x);  // table entry for -P ...
+        pt_tw_niels_from_affine(ymx, ypx, td, x, y);
+        if (i & 1) {  // ... used negated: -( -P ) = P
+            const Fe t = ymx;
+            ymx = ypx;
+            ypx = t;
+            td = fe_neg_nr(td);
+        }
+        acc = pt_madd_niels_tw(acc, ymx, ypx, td);
+    }
+    pt_tw_to_affine_bytes(out_xy, acc);
+}
+void ht_tw_pair(const uint8_t *p_xy, const uint8_t *q_xy, uint8_t *out)
+{
+    Pt a = pt_identity(), b = pt_identity();
+    Fe ymx, ypx, td;
+    pt_tw_niels_from_affine(ymx, ypx, td, fe_from_bytes(p_xy), fe_from_bytes(p_xy + 56));
+    a = pt_madd_niels_tw(a, ymx, ypx, td);
+    pt_tw_niels_from_affine(ymx, ypx, td, fe_from_bytes(q_xy), fe_from_bytes(q_xy + 56));
+    b = pt_madd_niels_tw(b, ymx, ypx, td);
+    b = pt_madd_niels_tw(b, ymx, ypx, td);
+    pt_tw_pair_to_affine_bytes(out, out + 112, a, b);
+}
 void ht_fe_roundtrip(const uint8_t *a, uint8_t *out) { fe_to_bytes(out, fe_from_bytes(a)); }
 // chained: ((a*b)^2 - a + b) * ... exercises lazily reduced operands
 void ht_fe_chain(const uint8_t *a, const uint8_t *b, int n, uint8_t *out)

@@ -82,6 +82,30 @@ def test_division_step_inversion_equals_fermat(L):
     assert worst <= 44, worst
 
 
+def test_twisted_curve_additions_and_the_way_back(L):
+    """The fixed base accumulates on the 4-isogenous twisted curve (7M mixed additions) and comes back through the dual
+    isogeny: phi^(sum of phi(P_i)) = 4 sum P_i.  Random subgroup points, with the negation handling of the kernels
+    (an entry for -P used negated), sums that pass through the identity, and the two-results-one-inversion form."""
+    rng = random.Random(0x150)
+    ident = (0, 1)
+    for n in (1, 2, 3, 7, 20):
+        pts = [E.scalarmul(rng.getrandbits(446), E.G) for _ in range(n)]
+        if n == 2:
+            pts[1] = E.pt_neg(pts[0]) if hasattr(E, "pt_neg") else ((-pts[0][0]) % E.P, pts[0][1])  # sum = identity
+        want = ident
+        for q in pts:
+            want = E.add(want, q)
+        want = E.scalarmul(4, want) if want != ident else ident
+        blob = b"".join(E.pt_to_bytes(q) for q in pts)
+        out = (C.c_uint8 * 112)()
+        L.ht_tw_sum(C.c_char_p(blob), n, out)
+        assert bytes(out) == E.pt_to_bytes(want), n
+    p, q = E.scalarmul(rng.getrandbits(446), E.G), E.scalarmul(rng.getrandbits(446), E.G)
+    out = (C.c_uint8 * 224)()
+    L.ht_tw_pair(C.c_char_p(E.pt_to_bytes(p)), C.c_char_p(E.pt_to_bytes(q)), out)
+    assert bytes(out[:112]) == E.pt_to_bytes(E.scalarmul(4, p)) and bytes(out[112:]) == E.pt_to_bytes(E.scalarmul(8, q))
+
+
 def test_lazy_reduction_chain(L):
     rng = random.Random(6)
     for _ in range(10):
@@ -126,6 +150,10 @@ def test_lazy_reduction_bounds_hold(L):
             call(L, "ht_scalarmul", E.sc_to_bytes(k), xy, outlen=112)  # off-curve inputs are fine: only bounds matter
             call(L, "ht_double_scalarmul", E.sc_to_bytes(k), E.sc_to_bytes(k ^ 0x5555), xy, outlen=112)
             call(L, "ht_basemul", E.sc_to_bytes(k), outlen=112)
+    # the twisted-curve mixed addition and the dual isogeny (fixed base, r03) on the same worst-case coordinates
+    out = (C.c_uint8 * 112)()
+    for xy in worst:
+        L.ht_tw_sum(C.c_char_p(xy * 5), 5, out)
     assert L.ht_bound_violations() == 0
 
 

@@ -582,6 +582,12 @@ def test_generator_can_be_replaced(capy, O):
         with pytest.raises(_lib.CapyHipError):
             capy.ops.ed448_set_generator(bytes(bad))
         assert capy.ops.ed448_get_generator() == g5
+        # a generator whose order is NOT the prime r is refused: G + (0, -1) = (-Gx, -Gy), of order 2r (the fixed-base
+        # tables are built from scalars reduced mod r and, on the twisted curve, from [1/4 mod r] G)
+        gx, gy = E.G
+        with pytest.raises(_lib.CapyHipError):
+            capy.ops.ed448_set_generator(E.pt_to_bytes(((-gx) % E.P, (-gy) % E.P)))
+        assert capy.ops.ed448_get_generator() == g5
     finally:
         capy.ops.ed448_set_generator(None)
     assert capy.ops.ed448_get_generator() == G

@@ -333,6 +333,8 @@ def test_generator_setting_is_validated_on_the_host():
     noncanon = (x + E.P).to_bytes(57, "little")[:56] + E.fe_to_bytes(y)  # only differs when x + p < 2^448: skip otherwise
     if x + E.P < 2 ** 448:
         assert lib.capy_ed448_set_generator(_lib.buf(noncanon)) == _lib.CAPY_ERR_ARG
+    # a point with a cofactor component ([9]G + (0, -1), order 2r) is refused as well: [r] of it is not the identity
+    assert lib.capy_ed448_set_generator(_lib.buf(E.pt_to_bytes(((-x) % E.P, (-y) % E.P)))) == _lib.CAPY_ERR_ARG
     try:
         _lib.check(lib.capy_ed448_set_generator(_lib.buf(E.pt_to_bytes((x, y)))))
         _lib.check(lib.capy_ed448_get_generator(out))
