@@ -737,26 +737,35 @@ static int try_launch_mixed(int rw, const SpongeParams &p, bool forced, hipStrea
     return 1;
 }
 
-// which kernel launch_sponge() picks: 1 one-lane latency-tuned, 2 two-lane, 3 rotating schedule, 4 one-lane issue-tuned
-// messages of up to this many rate blocks (suffix included) take sponge_short.h when the batch fills the chip
-// (CAPY_SHORT_MAX_BLOCKS overrides; profiles/r02_short_message_kernel.txt)
-static const uint32_t SHORT_MAX_BLOCKS = [] {
-    const char *e = getenv("CAPY_SHORT_MAX_BLOCKS");
-    const long v = e ? atol(e) : 4;
-    return (uint32_t)((v >= 0 && v <= 4096) ? v : 4);
-}();
+// which kernel launch_sponge() picks: 1 one-lane latency-tuned, 2 two-lane, 3 rotating schedule, 4 one-lane issue-tuned,
+// 5 wave-quantisation split, 6 wave-per-item digest, 7 uniform-framing kernel
+// occupancy cap of the uniform-framing kernel in waves per SIMD (0: none, four fit; CAPY_UNIFORM_WAVES = 1..4 for A/B)
+static int uniform_waves()
+{
+    static const int w = [] {
+        const char *e = getenv("CAPY_UNIFORM_WAVES");
+        const int v = e ? atoi(e) : 0;
+        return (v >= 1 && v <= 4) ? v : 0;
+    }();
+    return w;
+}
 
-// The conditions under which launch_sponge() takes the short-message kernel (sponge_short.h) / the wave-per-item digest
-// kernel (sponge_wide.h) -- shared with sponge_plan(), so that capy_sha3_launch_plan reports the kernel that really runs.
-// p.order must already hold the device-side processing order if one is used.
-static bool short_kernel_ok(int rw, const SpongeParams &p, int forced, unsigned dbg, size_t simds)
+// The conditions under which launch_sponge() takes the uniform-framing kernel (sponge_uniform.h) / the wave-per-item
+// digest kernel (sponge_wide.h) -- shared with sponge_plan(), so that capy_sha3_launch_plan reports the kernel that
+// really runs.  p.order must already hold the device-side processing order if one is used.  Debug bit 7: never.
+static bool uniform_kernel_ok(int rw, const SpongeParams &p, int forced, unsigned dbg, size_t simds)
 {
     const uint32_t rb = (uint32_t)rw * 8;
-    return forced == 0 && !(dbg & 128) && p.out_mode == 0 && p.absorb_body && p.pre_len == 0 && p.head_len == 0 &&
-           !p.key_offsets && !p.offsets && !p.mask && !p.order && !p.resume_state && !p.head_state && p.stride_bytes == rb &&
-           p.n > 128 * simds && p.uniform_len + p.suffix_len <= SHORT_MAX_BLOCKS * rb && p.msg_stride >= p.uniform_len &&
-           (((uintptr_t)p.msgs | p.msg_stride) & 7) == 0 && p.out_len <= 8 * p.sq_words &&
-           (((uintptr_t)p.out | p.out_stride) & 7) == 0;
+    if (forced != 0 || (dbg & 128) || p.n <= 128 * simds) return false;
+    if (p.out_mode != 0 || p.pre_len || p.key_offsets || p.offsets || p.mask || p.order || p.resume_state || p.head_state ||
+        p.stride_bytes != rb || p.head_len % rb)
+        return false;
+    if (p.head_len && ((((uintptr_t)p.keys | p.key_stride) & 7) || (p.key_len & 7) || p.hdr_len > 16)) return false;
+    if (p.absorb_body && p.uniform_len && ((((uintptr_t)p.msgs | p.msg_stride) & 7) || p.msg_stride < p.uniform_len)) return false;
+    if (p.out_len <= 8 * p.sq_words) return (((uintptr_t)p.out | p.out_stride) & 7) == 0;  // one squeeze block, per lane
+    // longer outputs leave as whole 128-byte lines: 16-byte chunks of 16-word rows
+    return rw >= 16 && p.sq_words == (uint32_t)rw && (p.out_len & 15) == 0 && (((uintptr_t)p.out | p.out_stride) & 15) == 0 &&
+           p.out_stride >= p.out_len && p.out_stride * 64 < 0xfff00000ULL;
 }
 static bool wide_digest_ok(int rw, const SpongeParams &p, int forced, unsigned dbg)
 {
@@ -776,7 +785,7 @@ static int sponge_plan(int rw, const SpongeParams &p, int *phases)
     MixedPlan m;
     const unsigned dbg = g_debug_flags.load();
     if (wide_digest_ok(rw, p, forced, dbg)) return 6;
-    if (short_kernel_ok(rw, p, forced, dbg, simds)) return 7;
+    if (uniform_kernel_ok(rw, p, forced, dbg, simds)) return 7;
     if ((forced == 3 || (forced == 0 && g_mixed_enabled.load())) && mixed_plan(rw, p, forced == 3, m)) {
         *phases = (int)m.P;
         return 3;
@@ -855,15 +864,13 @@ static int launch_sponge(int rw, const SpongeParams &p, hipStream_t s)
             return launch_sponge(rw, tail, s);
         }
     }
-    // Many short, equally long, key-less messages (SHA3 / SHAKE / cSHAKE digests of up to one squeeze block): the framing
-    // is wave-uniform, sponge_short.h decides it with scalar code.  Debug bit 7: never (A/B and tests).
-    {
-        if (short_kernel_ok(rw, p2, forced, q.debug_flags, simds)) {
-            e = launch_sponge_short(rw, p2, s);
-            if (e == hipErrorInvalidValue) return fail(CAPY_ERR_ARG, "internal: no kernel instance for this rate");
-            CAPY_HIP(e);
-            return CAPY_OK;
-        }
+    // Chip-full launches with wave-uniform framing (equal key, message and output lengths, 8-byte aligned): every framing
+    // decision is scalar code in sponge_uniform.h.  Debug bit 7: never (A/B and tests).
+    if (uniform_kernel_ok(rw, p2, forced, q.debug_flags, simds)) {
+        e = launch_sponge_uniform(rw, p2, uniform_waves(), s);
+        if (e == hipErrorInvalidValue) return fail(CAPY_ERR_ARG, "internal: no kernel instance for this rate");
+        CAPY_HIP(e);
+        return CAPY_OK;
     }
     // Very small digest batches of long messages: one sponge per 25 lanes (sponge_wide.h), 1.3x the two-lane kernel per
     // permutation while every wave has most of a SIMD pair's LDS bandwidth to itself (n / 2 waves <= SIMDs / 2).
@@ -1829,8 +1836,8 @@ int capy_debug_secret_scratch_nonzero(void *stream, uint64_t *nonzero_bytes)
 int capy_set_sponge_lanes(int lanes)
 {
     // undocumented A/B switches in the high bits; bit 18 of the argument = debug bit 8 (no paired latency-tuned instance)
-    // bit 19 = debug bit 9 (blocked two-lane round in forced two-lane launches)
-    g_debug_flags.store((((unsigned)lanes >> 8) & 0xff) | ((((unsigned)lanes >> 18) & 3) << 8));
+    // bit 19 = debug bit 9 (blocked two-lane round in forced two-lane launches); bit 20 = debug bit 10 (SPONGE_BLOCK_OUT)
+    g_debug_flags.store((((unsigned)lanes >> 8) & 0xff) | ((((unsigned)lanes >> 18) & 7) << 8));
     g_fused_enabled.store((((unsigned)lanes >> 16) & 1) == 0);  // bit 16: disable the fused encrypt kernel
     g_mixed_enabled.store((((unsigned)lanes >> 17) & 1) == 0);  // bit 17: disable the mixed one/two-lane schedule
     lanes &= 0xff;

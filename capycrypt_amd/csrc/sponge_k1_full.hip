@@ -1,6 +1,5 @@
 // sponge_k1_full.hip — instances of sponge_kernel<RW, FULLCHIP=true, MODE> (see sponge_kernels.h)
 #include "sponge_kernels.h"
-#include "sponge_short.h"
 #include "sponge_launch.h"
 
 namespace capy {
@@ -21,21 +20,6 @@ hipError_t launch_sponge_k1_full(int rw, int mode, const SpongeParams &p, hipStr
         CAPY_CASE(17, 1)  // keystream XOR exists only for cSHAKE/KMAC rates
         CAPY_CASE(19, 1)
         CAPY_CASE(21, 1)
-    default: return hipErrorInvalidValue;
-    }
-    return hipGetLastError();
-}
-
-hipError_t launch_sponge_short(int rw, const SpongeParams &p, hipStream_t s)
-{
-    const dim3 grid((unsigned)((p.n + 63) / 64)), block(64);
-    switch (rw) {
-    case 9: hipLaunchKernelGGL(sponge_short_kernel<9>, grid, block, 0, s, p); break;
-    case 13: hipLaunchKernelGGL(sponge_short_kernel<13>, grid, block, 0, s, p); break;
-    case 17: hipLaunchKernelGGL(sponge_short_kernel<17>, grid, block, 0, s, p); break;
-    case 18: hipLaunchKernelGGL(sponge_short_kernel<18>, grid, block, 0, s, p); break;
-    case 19: hipLaunchKernelGGL(sponge_short_kernel<19>, grid, block, 0, s, p); break;
-    case 21: hipLaunchKernelGGL(sponge_short_kernel<21>, grid, block, 0, s, p); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

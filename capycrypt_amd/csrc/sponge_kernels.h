@@ -349,7 +349,56 @@ __global__ __launch_bounds__(64, WAVES) void sponge_kernel(const SpongeParams p)
         // 8-byte aligned and the squeeze width equal to the rate (cSHAKE / KMAC).
         const bool coop_out = p.sq_words == (uint32_t)RW && p.out_len >= RB && item0 + 64 <= p.n && p.order == nullptr &&
                               p.mask == nullptr && (((uintptr_t)p.out | p.out_stride) & 7) == 0 && p.out_stride * 64 < 0xfff00000ULL;
-        if (coop_out) {
+        // r04: whole 128-byte LINES leave, not rate blocks.  A 136..168-byte block written at its own offset straddles
+        // lines, and the two halves of a straddled line are written a permutation apart: 1.32x the output bytes reached
+        // HBM (config 2, profiles/r02_config2_pmc.txt).  Here every lane files its squeeze words into its item's row of
+        // the staging buffer at (stream position mod 128); whenever the rows hold a full line the wave writes 64 lines
+        // with 8 store instructions of 16 bytes per lane (8 lanes = one line, 8 items per instruction).  The row index
+        // and the emit decision are wave-uniform (equal out_len), so this costs scalar branches only.
+        const bool line_out = RW >= 16 && coop_out && !(p.debug_flags & SPONGE_BLOCK_OUT) && p.out_len >= 128 && (p.out_len & 15) == 0 &&
+                              (((uintptr_t)p.out | p.out_stride) & 15) == 0;
+        if (line_out) {
+            uint8_t *wave_out = p.out + item0 * p.out_stride;  // SGPR pair
+            const uint32_t row = lane * RW;                     // this lane's row of s_stage (RW words; 16 are used)
+            const uint32_t q = lane & 7;
+            uint32_t goff = (lane >> 3) * (uint32_t)p.out_stride + 16 * q;  // store k: item 8k + lane/8, chunk lane%8
+            const uint32_t gstep = 8 * (uint32_t)p.out_stride;
+            const uint32_t total_words = p.out_len / 8;
+            uint32_t done = 0, fill = 0;
+            for (;;) {
+                const uint32_t nw = total_words - done < (uint32_t)RW ? total_words - done : (uint32_t)RW;
+                uint32_t w0 = 0;
+                while (w0 < nw) {
+                    const uint32_t cnt = (16 - fill) < (nw - w0) ? (16 - fill) : (nw - w0);
+#pragma unroll
+                    for (int i = 0; i < RW; i++)
+                        if ((uint32_t)i >= w0 && (uint32_t)i < w0 + cnt) s_stage[row + fill + i - w0] = state_word(a, i);
+                    fill += cnt;
+                    w0 += cnt;
+                    done += cnt;
+                    if (fill == 16 || done == total_words) {
+                        __syncthreads();
+#pragma unroll
+                        for (int k = 0; k < 8; k++) {
+                            const uint64_t *src = &s_stage[(8 * k + (lane >> 3)) * RW + 2 * q];
+                            const uint64_t v0 = src[0], v1 = src[1];
+                            if (2 * q < fill) {
+                                typedef uint32_t __attribute__((ext_vector_type(4))) u32x4;
+                                u32x4 v = {(uint32_t)v0, (uint32_t)(v0 >> 32), (uint32_t)v1, (uint32_t)(v1 >> 32)};
+                                *reinterpret_cast<__attribute__((address_space(1))) u32x4 *>(
+                                    reinterpret_cast<uintptr_t>(wave_out + (goff + (uint32_t)k * gstep))) = v;
+                            }
+                        }
+                        __syncthreads();
+                        goff += 128;
+                        fill = 0;
+                    }
+                }
+                if (done == total_words) break;
+                keccak_hot<FULLCHIP, PAIRED>(a);
+            }
+            produced = p.out_len;
+        } else if (coop_out) {
             uint32_t ooff[RW];
 #pragma unroll
             for (int k = 0; k < RW; k++) {

@@ -22,6 +22,7 @@ hipError_t launch_sponge_fused(int rw, const FusedParams &fp, hipStream_t s);
 // digests of very small batches of long messages: two items per wave, a sponge spread over 25 lanes (sponge_wide.h);
 // rw in {9, 13, 17, 18, 19, 21}, digest mode only, no raw prefix bytes
 hipError_t launch_sponge_wide_digest(int rw, const SpongeParams &p, hipStream_t s);
-// digests of many short, equally long, key-less messages (sponge_short.h); rw in {9, 13, 17, 18, 19, 21}
-hipError_t launch_sponge_short(int rw, const SpongeParams &p, hipStream_t s);
+// chip-full digest / XOF launches with wave-uniform framing (sponge_uniform.h); rw in {9, 13, 17, 18, 19, 21};
+// waves = 1..3: occupancy cap in waves per SIMD (A/B), else none
+hipError_t launch_sponge_uniform(int rw, const SpongeParams &p, int waves, hipStream_t s);
 }  // namespace capy

@@ -8,6 +8,8 @@ namespace capy {
 // set by the launcher (never by the caller) in SpongeParams::debug_flags: the one-lane kernels load message blocks per
 // lane instead of cooperatively through LDS (the default; cleared by debug bit 6 for A/B runs)
 constexpr uint32_t SPONGE_DIRECT_LOADS = 1u << 16;
+// debug bit 10 (A/B): long squeezes leave as rate blocks at their own offsets (r01-r03) instead of whole 128-byte lines
+constexpr uint32_t SPONGE_BLOCK_OUT = 1u << 10;
 
 struct SpongeParams {
     uint64_t init_state[25];  // state after the batch-shared prefix (zeros for SHA3)

@@ -40,9 +40,19 @@ def sponge_lanes(request):
     they can take, and with the wave-cooperative loads through LDS of round 1 (debug bit 6; the default is per-lane loads)."""
     from capycrypt_amd import _lib
 
+    global _CURRENT_LANES
+    _CURRENT_LANES = request.param
     _lib.check(_lib.lib().capy_set_sponge_lanes(request.param))
     yield request.param
+    _CURRENT_LANES = 0
     _lib.check(_lib.lib().capy_set_sponge_lanes(0))
+
+
+_CURRENT_LANES = 0
+
+
+def sponge_lanes_current():
+    return _CURRENT_LANES
 
 
 # ---------------------------------------------------------------- (1) the reference's KATs, via the mirrored API
@@ -239,6 +249,45 @@ def test_config2_keystream_units(capy, O):
     for i in list(range(0, 4096, 97)) + [4095]:
         assert got[i] == O.kmac_xof(keys[i], b"", 8192, b"SKE", 512)
     assert len(set(got)) == len(got)
+
+
+@pytest.mark.parametrize("d", [512, 256, 384, 224])
+def test_long_squeeze_leaves_as_whole_lines(capy, O, d):
+    """r04: XOF squeezes of at least one 128-byte line per item leave the one-lane kernels as whole lines assembled in
+    LDS (sponge_kernels.h, squeeze), not as rate blocks at their own offsets.  Device-pointer kmac_xof at output lengths
+    around the line / block boundaries, row strides that do and do not allow 16-byte stores, full and partial waves, the
+    latency-tuned and (n > 128 per SIMD) the issue-tuned instance: every row must equal the rate-block form's (debug
+    bit 10) and sampled rows the oracle's; bytes between rows stay untouched."""
+    import torch
+
+    from capycrypt_amd import _lib
+
+    lib = _lib.lib()
+    lanes = sponge_lanes_current()
+    cases = [(200, 128, 128), (200, 136, 144), (200, 144, 160), (200, 1024, 1024), (200, 1040, 1056), (200, 2176, 2176),
+             (200, 2304, 2320), (200, 1000, 1000), (200, 1024, 1032), (70000, 1024, 1024), (140032, 272, 288),
+             (140000, 1024, 1024)]
+    for n, out_len, stride in cases:
+        if n > 1000 and d in (384, 224) and out_len != 1024:
+            continue
+        keys = _dev_rand(n * 64, 100 + out_len)
+        hkeys = bytes(keys.cpu().numpy())
+        outs = []
+        # automatic choice (n > 128 per SIMD: sponge_uniform.h) / the fixture's kernel, whole lines / the same, rate blocks
+        for flags in (0, lanes, lanes | (1 << 20)):
+            _lib.check(lib.capy_set_sponge_lanes(flags))
+            out = torch.full((n * stride + 16,), 0xA5, dtype=torch.uint8, device="cuda")
+            _lib.check(lib.capy_kmac_xof_batch_dev(d, n, keys.data_ptr(), 64, 64, None, None, None, 0, 0, 8 * out_len, b"SKE", 3,
+                                                   out.data_ptr(), stride, None))
+            torch.cuda.synchronize()
+            outs.append(out)
+        _lib.check(lib.capy_set_sponge_lanes(lanes))
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), (n, out_len, stride)
+        rows = outs[0][:n * stride].view(n, stride)
+        assert bool((rows[:, out_len:] == 0xA5).all()) and bool((outs[0][n * stride:] == 0xA5).all()), (n, out_len, stride)
+        for i in sorted({0, 1, 63, 64, 127, n // 2, n - 65, n - 2, n - 1}):
+            assert bytes(rows[i, :out_len].cpu().numpy()) == O.kmac_xof(hkeys[64 * i:64 * i + 64], b"", 8 * out_len, b"SKE", d), \
+                (n, out_len, stride, i)
 
 
 # ---------------------------------------------------------------- device-pointer API, unaligned inputs
@@ -819,9 +868,9 @@ def test_small_ragged_batches_of_long_messages(capy, O, sponge_lanes):
 
 
 @pytest.mark.parametrize("d", [224, 256, 384, 512])
-def test_short_message_kernel_matches_generic_kernel(capy, O, sponge_lanes, d):
-    """Uniform batches of more than 128 items per SIMD whose messages are at most four rate blocks long take
-    sponge_short.h (wave-uniform framing decided by scalar code).  Every digest must equal the generic kernel's
+def test_uniform_framing_kernel_matches_generic_kernel(capy, O, sponge_lanes, d):
+    """Uniform, 8-byte aligned digest batches of more than 128 items per SIMD take sponge_uniform.h (wave-uniform
+    framing decided by scalar code; r02-r03: sponge_short.h for at most four blocks).  Every digest must equal the generic kernel's
     (debug bit 7) at the lengths where the framing changes shape -- empty, one byte, word boundaries, r - 1, r, r + 1
     around every block boundary, the reference's 135 (mod 136) suffix rule -- and the oracle's for sampled items;
     cSHAKE with a one-block output goes the same way."""
@@ -837,7 +886,7 @@ def test_short_message_kernel_matches_generic_kernel(capy, O, sponge_lanes, d):
     r = (1600 - 2 * d) // 8
     n = 140000
     lengths = sorted({0, 1, 7, 8, 9, 63, 64, 135, 136, 137, r - 8, r - 1, r, r + 1, 2 * r - 1, 2 * r, 2 * r + 7, 271, 3 * r - 2,
-                      3 * r, 4 * r - 2})
+                      3 * r, 4 * r - 2, 4 * r, 5 * r + 3, 11 * r - 1})
     for L in lengths:
         stride = max(8, (L + 7) // 8 * 8)
         msgs = _dev_rand(n * stride, 100 + L)
@@ -848,7 +897,7 @@ def test_short_message_kernel_matches_generic_kernel(capy, O, sponge_lanes, d):
             _lib.check(lib.capy_sha3_launch_plan(d, n, L, stride, C.byref(kind), C.byref(phases)))
             # the plan shares its predicates with the launcher since r03: dense 28-byte digests (d = 224) are not
             # 8-byte aligned, so that batch really runs on the generic kernel -- and the plan now says so
-            assert (kind.value == 7) == (lanes == 0 and L + 1 <= 4 * r and (d // 8) % 8 == 0), (L, lanes, kind.value)
+            assert (kind.value == 7) == (lanes == 0 and (d // 8) % 8 == 0), (L, lanes, kind.value)
             dig = torch.zeros(n * (d // 8), dtype=torch.uint8, device="cuda")
             _lib.check(lib.capy_sha3_batch_dev(d, n, msgs.data_ptr(), None, L, stride, dig.data_ptr(), None))
             torch.cuda.synchronize()
@@ -875,6 +924,27 @@ def test_short_message_kernel_matches_generic_kernel(capy, O, sponge_lanes, d):
     ho = bytes(outs[0].cpu().numpy())
     for i in range(4):
         assert ho[i * 32:(i + 1) * 32] == O.cshake(host[i * stride:i * stride + L], lbits, b"FN", b"custom", d), (d, i)
+    # KMACXOF with equally long keys (the head is built from aligned key words with one launch-wide funnel shift), bodies
+    # from empty to several blocks, one-block and multi-line outputs
+    rk = (1600 - d) // 8
+    for klen, L, out_len in [(64, 0, 1024), (56, 1000, 64), (8, rk - 3, 64), (24, rk - 4, 48), (32, 2 * rk, 160), (136, 5, 64),
+                             (168 - 8, 7, 64), (400, 3 * rk + 1, 256), (64, 8 * rk - 3, 64), (0, 9, 64)]:
+        stride = max(8, (L + 7) // 8 * 8)
+        kstride = max(8, klen)
+        msgs, keys = _dev_rand(n * stride, 300 + L), _dev_rand(n * kstride, 400 + klen)
+        outs = []
+        for lanes in (0, 128 << 8):
+            _lib.check(lib.capy_set_sponge_lanes(lanes))
+            out = torch.zeros(n * out_len, dtype=torch.uint8, device="cuda")
+            _lib.check(lib.capy_kmac_xof_batch_dev(d, n, keys.data_ptr(), klen, kstride, None, msgs.data_ptr(), None, L, stride,
+                                                   8 * out_len, b"T", 1, out.data_ptr(), out_len, None))
+            torch.cuda.synchronize()
+            outs.append(out)
+        assert torch.equal(outs[0], outs[1]), (d, klen, L, out_len)
+        for i in (0, 63, 64, n - 1):
+            k = bytes(keys[i * kstride:i * kstride + klen].cpu().numpy())
+            m = bytes(msgs[i * stride:i * stride + L].cpu().numpy())
+            assert bytes(outs[0][i * out_len:(i + 1) * out_len].cpu().numpy()) == O.kmac_xof(k, m, 8 * out_len, b"T", d), (d, klen, L, i)
 
 
 def test_wave_per_item_digest_pairs_of_unequal_length(capy, O, sponge_lanes):

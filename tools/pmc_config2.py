@@ -15,6 +15,7 @@ dev = torch.device("cuda", 0)
 st = torch.cuda.current_stream()
 sp = C.c_void_p(st.cuda_stream)
 n = int(os.environ.get("N", str(1 << 20)))
+_lib.check(lib.capy_set_sponge_lanes(int(os.environ.get("LANES", "0"), 0)))  # A/B switches (bit 20: rate-block stores of r03)
 keys = torch.empty(n * 64, dtype=torch.uint8, device=dev)
 _lib.check(lib.capy_fill_random_dev(keys.data_ptr(), keys.numel(), 5, sp))
 out = torch.empty(n * 1024, dtype=torch.uint8, device=dev)
@@ -28,9 +29,10 @@ run()
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record(st)
-for _ in range(5):
+REPS = int(os.environ.get("REPS", "5"))
+for _ in range(REPS):
     run()
 e1.record(st)
 torch.cuda.synchronize()
-ms = e0.elapsed_time(e1) / 5
+ms = e0.elapsed_time(e1) / REPS
 print("config 2: n = %d  %.3f ms per call  %.1f M units/s  %.2f G permutations/s  %.0f GB/s written" % (n, ms, n / ms / 1e3, 11 * n / ms / 1e6, n * 1024 / ms / 1e6))
