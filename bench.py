@@ -350,7 +350,38 @@ def main():
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 eel = float(t.item())
             ed = {"pairs_per_gpu": n, "scalar_mults_per_s": world * n * reps / eel,
-                  "kernel_ms": e0.elapsed_time(e1) / reps}
+                  "kernel_ms": e0.elapsed_time(e1) / reps, "scaling": "weak (every rank its own 2^18 pairs)"}
+            # BASELINE config 4 as specified is a FIXED batch of 2^18 pairs over 1 -> 8 GPUs (2^18 / N per
+            # GPU): the strong-scaled figure beside the weak one.  Rank r takes the contiguous slice r of one global,
+            # rank-independent batch (no collective on the data path; the N outputs concatenate to the 1-GPU output).
+            if world > 1:
+                ns = n // world
+                gsc = torch.empty(n * 56, dtype=torch.uint8, device=dev)
+                gts = torch.empty(n * 56, dtype=torch.uint8, device=dev)
+                _lib.check(lib.capy_fill_random_dev(gsc.data_ptr(), n * 56, 0xCA9C0004, sp))
+                _lib.check(lib.capy_fill_random_dev(gts.data_ptr(), n * 56, 0xCA9C1004, sp))
+                ssc = gsc[rank * ns * 56:(rank + 1) * ns * 56]
+                spt = torch.empty(ns * 112, dtype=torch.uint8, device=dev)
+                sout = torch.empty(ns * 112, dtype=torch.uint8, device=dev)
+                _lib.check(lib.capy_ed448_basemul_batch_dev(ns, gts.data_ptr() + rank * ns * 56, spt.data_ptr(), sp))
+                _lib.check(lib.capy_ed448_scalarmul_batch_dev(ns, ssc.data_ptr(), spt.data_ptr(), sout.data_ptr(), sp))
+                barrier()
+                sreps = 10
+                s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                t2 = time.perf_counter()
+                s0.record(stream)
+                for _ in range(sreps):
+                    _lib.check(lib.capy_ed448_scalarmul_batch_dev(ns, ssc.data_ptr(), spt.data_ptr(), sout.data_ptr(), sp))
+                s1.record(stream)
+                barrier()
+                sel = time.perf_counter() - t2
+                t = torch.tensor([sel], dtype=torch.float64, device=red_dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                sel = float(t.item())
+                ed["strong"] = {"pairs_total": ns * world, "pairs_per_gpu": ns, "scalar_mults_per_s": ns * world * sreps / sel,
+                                "kernel_ms": s0.elapsed_time(s1) / sreps,
+                                "what": "BASELINE config 4: one batch of 2^18 pairs split contiguously over the ranks"}
+                del gsc, gts, spt, sout
             # latency of a small batch (what a one-message-at-a-time caller of the reference's API pays): 64 variable-base
             # multiplications per call, one item per wave (csrc/ed448_wave.h, the default up to 8192 items) against one
             # item per lane; the outputs must be identical
@@ -384,7 +415,7 @@ def main():
     kname = {1: "sponge_kernel<17, false, 0>", 2: "sponge_kernel_k2<17, 0>", 3: "sponge_mixed_kernel<17>",
              4: "sponge_kernel<17, true, 0>",
              5: "sponge_kernel<17, false, 0> head + remainder (wave-quantisation split)",
-             6: "sponge_wide_digest_kernel<17>", 7: "sponge_short_kernel<17>"}[kind.value]
+             6: "sponge_wide_digest_kernel<17>", 7: "sponge_uniform_kernel<17>"}[kind.value]
     launches = phases.value if kind.value != 5 else 1  # a split launch is priced as one step-long launch
 
     # HBM traffic of the dominant kernel: PMC counters cannot be collected from inside the timed process, so the
@@ -480,6 +511,8 @@ def main():
         }
         if ed:
             res["ed448_scalar_mults_per_s"] = ed["scalar_mults_per_s"]
+            if "strong" in ed:
+                res["ed448_scalar_mults_per_s_strong"] = ed["strong"]["scalar_mults_per_s"]
             res["ed448"] = ed
             # Ed448 is integer-multiply VALU bound: instructions per scalar multiplication from the PMC
             # summary of this build, achieved wave-instructions/s from the live kernel time, against the single-issue

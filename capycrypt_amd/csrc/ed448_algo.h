@@ -231,8 +231,7 @@ CAPY_HD_INLINE Pt vb_scalarmul_ct(const uint8_t *k_be, const Pt &P, const CtTabl
     Pt acc = vb_add_digit_ct(pt_identity(), t, (int)top);
 #pragma unroll 1
     for (int i = 0; i < CtWin::NWIN; i++) {
-        CAPY_UNROLL(CAPY_ED448_DBL_UNROLL)
-        for (int j = 0; j < CT_WBITS; j++) acc = pt_dbl<true>(acc);
+        acc = pt_dbl_n<CT_WBITS, CAPY_ED448_DBL_UNROLL>(acc);
         acc = vb_add_digit_ct(acc, t, sc_next_digit_msb<CT_WBITS>(w));
     }
     return acc;
@@ -255,8 +254,7 @@ CAPY_HD_INLINE Pt vb_scalarmul(const uint8_t *k_be, const Pt &P, uint32_t *tab, 
             const int digit = sc_next_digit_msb<WBITS>(w);
             const bool neg = digit < 0;
             lds_prefetch<16>(lds, tab + (neg ? -digit : digit) * 64);
-            CAPY_UNROLL(CAPY_ED448_DBL_UNROLL)
-            for (int j = 0; j < WBITS; j++) acc = pt_dbl<true>(acc);
+            acc = pt_dbl_n<WBITS, CAPY_ED448_DBL_UNROLL>(acc);
             lds_prefetch_wait();
             // pt_add_cached with every operand of the entry read from LDS right before its multiplication (16 live
             // registers for the entry instead of 64: the doubling loop around this keeps 256 VGPRs busy)
@@ -287,10 +285,9 @@ CAPY_HD_INLINE Pt vb_scalarmul(const uint8_t *k_be, const Pt &P, uint32_t *tab, 
 #endif
 #pragma unroll 1
     for (int i = 0; i < NWIN; i++) {
-        // one doubling body keeps the loop inside the I-cache; the compiler sinks the T product (dead in all but
-        // the last trip) out of the loop, so this runs 4S+3M per doubling plus one multiplication per window
-        CAPY_UNROLL(CAPY_ED448_DBL_UNROLL)
-        for (int j = 0; j < WBITS; j++) acc = pt_dbl<true>(acc);
+        // one doubling body keeps the loop inside the I-cache; T comes from the last doubling only (pt_dbl_n): 3S + 4M per
+        // doubling plus one multiplication per window
+        acc = pt_dbl_n<WBITS, CAPY_ED448_DBL_UNROLL>(acc);
         acc = vb_add_digit(acc, tab, sc_next_digit_msb<WBITS>(w));
     }
     return acc;

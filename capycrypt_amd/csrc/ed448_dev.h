@@ -153,6 +153,26 @@ CAPY_HD inline Fe fe_from_columns(uint64_t lo[8], uint64_t hi[8])
     return r;
 }
 
+// acc + x * y as ONE v_mad_u64_u32, in the order written.  The optimiser re-associates a column's sum of products and
+// addends freely and then needs a separate 64-bit addition wherever a value other than the running sum should have been
+// the first multiply-add's addend (r04: 33 v_lshl_add_u64 per fe_mul where 26 are needed); the asm pins the chain.
+// CAPY_ED448_ASM_MAD=0 keeps the plain C form (also what the host build runs).
+#ifndef CAPY_ED448_ASM_MAD
+#define CAPY_ED448_ASM_MAD 1
+#endif
+CAPY_HD inline uint64_t mad64(uint32_t x, uint32_t y, uint64_t acc)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && CAPY_ED448_ASM_MAD
+    // (a literal v_mad_u64_u32 in the asm would do the same, but the hazard recogniser then puts an s_nop after every one
+    // of them and the optimiser no longer sinks dead products out of loops: 12 % slower, measured)
+    uint64_t d = (uint64_t)x * y + acc;
+    asm("" : "+v"(d));
+    return d;
+#else
+    return (uint64_t)x * y + acc;
+#endif
+}
+
 // CAPY_ED448_INLINE=1: inline fe_mul / fe_sqr at every call site (no call, no stack traffic, larger code).
 #ifndef CAPY_ED448_INLINE
 #define CAPY_ED448_INLINE 1
@@ -229,36 +249,37 @@ CAPY_HD CAPY_NOINLINE inline Fe fe_mul(const Fe a, const Fe b)
 #pragma unroll
     for (int i = 0; i < 8; i++)
 #pragma unroll
-        for (int j = 0; j < 8; j++) aa[i + j] += (uint64_t)a.l[i] * b.l[j];
-    // lo starts from AA[k], hi from 0; BB then lands on lo (k < 8) / hi (k >= 8), CC on hi (k < 8) / cch (k >= 8)
+        for (int j = 0; j < 8; j++) aa[i + j] = mad64(a.l[i], b.l[j], aa[i + j]);
+    // the upper columns of CC first: cch[k] is an addend of lo[k] AND the start of hi[k]'s multiply-add chain (r04: a
+    // chain's first multiply-add takes any 64-bit addend for free, so `hi[k] += cch[k]` costs nothing this way)
+#pragma unroll
+    for (int k = 0; k < 7; k++) cch[k] = 0;
+#pragma unroll
+    for (int i = 1; i < 8; i++)
+#pragma unroll
+        for (int j = 8 - i; j < 8; j++) cch[i + j - 8] = mad64(as[i], bs[j], cch[i + j - 8]);
+    // lo starts from AA[k] and takes BB[k]; hi starts from CC[k + 8] and takes CC[k] and BB[k + 8]
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         lo[k] = aa[k];
-        hi[k] = 0;
+        hi[k] = k < 7 ? cch[k] : 0;
     }
-#pragma unroll
-    for (int k = 0; k < 7; k++) cch[k] = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++)
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const int k = i + j;
-            const uint64_t bb = (uint64_t)a.l[8 + i] * b.l[8 + j], cc = (uint64_t)as[i] * bs[j];
             if (k < 8) {
-                lo[k] += bb;
-                hi[k] += cc;
+                lo[k] = mad64(a.l[8 + i], b.l[8 + j], lo[k]);
+                hi[k] = mad64(as[i], bs[j], hi[k]);
             } else {
-                hi[k - 8] += bb;
-                cch[k - 8] += cc;
+                hi[k - 8] = mad64(a.l[8 + i], b.l[8 + j], hi[k - 8]);
             }
         }
 #pragma unroll
     for (int k = 0; k < 8; k++) hi[k] -= aa[k];
 #pragma unroll
-    for (int k = 0; k < 7; k++) {
-        lo[k] += cch[k] - aa[k + 8];
-        hi[k] += cch[k];
-    }
+    for (int k = 0; k < 7; k++) lo[k] += cch[k] - aa[k + 8];
     return fe_from_columns(lo, hi);
 }
 #else
@@ -306,54 +327,96 @@ CAPY_HD CAPY_NOINLINE inline Fe fe_mul(const Fe a, const Fe b)
 
 #if CAPY_ED448_KARATSUBA
 // r = a^2 mod p, Karatsuba as in fe_mul with AA = a0^2, BB = a1^2, CC = (a0 + a1)^2: 3 x 36 = 108 MADs instead of 136.
+// r04: only AA (the product that is SUBTRACTED) is formed with pre-doubled operands.  BB and CC are kept as
+//   off[k]  = sum over i < j, i + j = k of x_i x_j        (the off-diagonal HALF sum)      and
+//   diag[k] = x_(k/2)^2 for even k,
+// the off-diagonal sums of a result column share one multiply-add chain, and the column is
+//   (off << 1) + (carry + diag terms + AA terms)
+// -- one v_lshl_add_u64, which doubles, adds and takes the place of the carry addition of fe_from_columns; the diagonal
+// squares ride on a chain that starts from the carry.  16 operand doublings, 7 `hi += cch` and 8 carry additions go.
 CAPY_HD CAPY_NOINLINE inline Fe fe_sqr(const Fe a)
 {
     CAPY_FE_CHECK_SQR(a);
-    uint32_t as[8], d0[8], d1[8], ds[8];
+    uint32_t as[8], d0[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         as[j] = a.l[j] + a.l[8 + j];  // < 2^31 under the operand bound
         d0[j] = 2 * a.l[j];
-        d1[j] = 2 * a.l[8 + j];
-        ds[j] = 2 * as[j];
     }
-    uint64_t aa[15], lo[8], hi[8], cch[7];
+    uint64_t aa[15];
 #pragma unroll
     for (int k = 0; k < 15; k++) aa[k] = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++)
 #pragma unroll
-        for (int j = i; j < 8; j++) aa[i + j] += (uint64_t)(i < j ? d0[i] : a.l[i]) * a.l[j];
+        for (int j = i; j < 8; j++) aa[i + j] = mad64(i < j ? d0[i] : a.l[i], a.l[j], aa[i + j]);
+    // off-diagonal half sums: och[k] of CC column k + 8 (shared by lo[k] and hi[k]); olo[k] = och[k] + BB[k];
+    // ohi[k] = och[k] + CC[k] + BB[k + 8]
+    uint64_t och[7], olo[8], ohi[8];
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-        lo[k] = aa[k];
-        hi[k] = 0;
-    }
+    for (int k = 0; k < 7; k++) och[k] = 0;
 #pragma unroll
-    for (int k = 0; k < 7; k++) cch[k] = 0;
+    for (int i = 1; i < 8; i++)
+#pragma unroll
+        for (int j = i + 1; j < 8; j++)
+            if (i + j >= 8) och[i + j - 8] = mad64(as[i], as[j], och[i + j - 8]);
+#pragma unroll
+    for (int k = 0; k < 8; k++) olo[k] = ohi[k] = k < 7 ? och[k] : 0;
 #pragma unroll
     for (int i = 0; i < 8; i++)
 #pragma unroll
-        for (int j = i; j < 8; j++) {
+        for (int j = i + 1; j < 8; j++) {
             const int k = i + j;
-            const uint64_t bb = (uint64_t)(i < j ? d1[i] : a.l[8 + i]) * a.l[8 + j];
-            const uint64_t cc = (uint64_t)(i < j ? ds[i] : as[i]) * as[j];
             if (k < 8) {
-                lo[k] += bb;
-                hi[k] += cc;
+                olo[k] = mad64(a.l[8 + i], a.l[8 + j], olo[k]);
+                ohi[k] = mad64(as[i], as[j], ohi[k]);
             } else {
-                hi[k - 8] += bb;
-                cch[k - 8] += cc;
+                ohi[k - 8] = mad64(a.l[8 + i], a.l[8 + j], ohi[k - 8]);
             }
         }
+    // columns in carry order; the diagonal squares of column k sit at index k / 2 (even k only)
+    Fe r;
+    uint64_t c = 0;
 #pragma unroll
-    for (int k = 0; k < 8; k++) hi[k] -= aa[k];
-#pragma unroll
-    for (int k = 0; k < 7; k++) {
-        lo[k] += cch[k] - aa[k + 8];
-        hi[k] += cch[k];
+    for (int k = 0; k < 8; k++) {
+        uint64_t d = c;
+        if (k % 2 == 0) {
+            d = mad64(a.l[8 + k / 2], a.l[8 + k / 2], d);                // BB[k]
+            if (k < 7) d = mad64(as[(k + 8) / 2], as[(k + 8) / 2], d);  // CC[k + 8]
+        }
+        d += aa[k];
+        if (k < 7) d -= aa[k + 8];
+        const uint64_t v = (olo[k] << 1) + d;
+        r.l[k] = (uint32_t)v & M28;
+        c = v >> 28;
     }
-    return fe_from_columns(lo, hi);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        uint64_t d = c;
+        if (k % 2 == 0) {
+            d = mad64(as[k / 2], as[k / 2], d);  // CC[k]
+            if (k < 7) {
+                d = mad64(as[(k + 8) / 2], as[(k + 8) / 2], d);            // CC[k + 8]
+                d = mad64(a.l[8 + (k + 8) / 2], a.l[8 + (k + 8) / 2], d);  // BB[k + 8]
+            }
+        }
+        d -= aa[k];
+        const uint64_t v = (ohi[k] << 1) + d;
+        r.l[8 + k] = (uint32_t)v & M28;
+        c = v >> 28;
+    }
+    // c * 2^448 = c * (2^224 + 1), c < 2^36
+    uint64_t v = r.l[0] + c;
+    r.l[0] = (uint32_t)v & M28;
+    v = r.l[1] + (v >> 28);
+    r.l[1] = (uint32_t)v & M28;
+    r.l[2] += (uint32_t)(v >> 28);
+    v = r.l[8] + c;
+    r.l[8] = (uint32_t)v & M28;
+    v = r.l[9] + (v >> 28);
+    r.l[9] = (uint32_t)v & M28;
+    r.l[10] += (uint32_t)(v >> 28);
+    return r;
 }
 #else
 // r = a^2 mod p.  P = a0^2 + a1^2 ; Q = a1 (2 a0 + a1).  136 MADs.
@@ -807,28 +870,64 @@ CAPY_HD inline Pt pt_add_affine_cached(const Pt &p, const Fe &x2, const Fe &y2, 
     return r;
 }
 
-// Doubling (dbl-2008-hwcd, a = 1): 4 squarings + 4 multiplications (3 if T is not needed).
-template <bool WANT_T>
-CAPY_HD inline Pt pt_dbl(const Pt &p)
+// Doubling (dbl-2008-hwcd, a = 1).  E = 2XY is formed as ONE multiplication X * Y (r04), not as (X + Y)^2 - X^2 - Y^2:
+// a squaring is cheaper than a multiplication (237 against 310 VALU) but extracting the cross term from it costs a limb
+// sum, two limb-wise subtractions and a carry pass (129): 3 squarings + 4 multiplications (5 with T).
+// pt_dbl_core leaves E and H to the caller: T3 = E H is only needed by an addition that follows, so a run of
+// doublings computes it once, after the last one (the optimiser used to sink that product out of the loop on its own;
+// with the pinned multiply-add chains of fe_mul it no longer does).
+// Bounds: A, B, C', XY are R (2^28 + 2^10); E, C, G <= 2^29 + 2^11; H <= 2^29.58; F reduced.
+#ifndef CAPY_ED448_DBL_XY
+#define CAPY_ED448_DBL_XY 1
+#endif
+CAPY_HD inline void pt_dbl_core(Pt &r, Fe &E, Fe &H, const Pt &p)
 {
     Fe A = fe_sqr(p.X);
     Fe B = fe_sqr(p.Y);
     Fe C = fe_sqr(p.Z);
     C = fe_add_nr(C, C);                          // <= 2^29
-    Fe E = fe_sqr(fe_add_nr(p.X, p.Y));           // sqr of 2^29: 40 * 2^58 < 2^64
+#if CAPY_ED448_DBL_XY
+    E = fe_mul(p.X, p.Y);
+    E = fe_add_nr(E, E);                          // <= 2^29 + 2^11
+#else
+    E = fe_sqr(fe_add_nr(p.X, p.Y));              // sqr of 2^29: 40 * 2^58 < 2^64
     E = fe_sub(fe_sub_nr(E, A), B);               // reduced
+#endif
     Fe G = fe_add_nr(A, B);                       // <= 2^29
     Fe F = fe_sub4(G, C);                         // reduced (C exceeds the 2p bias)
-    Fe H = fe_sub_nr(A, B);                       // <= 2^29.58
-    Pt r;
+    H = fe_sub_nr(A, B);                          // <= 2^29.58
+    r.Z = fe_mul(F, G);
     r.X = fe_mul(E, F);
     r.Y = fe_mul(G, H);                           // 2^29 x 2^29.58
-    r.Z = fe_mul(F, G);
+}
+template <bool WANT_T>
+CAPY_HD inline Pt pt_dbl(const Pt &p)
+{
+    Pt r;
+    Fe E, H;
+    pt_dbl_core(r, E, H, p);
     if (WANT_T)
-        r.T = fe_mul(E, H);
+        r.T = fe_mul(E, H);                       // (2^29 + 2^11) x 2^29.58
     else
         r.T = p.T;
     return r;
+}
+// N doublings in a row, T from the last one only
+#define CAPY_PRAGMA_DEV_(x) _Pragma(#x)
+template <int N, int UNROLL = 1>
+CAPY_HD inline Pt pt_dbl_n(Pt acc)
+{
+    Fe E, H;
+    CAPY_PRAGMA_DEV_(unroll UNROLL)
+    for (int j = 0; j < N; j++) {
+        Pt r;
+        pt_dbl_core(r, E, H, acc);
+        acc.X = r.X;
+        acc.Y = r.Y;
+        acc.Z = r.Z;
+    }
+    acc.T = fe_mul(E, H);
+    return acc;
 }
 
 CAPY_HD inline Pt pt_from_affine_bytes(const uint8_t *xy)

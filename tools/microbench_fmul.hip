@@ -47,6 +47,7 @@
 #define X3(P) P P P
 #define X4(P) P P P P
 #define X8(P) X4(P) X4(P)
+#define X12(P) X8(P) X4(P)
 #define X15(P) X8(P) X4(P) X3(P)
 #define X16(P) X8(P) X8(P)
 #define X17(P) X16(P) P
@@ -57,6 +58,25 @@
 #define FMUL_MAD X24(MAD8) X2(ADD32_8) X15(SUB64_2) ADD64_8 X4("v_lshl_add_u64 v[24:25], v[8:9], 0, v[24:25]\n\t") X2("v_lshl_add_u64 v[26:27], v[10:11], 0, v[26:27]\n\t") X16(CARRY1)
 #define FMUL_DFMA X20(FMA8) X2("v_fma_f64 v[8:9], v[40:41], v[42:43], v[8:9]\n\t") X20(ADD64_8) X2("v_lshl_add_u64 v[24:25], v[8:9], 0, v[24:25]\n\t") X17("v_lshl_add_u64 v[26:27], v[10:11], 0, v[26:27]\n\t") X17(CARRY1) X8(SHIFT5) SHIFT5
 
+// r04: timing skeleton of a field multiplication spread over TWO lanes on the Goldilocks split (lane 0
+// holds a0, b0, lane 1 holds a1, b1; each lane computes its own half product and one triangle of (a0 + a1)(b0 + b1)), per
+// lane: 100 v_mad_u64_u32 (64 + 36) | 16 v_add_u32_dpp (limb sums from the partner) | 32 v_cndmask_b32 (the reversed operand
+// copy of the lane that takes the upper triangle; role-dependent operands of the recombination) | 16 64-bit subtractions
+// | 24 64-bit additions | 20 v_mov_b32_dpp (the 8-column exchange and the two carries) | carry propagation 8 x 3 | 10 limb
+// additions (cross-lane carries, wrap)                                                                                   = 258
+#define DPPADD8                                                                                                          \
+    "v_add_u32_dpp v24, v40, v41 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\tv_add_u32_dpp v25, v42, v43 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t" \
+    "v_add_u32_dpp v26, v44, v45 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\tv_add_u32_dpp v27, v46, v47 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t" \
+    "v_add_u32_dpp v28, v40, v43 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\tv_add_u32_dpp v29, v42, v45 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t" \
+    "v_add_u32_dpp v30, v44, v47 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\tv_add_u32_dpp v31, v46, v41 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+#define DPPMOV4                                                                                                          \
+    "v_mov_b32_dpp v32, v8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp v33, v9 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t" \
+    "v_mov_b32_dpp v34, v10 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp v35, v11 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+#define CND8                                                                                                             \
+    "v_cndmask_b32 v24, v8, v9, vcc\n\tv_cndmask_b32 v25, v10, v11, vcc\n\tv_cndmask_b32 v26, v12, v13, vcc\n\tv_cndmask_b32 v27, v14, v15, vcc\n\t" \
+    "v_cndmask_b32 v28, v16, v17, vcc\n\tv_cndmask_b32 v29, v18, v19, vcc\n\tv_cndmask_b32 v30, v20, v21, vcc\n\tv_cndmask_b32 v31, v22, v23, vcc\n\t"
+#define FMUL_2LANE X12(MAD8) X4("v_mad_u64_u32 v[8:9], vcc, v40, v41, v[8:9]\n\t") X2(DPPADD8) X4(CND8) X8(SUB64_2) X3(ADD64_8) X4(DPPMOV4) DPPMOV4 X8(CARRY1) ADD32_8 X2("v_add_u32 v24, v8, v40\n\t")
+
 #define DEF(NAME, BODY)                                                                  \
     __global__ __launch_bounds__(256) void k_##NAME(int loops)                           \
     {                                                                                    \
@@ -64,6 +84,7 @@
     }
 DEF(mad, X4(FMUL_MAD))
 DEF(dfma, X4(FMUL_DFMA))
+DEF(two_lane, X4(FMUL_2LANE))
 DEF(mad_only, X24(MAD8))
 DEF(fma_only, X20(FMA8) X2("v_fma_f64 v[8:9], v[40:41], v[42:43], v[8:9]\n\t"))
 
@@ -74,6 +95,7 @@ int main()
 {
     Ent ents[] = {{"MAD form, whole multiplication (330 instr)", k_mad, 4, 330},
                   {"DFMA form, whole multiplication (437 instr)", k_dfma, 4, 437},
+                  {"two lanes per multiplication, per lane (258 instr)", k_two_lane, 4, 258},
                   {"192 v_mad_u64_u32 alone", k_mad_only, 1, 192},
                   {"162 v_fma_f64 alone", k_fma_only, 1, 162}};
     printf("%-46s %6s %12s %22s %14s\n", "stream", "W", "ms", "G field-mults/s (chip)", "ns/instr/SIMD");
