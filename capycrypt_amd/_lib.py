@@ -20,6 +20,18 @@ CAPY_ERR_UNSUPPORTED_SECPARAM = -1
 CAPY_ERR_ARG = -2
 CAPY_ERR_HIP = -3
 CAPY_ERR_UNSUPPORTED = -4
+CAPY_HARDEN_OFF, CAPY_HARDEN_ALL, CAPY_HARDEN_PROTOCOL = 0, 1, 4
+CAPY_OPT_DEFAULT = -1
+
+
+class CallOptions(C.Structure):
+    """capy_call_options (include/capyhip.h): per-call hardened mode / scalar-star mode / generator handle / stream."""
+    _fields_ = [("struct_size", C.c_uint32), ("hardened", C.c_int32), ("scalar_star", C.c_int32), ("generator", C.c_int32),
+                ("stream", C.c_void_p)]
+
+    def __init__(self, hardened=CAPY_OPT_DEFAULT, scalar_star=CAPY_OPT_DEFAULT, generator=0, stream=None):
+        super().__init__(C.sizeof(CallOptions), hardened, scalar_star, generator, stream)
+
 
 # every symbol include/capyhip.h declares: name -> (restype, argtypes)
 SIGNATURES = {
@@ -33,6 +45,7 @@ SIGNATURES = {
     "capy_device_synchronize": (C.c_int, []),
     "capy_release_workspace": (C.c_int, []),
     "capy_debug_secret_scratch_nonzero": (C.c_int, [vp, vp]),
+    "capy_debug_last_curve_kernel": (C.c_int, [vp, vp]),
     "capy_sha3_batch": (C.c_int, [C.c_int, sz, vp, vp, vp]),
     "capy_sha3_batch_dev": (C.c_int, [C.c_int, sz, vp, vp, u64, u64, vp, vp]),
     "capy_cshake_batch": (C.c_int, [C.c_int, sz, vp, vp, sz, vp, sz, vp, sz, vp]),
@@ -45,12 +58,17 @@ SIGNATURES = {
     "capy_sha3_decrypt_batch_dev": (C.c_int, [C.c_int, sz, vp, sz, vp, u64, vp, vp, vp, u64, u64, vp, vp, vp]),
     "capy_kem_sponge_encrypt_batch": (C.c_int, [C.c_int, sz, vp, sz, vp, vp, vp, vp]),
     "capy_kem_sponge_decrypt_batch": (C.c_int, [C.c_int, sz, vp, sz, vp, vp, vp, vp, vp]),
+    "capy_kem_sponge_encrypt_batch_dev": (C.c_int, [C.c_int, sz, vp, sz, vp, vp, vp, u64, u64, vp, vp]),
+    "capy_kem_sponge_decrypt_batch_dev": (C.c_int, [C.c_int, sz, vp, sz, vp, vp, vp, u64, u64, vp, vp, vp]),
     "capy_ed448_scalarmul_batch": (C.c_int, [sz, vp, vp, vp]),
     "capy_ed448_scalarmul_batch_dev": (C.c_int, [sz, vp, vp, vp, vp]),
     "capy_ed448_basemul_batch": (C.c_int, [sz, vp, vp]),
     "capy_ed448_basemul_batch_dev": (C.c_int, [sz, vp, vp, vp]),
     "capy_ed448_add_batch": (C.c_int, [sz, vp, vp, vp]),
     "capy_ed448_double_scalarmul_batch": (C.c_int, [sz, vp, vp, vp, vp]),
+    "capy_ed448_add_batch_dev": (C.c_int, [sz, vp, vp, vp, vp]),
+    "capy_ed448_double_scalarmul_batch_dev": (C.c_int, [sz, vp, vp, vp, vp, vp]),
+    "capy_ed448_generator_create": (C.c_int, [vp, vp]),
     "capy_ed448_set_hardened": (C.c_int, [C.c_int]),
     "capy_ed448_set_wave_max": (C.c_int, [C.c_long]),
     "capy_ed448_set_generator": (C.c_int, [vp]),
@@ -68,6 +86,20 @@ SIGNATURES = {
     "capy_schnorr_verify_batch_dev": (C.c_int, [C.c_int, sz, vp, vp, vp, u64, u64, vp, vp, vp, vp]),
     "capy_key_encrypt_batch_dev": (C.c_int, [C.c_int, sz, vp, vp, vp, vp, u64, u64, vp, vp, vp]),
     "capy_key_decrypt_batch_dev": (C.c_int, [C.c_int, sz, vp, sz, vp, vp, vp, vp, u64, u64, vp, vp, vp]),
+    "capy_ed448_scalarmul_batch_ex": (C.c_int, [sz, vp, vp, vp, vp]),
+    "capy_ed448_scalarmul_batch_dev_ex": (C.c_int, [sz, vp, vp, vp, vp]),
+    "capy_ed448_basemul_batch_ex": (C.c_int, [sz, vp, vp, vp]),
+    "capy_ed448_basemul_batch_dev_ex": (C.c_int, [sz, vp, vp, vp]),
+    "capy_keypair_batch_ex": (C.c_int, [C.c_int, sz, vp, sz, vp, vp, vp]),
+    "capy_schnorr_sign_batch_ex": (C.c_int, [C.c_int, sz, vp, sz, vp, vp, vp, vp, vp, vp]),
+    "capy_schnorr_verify_batch_ex": (C.c_int, [C.c_int, sz, vp, vp, vp, vp, vp, vp, vp]),
+    "capy_key_encrypt_batch_ex": (C.c_int, [C.c_int, sz, vp, vp, vp, vp, vp, vp, vp]),
+    "capy_key_decrypt_batch_ex": (C.c_int, [C.c_int, sz, vp, sz, vp, vp, vp, vp, vp, vp, vp]),
+    "capy_keypair_batch_dev_ex": (C.c_int, [C.c_int, sz, vp, sz, vp, vp, vp]),
+    "capy_schnorr_sign_batch_dev_ex": (C.c_int, [C.c_int, sz, vp, sz, vp, vp, vp, u64, u64, vp, vp, vp]),
+    "capy_schnorr_verify_batch_dev_ex": (C.c_int, [C.c_int, sz, vp, vp, vp, u64, u64, vp, vp, vp, vp]),
+    "capy_key_encrypt_batch_dev_ex": (C.c_int, [C.c_int, sz, vp, vp, vp, vp, u64, u64, vp, vp, vp]),
+    "capy_key_decrypt_batch_dev_ex": (C.c_int, [C.c_int, sz, vp, sz, vp, vp, vp, vp, u64, u64, vp, vp, vp]),
     "capy_set_sponge_lanes": (C.c_int, [C.c_int]),
     "capy_sha3_launch_plan": (C.c_int, [C.c_int, sz, u64, u64, vp, vp]),
     "capy_fill_random_dev": (C.c_int, [vp, u64, u64, vp]),

@@ -21,13 +21,39 @@ int fail(int code, const std::string &msg);
             return capy::fail(CAPY_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));           \
     } while (0)
 
+// Per-call options (capy_call_options, include/capyhip.h): the *_ex entry points set them for the calling thread for
+// the duration of the call; the sharded host forms hand them to their per-device workers.  -1 / 0 = the process-wide
+// defaults of the setters.
+struct CallOpts {
+    int hardened = -1;
+    int scalar_star = -1;
+    int generator = 0;
+    void *stream = nullptr;  // host-buffer forms: unused (they work on the calling thread's default stream)
+};
+CallOpts &thread_opts();
+int parse_call_options(const capy_call_options *opt, CallOpts &out);  // CAPY_OK or CAPY_ERR_ARG
+struct OptScope {
+    CallOpts saved;
+    explicit OptScope(const CallOpts &o) : saved(thread_opts()) { thread_opts() = o; }
+    OptScope(const OptScope &) = delete;
+    OptScope &operator=(const OptScope &) = delete;
+    ~OptScope() { thread_opts() = saved; }
+};
+
+// Debug / A-B knobs (r04: ONE environment variable, parsed once when the library first needs a knob):
+//   CAPY_DEBUG="key=value,key=value,..."   e.g. CAPY_DEBUG="uniform_waves=3,fused_max=65536"
+// keys: fused_max, wide_max, mixed_ratio, uniform_waves (sponge launch thresholds); ed448_pair (0 / 1), ed448_wave_max,
+// host_overlap (0), host_arena (0), worker_affinity (0).  Unknown keys are reported once on stderr.  A knob that is not
+// set returns `dflt`.  These are measurement switches, not product settings (those are function arguments / call options).
+double debug_knob(const char *key, double dflt);
+
 // RAII device allocation for the host-pointer entry points, served from a per-thread cache of blocks (sponge.hip:
 // devbuf_take / devbuf_give) so that repeated calls neither allocate nor free (= synchronise).
 // Buffers of up to ARENA_MAX_BUF bytes come from the thread's ARENA instead: one block of pinned host memory that the device
 // maps.  The kernels read such inputs from it and write such outputs to it directly, so a small call makes no copy
 // calls at all -- filling it is a memcpy, reading a result is one stream synchronisation and a memcpy (r03: a KMAC tag
 // of one 1 KiB message took 112 us through this ABI against 38 us on device buffers, the difference being five small
-// synchronous hipMemcpy).  CAPY_HOST_ARENA=0 switches it off.  `host` is the CPU's address of an arena buffer.
+// synchronous hipMemcpy).  CAPY_DEBUG=host_arena=0 switches it off.  `host` is the CPU's address of an arena buffer.
 void *devbuf_take(size_t bytes, size_t *cap);  // nullptr on allocation failure
 void devbuf_give(void *p, size_t cap);
 constexpr size_t ARENA_MAX_BUF = (1 << 20) + 16;  // measured 16 KiB / 64 KiB / 1 MiB: profiles/r03_small_calls.txt
@@ -185,6 +211,8 @@ inline bool keys_ok(const uint8_t *keys, size_t key_len, const uint64_t *key_off
 
 // longest per-item key / password (the per-item head builder of the kernels encodes 8*|K| in at most three bytes)
 constexpr size_t CAPY_MAX_KEY_LEN = (size_t)1 << 20;
+// longest squeeze per item: SpongeParams::out_len is 32 bits wide
+constexpr size_t CAPY_MAX_OUT_LEN = 0xffffffffULL;
 
 inline bool valid_d(int d) { return d == 224 || d == 256 || d == 384 || d == 512; }
 

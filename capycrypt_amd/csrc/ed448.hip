@@ -362,13 +362,13 @@ __global__ void sc_sign_z_kernel(uint64_t n, const uint8_t *k_be, const uint8_t 
 static inline dim3 grid64(size_t n) { return dim3((unsigned)((n + 63) / 64)); }
 
 // Two items per lane (one shared inversion) once the batch still gives every SIMD two waves at half the wave count:
-// 2 waves x 4 SIMDs x CUs x 128 items = 262 144 on MI355X.  CAPY_ED448_PAIR=0/1 forces it off / on (A/B).
+// 2 waves x 4 SIMDs x CUs x 128 items = 262 144 on MI355X.  CAPY_DEBUG=ed448_pair=0/1 forces it off / on (A/B).
 static size_t pair_min_items()
 {
     static const size_t v = [] {
-        const char *e = getenv("CAPY_ED448_PAIR");
-        if (e && e[0] == '0') return (size_t)-1;
-        if (e && e[0] == '1') return (size_t)128;
+        const double e = debug_knob("ed448_pair", -1);
+        if (e == 0) return (size_t)-1;
+        if (e == 1) return (size_t)128;
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) != hipSuccess ||
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
@@ -378,21 +378,30 @@ static size_t pair_min_items()
     return v;
 }
 
-// Constant-address table lookups (capy_ed448_set_hardened): table reads that do not depend on the scalar.  Variable
-// base: vb_scalarmul_ct reads every row of the (lane-interleaved) per-item table per window.  Fixed base: the 12-bit table
-// cannot be read in full per window (2049 entries), so fb_scalarmul_ct uses a second shared table with 5-bit windows (17
-// entries per row, 90 windows).  Mode bits: 1 = the multiplications by SECRET scalars inside the protocol calls
-// (KeyPair::new, sign, key_encrypt's ephemeral k, key_decrypt) -- ON BY DEFAULT since r03, as the reference's curve
-// crate advertises fixed-time lookups; 2 = also the raw capy_ed448_scalarmul / basemul calls, whose scalars the library
-// cannot classify.  Verification and the table builds work on public data and always take the indexed kernels.
-static std::atomic<int> g_hardened{1};
+// Constant-address table lookups (capy_ed448_set_hardened / capy_call_options::hardened): table reads that do not depend
+// on the scalar.  Variable base: vb_scalarmul_ct reads every row of the (lane-interleaved) per-item table per window.
+// Fixed base: the 12-bit table cannot be read in full per window (2049 entries), so the hardened kernels use tables with
+// narrow windows.  CAPY_HARDEN_PROTOCOL (the default): the multiplications by SECRET scalars inside the protocol calls
+// (KeyPair::new, sign, key_encrypt's ephemeral k, key_decrypt), as the reference's curve crate advertises fixed-time
+// lookups; CAPY_HARDEN_ALL: also the raw capy_ed448_scalarmul / basemul calls, whose scalars the library cannot
+// classify; CAPY_HARDEN_OFF: none.  Verification and the table builds work on public data and always take the indexed kernels.
+static std::atomic<int> g_hardened{CAPY_HARDEN_PROTOCOL};
 // reading of the curve crate's `Scalar * Scalar` at signable.rs:46 (ed448_algo.h: sc_star4); 0 = product mod r
 static std::atomic<int> g_scalar_star{0};
 static bool harden(bool secret)
 {
-    const int m = g_hardened.load();
-    return (m & 2) || (secret && (m & 1));
+    const int o = thread_opts().hardened;
+    const int m = o >= 0 ? o : g_hardened.load();
+    return m == CAPY_HARDEN_ALL || (secret && m == CAPY_HARDEN_PROTOCOL);
 }
+static int scalar_star_mode()
+{
+    const int o = thread_opts().scalar_star;
+    return o >= 0 ? o : g_scalar_star.load();
+}
+// test hook (capy_debug_last_curve_kernel): which kernel family the calling thread's last variable-base / fixed-base
+// launch took: 1 indexed, 2 constant-address; +16 for the one-item-per-wave kernels
+static thread_local int t_last_vb_kernel = 0, t_last_fb_kernel = 0;
 
 // Small batches: one item per WAVE (ed448_wave.h) instead of one per lane -- 7x lower latency for the variable-base
 // and 3.6x for the fixed-base multiplication, worth it while the batch is too small to fill the chip's lanes: the
@@ -401,16 +410,13 @@ static bool harden(bool secret)
 // 0.46 -> 0.30 ms at one wave per SIMD, wave kernel 0.147 -> 0.119 ms; profiles/r03_ed448_gcd_inversion.txt): the
 // crossover is ~3000 items indexed and ~6500 with constant-address lookups, hence 5/16 and 3/4 of the threshold; with
 // the constant-address lookups on the matrix cores (ed448_fb7.h: 0.52 ms at one wave per SIMD) ~3800, hence 7/16.
-// capy_ed448_set_wave_max() / CAPY_ED448_WAVE_MAX override the threshold (0 = never).
+// capy_ed448_set_wave_max() / CAPY_DEBUG=ed448_wave_max=N override the threshold (0 = never).
 static std::atomic<long> g_wave_max{-1};
 static size_t wave_max_items()
 {
     const long forced = g_wave_max.load();
     if (forced >= 0) return (size_t)forced;
-    static const long env = [] {
-        const char *e = getenv("CAPY_ED448_WAVE_MAX");
-        return e ? atol(e) : -1L;
-    }();
+    static const long env = (long)debug_knob("ed448_wave_max", -1);
     return env >= 0 ? (size_t)env : (size_t)CAPY_ED448_WAVE_MAX_DEFAULT;
 }
 
@@ -420,6 +426,7 @@ static int vb_launch(size_t n, const uint8_t *scalars, uint64_t scalar_stride, c
 {
     if (!n) return CAPY_OK;
     const bool ct = harden(secret);
+    t_last_vb_kernel = (ct ? 2 : 1) + (n <= wave_max_items() ? 16 : 0);
     if (n <= wave_max_items()) {
         if (ct)
             hipLaunchKernelGGL(wave::vb_wave_kernel<true>, dim3((unsigned)n), dim3(64), 0, s, (uint64_t)n, scalars, scalar_stride,
@@ -454,7 +461,6 @@ static int vb_launch(size_t n, const uint8_t *scalars, uint64_t scalar_stride, c
 // The shared fixed-base table: row i, entry j = (j * 2^(WBITS i) mod r) * G, affine cached.  Built once per
 // device by running the variable-base kernel on G itself, then packed into limbs.
 static std::mutex g_gtab_mu;
-static uint32_t *g_gtab[64] = {nullptr};
 
 static const uint8_t G_XY[112] = {
     0x5e, 0xc0, 0x0c, 0xc7, 0x2b, 0xa8, 0x26, 0x26, 0x8e, 0x93, 0x00, 0x8b, 0xe1, 0x80, 0x3b, 0x43, 0x11, 0x65, 0xb6,
@@ -464,27 +470,43 @@ static const uint8_t G_XY[112] = {
     0xe6, 0x1c, 0xff, 0xd3, 0x3a, 0xd7, 0xc2, 0xa0, 0x05, 0x1e, 0x9c, 0x78, 0x87, 0x40, 0x98, 0xa3, 0x6c, 0x73, 0x73,
     0xea, 0x4b, 0x62, 0xc7, 0xc9, 0x56, 0x37, 0x20, 0x76, 0x88, 0x24, 0xbc, 0xb6, 0x6e, 0x71, 0x46, 0x3f, 0x69};
 
-// The generator in use.  Default: the RFC 8032 base point above -- what `ExtendedPoint::generator()` of the absent curve
-// crate is ASSUMED to be (assumption (i)).  capy_ed448_set_generator replaces it, so that a
-// maintainer who finds the crate's generator to be a different point of the curve aligns the library in one call
-// instead of a rebuild; every fixed-base table is rebuilt lazily from the new point.
-static uint8_t g_gen_xy[112];
-static bool g_gen_set = false;
+// Generators.  Handle 0 is the process generator: by default the RFC 8032 base point above -- what
+// `ExtendedPoint::generator()` of the absent curve crate is ASSUMED to be (assumption (i)).
+// capy_ed448_set_generator replaces it, so that a maintainer who finds the crate's generator to be a different point of
+// the curve aligns the library in one call instead of a rebuild; capy_ed448_generator_create registers further points
+// that single calls select through capy_call_options::generator (r04), so that two host threads can work with different
+// generators at the same time.  Every context owns its fixed-base tables, built lazily per device.
+struct GenCtx {
+    uint8_t xy[112];
+    int order_r = -1;                    // -1 not yet known, 0 / 1 (the twisted-curve tables need the prime order r)
+    uint32_t *gtab[64] = {nullptr};      // indexed 12-bit table on E
+    uint32_t *gtab_ct[64] = {nullptr};   // the hardened table (FBCT_WBITS-bit windows), built on first hardened use
+    uint32_t *gtab_tw[64] = {nullptr};   // the indexed 12-bit table on the twisted curve (lane-per-item fixed base)
+    uint8_t *gtab7[64] = {nullptr};      // the hardened table as matrix-core operands (ed448_fb7.h)
+    bool gtab7_twisted[64] = {false};
+};
+static std::vector<GenCtx *> g_gens;  // guarded by g_gtab_mu; contexts are never freed (handles stay valid)
+static GenCtx *gen_ctx(int handle)    // caller holds g_gtab_mu; nullptr for an unknown handle
+{
+    if (g_gens.empty()) {
+        GenCtx *c = new GenCtx();
+        memcpy(c->xy, G_XY, 112);
+        g_gens.push_back(c);
+    }
+    return (handle >= 0 && (size_t)handle < g_gens.size()) ? g_gens[handle] : nullptr;
+}
+static GenCtx *current_gen() { return gen_ctx(thread_opts().generator); }  // caller holds g_gtab_mu
 static const uint8_t *current_generator()  // caller holds g_gtab_mu
 {
-    if (!g_gen_set) {
-        memcpy(g_gen_xy, G_XY, 112);
-        g_gen_set = true;
-    }
-    return g_gen_xy;
+    GenCtx *c = current_gen();
+    return c ? c->xy : G_XY;
 }
 
-static uint32_t *g_gtab_ct[64] = {nullptr};  // the hardened table (FBCT_WBITS-bit windows), built on first hardened use
 
 // rows x entries table of j * 2^(wbits row) * G in affine cached form, built by the variable-base kernel on G itself
 // twisted: the multiples of G4 = [1/4 mod r] G mapped to the 4-isogenous twisted curve (ed448_dev.h); only for a
 // generator of order r (generator_has_order_r)
-static int build_gtab(int rows, int entries, int wbits, uint32_t **slot, bool twisted = false)
+static int build_gtab(const uint8_t *gen_xy, int rows, int entries, int wbits, uint32_t **slot, bool twisted = false)
 {
     const size_t n = (size_t)rows * entries;
     std::vector<uint8_t> sc(n * 56), pts(n * 112);
@@ -497,7 +519,7 @@ static int build_gtab(int rows, int entries, int wbits, uint32_t **slot, bool tw
         uint32_t acc[14] = {0};
         for (int j = 0; j < entries; j++) {
             sc_to_be(sc.data() + (size_t)(row * entries + j) * 56, acc);
-            memcpy(pts.data() + (size_t)(row * entries + j) * 112, current_generator(), 112);
+            memcpy(pts.data() + (size_t)(row * entries + j) * 112, gen_xy, 112);
             sc_add_mod(acc, pw);
         }
         for (int d = 0; d < wbits; d++) sc_dbl_mod(pw);
@@ -535,10 +557,9 @@ static int build_gtab(int rows, int entries, int wbits, uint32_t **slot, bool tw
 #ifndef CAPY_ED448_FB_TWISTED
 #define CAPY_ED448_FB_TWISTED 1
 #endif
-static int g_gen_order_r = -1;  // -1 not yet known, 0 / 1; guarded by g_gtab_mu, reset by capy_ed448_set_generator
-static int generator_has_order_r(bool *yes)  // caller holds g_gtab_mu
+static int generator_has_order_r(GenCtx *g, bool *yes)  // caller holds g_gtab_mu
 {
-    if (g_gen_order_r < 0) {
+    if (g->order_r < 0) {
         static const uint32_t R_WORDS[14] = {0xab5844f3u, 0x2378c292u, 0x8dc58f55u, 0x216cc272u, 0xaed63690u, 0xc44edb49u, 0x7cca23e9u,
                                              0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0x3fffffffu};
         uint8_t r_be[56], out[112];
@@ -549,7 +570,7 @@ static int generator_has_order_r(bool *yes)  // caller holds g_gtab_mu
         CAPY_HIP(dout.alloc(112));
         CAPY_HIP(dtab.alloc(VB_TABLE_DWORDS * 4));
         CAPY_HIP(dsc.put(r_be, 56));
-        CAPY_HIP(dpt.put(current_generator(), 112));
+        CAPY_HIP(dpt.put(g->xy, 112));
         hipLaunchKernelGGL(vb_kernel, dim3(1), dim3(64), 0, nullptr, (uint64_t)1, dsc.as<uint8_t>(), (uint64_t)56, dpt.as<uint8_t>(),
                            (uint64_t)112, dout.as<uint8_t>(), dtab.as<uint32_t>());
         CAPY_HIP(hipGetLastError());
@@ -557,27 +578,27 @@ static int generator_has_order_r(bool *yes)  // caller holds g_gtab_mu
         bool ident = out[56] == 1;  // (0, 1): x all zero, y = 1 little-endian
         for (int i = 0; i < 112; i++)
             if (i != 56 && out[i] != 0) ident = false;
-        g_gen_order_r = ident ? 1 : 0;
+        g->order_r = ident ? 1 : 0;
     }
-    *yes = CAPY_ED448_FB_TWISTED && g_gen_order_r == 1;
+    *yes = CAPY_ED448_FB_TWISTED && g->order_r == 1;
     return CAPY_OK;
 }
 
-static uint8_t *g_gtab7[64] = {nullptr};
-static bool g_gtab7_twisted[64] = {false};
 static int ensure_gtab7(const uint8_t **out, bool *twisted)
 {
     int dev = 0;
     CAPY_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64) return fail(CAPY_ERR_ARG, "device index out of range");
     std::lock_guard<std::mutex> lk(g_gtab_mu);
-    if (!g_gtab7[dev]) {
+    GenCtx *g = current_gen();
+    if (!g) return fail(CAPY_ERR_ARG, "unknown generator handle");
+    if (!g->gtab7[dev]) {
         bool tw = false;
-        const int rco = generator_has_order_r(&tw);
+        const int rco = generator_has_order_r(g, &tw);
         if (rco) return rco;
-        g_gtab7_twisted[dev] = tw;
+        g->gtab7_twisted[dev] = tw;
         uint32_t *lin = nullptr;
-        const int rc = build_gtab(FB7_ROWS, FB7_ENTRIES, FB7_WBITS, &lin, tw);
+        const int rc = build_gtab(g->xy, FB7_ROWS, FB7_ENTRIES, FB7_WBITS, &lin, tw);
         if (rc) return rc;
         uint8_t *gt7 = nullptr;
         if (hipMalloc((void **)&gt7, FB7_TABLE_BYTES) != hipSuccess) {
@@ -592,14 +613,13 @@ static int ensure_gtab7(const uint8_t **out, bool *twisted)
             (void)hipFree(gt7);
             return fail(CAPY_ERR_HIP, "building the fixed-base table failed");
         }
-        g_gtab7[dev] = gt7;
+        g->gtab7[dev] = gt7;
     }
-    *out = g_gtab7[dev];
-    *twisted = g_gtab7_twisted[dev];
+    *out = g->gtab7[dev];
+    *twisted = g->gtab7_twisted[dev];
     return CAPY_OK;
 }
 
-static uint32_t *g_gtab_tw[64] = {nullptr};  // the indexed 12-bit table on the twisted curve (lane-per-item fixed base)
 // twisted (in/out, indexed table only): ask for the twisted table; comes back false when the generator's order is not r
 static int ensure_gtab(const uint32_t **out, bool hardened_table = false, bool *twisted = nullptr)
 {
@@ -607,16 +627,18 @@ static int ensure_gtab(const uint32_t **out, bool hardened_table = false, bool *
     CAPY_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64) return fail(CAPY_ERR_ARG, "device index out of range");
     std::lock_guard<std::mutex> lk(g_gtab_mu);
+    GenCtx *g = current_gen();
+    if (!g) return fail(CAPY_ERR_ARG, "unknown generator handle");
     bool tw = false;
     if (twisted && *twisted && !hardened_table) {
-        const int rco = generator_has_order_r(&tw);
+        const int rco = generator_has_order_r(g, &tw);
         if (rco) return rco;
     }
     if (twisted) *twisted = tw;
-    uint32_t **slot = hardened_table ? &g_gtab_ct[dev] : (tw ? &g_gtab_tw[dev] : &g_gtab[dev]);
+    uint32_t **slot = hardened_table ? &g->gtab_ct[dev] : (tw ? &g->gtab_tw[dev] : &g->gtab[dev]);
     if (!*slot) {
-        const int rc = hardened_table ? build_gtab(FBCT_ROWS, FBCT_ENTRIES, FBCT_WBITS, slot)
-                                      : build_gtab(FB_ROWS, FB_TAB_ENTRIES, FB_WBITS, slot, tw);
+        const int rc = hardened_table ? build_gtab(g->xy, FBCT_ROWS, FBCT_ENTRIES, FBCT_WBITS, slot)
+                                      : build_gtab(g->xy, FB_ROWS, FB_TAB_ENTRIES, FB_WBITS, slot, tw);
         if (rc) return rc;
     }
     *out = *slot;
@@ -628,6 +650,7 @@ static int fb_launch(size_t n, const uint8_t *scalars, uint8_t *out, hipStream_t
     if (!n) return CAPY_OK;
     const bool ct = harden(secret);
     const bool small = n <= (ct ? (CAPY_ED448_FBCT_MFMA ? wave_max_items() * 7 / 16 : wave_max_items() * 3 / 4) : wave_max_items() * 5 / 16);
+    t_last_fb_kernel = (ct ? 2 : 1) + (small ? 16 : 0);
     if (ct && !small && CAPY_ED448_FBCT_MFMA) {
         // every byte of the window's table row is read per window by every wave and the wanted entry is picked by a
         // one-hot matrix product on the matrix cores: no address depends on the scalar (ed448_fb7.h)
@@ -732,7 +755,7 @@ static int sign_dev(int d, size_t n, const KeyView &pw, const MsgView &m, uint8_
     // k = 4 * KMAC(s_bytes, msg, 448, "N")  (`*` taken as arithmetic mod r)
     rc = kmac_launch(d, n, fixed_keys(s_be, 56, 56), m, true, (const uint8_t *)"N", 1, 0, k_be, 56, 56, nullptr, st);
     if (rc) return rc;
-    const int star = g_scalar_star.load();
+    const int star = scalar_star_mode();
     hipLaunchKernelGGL(sc_star4_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, (uint64_t)n, k_be, k_be, star);
     CAPY_HIP(hipGetLastError());
     rc = fb_launch(n, k_be, U, st, true);  // U = k*G, affine; k is the secret nonce
@@ -775,10 +798,8 @@ static hipStream_t side_stream()
 {
     thread_local SideStreams holder;
     hipStream_t *streams = holder.s;
-    static const bool off = [] {  // CAPY_HOST_OVERLAP=0: everything on the default stream (A/B: copy and kernels serialise)
-        const char *e = getenv("CAPY_HOST_OVERLAP");
-        return e && e[0] == '0';
-    }();
+    // CAPY_DEBUG=host_overlap=0: everything on the default stream (A/B: copy and kernels serialise)
+    static const bool off = debug_knob("host_overlap", 1) == 0;
     if (off) return nullptr;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
@@ -922,6 +943,15 @@ int capy_ed448_basemul_batch(size_t n, const uint8_t *scalars_be, uint8_t *out_x
     return down(out_xy, o, n * 112);
 }
 
+int capy_ed448_add_batch_dev(size_t n, const uint8_t *p_xy, const uint8_t *q_xy, uint8_t *out_xy, void *stream)
+{
+    if (!n) return CAPY_OK;
+    CAPY_REQUIRE(p_xy && q_xy && out_xy, "p / q / out");
+    hipLaunchKernelGGL(add_kernel, grid64(n), dim3(64), 0, (hipStream_t)stream, (uint64_t)n, p_xy, q_xy, out_xy);
+    CAPY_HIP(hipGetLastError());
+    return CAPY_OK;
+}
+
 int capy_ed448_add_batch(size_t n, const uint8_t *p_xy, const uint8_t *q_xy, uint8_t *out_xy)
 {
     if (!n) return CAPY_OK;
@@ -931,9 +961,7 @@ int capy_ed448_add_batch(size_t n, const uint8_t *p_xy, const uint8_t *q_xy, uin
     TRY(up(p, p_xy, n * 112));
     TRY(up(q, q_xy, n * 112));
     CAPY_HIP(o.alloc(n * 112));
-    hipLaunchKernelGGL(add_kernel, grid64(n), dim3(64), 0, nullptr, (uint64_t)n, p.as<uint8_t>(), q.as<uint8_t>(),
-                       o.as<uint8_t>());
-    CAPY_HIP(hipGetLastError());
+    TRY(capy_ed448_add_batch_dev(n, p.as<uint8_t>(), q.as<uint8_t>(), o.as<uint8_t>(), nullptr));
     return down(out_xy, o, n * 112);
 }
 
@@ -945,8 +973,18 @@ int capy_ed448_set_wave_max(long max_items)
 
 int capy_ed448_set_hardened(int mode)
 {
-    if (mode < 0 || mode > 3) return fail(CAPY_ERR_ARG, "mode must be 0 (off), 1 (secret scalars of the protocol calls, default), 2 or 3");
+    // 2 and 3 were "raw calls only" / "everything" in the r03 library, where 1 had come to mean "protocol calls only" after
+    // meaning "everything" in r02: the ambiguous values are refused rather than reinterpreted
+    if (mode != CAPY_HARDEN_OFF && mode != CAPY_HARDEN_ALL && mode != CAPY_HARDEN_PROTOCOL)
+        return fail(CAPY_ERR_ARG, "mode must be CAPY_HARDEN_OFF (0), CAPY_HARDEN_ALL (1) or CAPY_HARDEN_PROTOCOL (4, the default)");
     g_hardened.store(mode);
+    return CAPY_OK;
+}
+
+int capy_debug_last_curve_kernel(int *variable_base, int *fixed_base)
+{
+    if (variable_base) *variable_base = t_last_vb_kernel;
+    if (fixed_base) *fixed_base = t_last_fb_kernel;
     return CAPY_OK;
 }
 
@@ -984,33 +1022,49 @@ static bool pt_has_order_r(const uint8_t *xy)
     return fe_is_zero(q.X) && fe_is_zero(fe_sub(q.Y, q.Z));
 }
 
-int capy_ed448_set_generator(const uint8_t *xy)
+static int check_generator(const uint8_t *xy)
 {
-    if (xy && !pt_validate_bytes(xy)) return fail(CAPY_ERR_ARG, "generator is not a canonical point of the curve");
-    if (xy && pt_order_divides_4(xy)) return fail(CAPY_ERR_ARG, "generator has order 1, 2 or 4");
+    if (!pt_validate_bytes(xy)) return fail(CAPY_ERR_ARG, "generator is not a canonical point of the curve");
+    if (pt_order_divides_4(xy)) return fail(CAPY_ERR_ARG, "generator has order 1, 2 or 4");
     // the fixed-base tables are built from scalars reduced mod r (and, on the twisted curve, from [1/4 mod r] G): both
     // need a generator of the prime order r, as ExtendedPoint::generator() of any Ed448 library is
-    if (xy && !pt_has_order_r(xy)) return fail(CAPY_ERR_ARG, "generator does not have the prime order r (cofactor component)");
+    if (!pt_has_order_r(xy)) return fail(CAPY_ERR_ARG, "generator does not have the prime order r (cofactor component)");
+    return CAPY_OK;
+}
+
+int capy_ed448_set_generator(const uint8_t *xy)
+{
+    if (xy) TRY(check_generator(xy));
     std::lock_guard<std::mutex> lk(g_gtab_mu);
     const uint8_t *want = xy ? xy : G_XY;
-    if (memcmp(current_generator(), want, 112) == 0) return CAPY_OK;
-    // Every device's table is rebuilt lazily from the new point.  The old tables are RETIRED, not freed: a concurrent
-    // call that took the table pointer before this one (ensure_gtab releases the mutex before it launches) may still
-    // have kernels in flight on it.  A retired table (15 MB) stays allocated until the process ends; the generator is
-    // meant to be set once, at start-up.
-    static std::vector<uint32_t *> retired;
-    for (int dev = 0; dev < 64; dev++) {
-        if (g_gtab[dev]) retired.push_back(g_gtab[dev]);
-        if (g_gtab_ct[dev]) retired.push_back(g_gtab_ct[dev]);
-        if (g_gtab7[dev]) retired.push_back(reinterpret_cast<uint32_t *>(g_gtab7[dev]));
-        if (g_gtab_tw[dev]) retired.push_back(g_gtab_tw[dev]);
-        g_gtab[dev] = nullptr;
-        g_gtab_ct[dev] = nullptr;
-        g_gtab7[dev] = nullptr;
-        g_gtab_tw[dev] = nullptr;
-    }
-    memcpy(g_gen_xy, want, 112);
-    g_gen_order_r = -1;
+    GenCtx *old = gen_ctx(0);
+    if (memcmp(old->xy, want, 112) == 0) return CAPY_OK;
+    // A fresh context takes handle 0; its tables are built lazily per device.  The old context is RETIRED, not freed: a
+    // concurrent call that took a table pointer before this one (ensure_gtab releases the mutex before it launches) may
+    // still have kernels in flight on it.  A retired set of tables (15 MB per device used) stays allocated until the
+    // process ends; the process generator is meant to be set once, at start-up.
+    GenCtx *fresh = new GenCtx();
+    memcpy(fresh->xy, want, 112);
+    g_gens[0] = fresh;
+    return CAPY_OK;
+}
+
+int capy_ed448_generator_create(const uint8_t *xy, int *handle)
+{
+    if (!xy || !handle) return fail(CAPY_ERR_ARG, "null argument");
+    TRY(check_generator(xy));
+    std::lock_guard<std::mutex> lk(g_gtab_mu);
+    (void)gen_ctx(0);
+    for (size_t i = 1; i < g_gens.size(); i++)
+        if (memcmp(g_gens[i]->xy, xy, 112) == 0) {
+            *handle = (int)i;
+            return CAPY_OK;
+        }
+    if (g_gens.size() >= 64) return fail(CAPY_ERR_ARG, "too many generators (64)");
+    GenCtx *c = new GenCtx();
+    memcpy(c->xy, xy, 112);
+    g_gens.push_back(c);
+    *handle = (int)g_gens.size() - 1;
     return CAPY_OK;
 }
 
@@ -1033,6 +1087,13 @@ int capy_ed448_validate_batch(size_t n, const uint8_t *points_xy, int32_t *statu
     CAPY_HIP(st.alloc(n * 4));
     TRY(capy_ed448_validate_batch_dev(n, p.as<uint8_t>(), st.as<int32_t>(), nullptr));
     return down(status, st, n * 4);
+}
+
+int capy_ed448_double_scalarmul_batch_dev(size_t n, const uint8_t *a_be, const uint8_t *b_be, const uint8_t *points_xy,
+                                          uint8_t *out_xy, void *stream)
+{
+    if (n) CAPY_REQUIRE(a_be && b_be && points_xy && out_xy, "a / b / points / out");
+    return dsm_launch(n, a_be, b_be, points_xy, out_xy, (hipStream_t)stream);
 }
 
 int capy_ed448_double_scalarmul_batch(size_t n, const uint8_t *a_be, const uint8_t *b_be, const uint8_t *points_xy,
@@ -1205,6 +1266,7 @@ int capy_key_encrypt_batch(int d, size_t n, const uint8_t *pub_xy, const uint8_t
     PackedBatch b;
     LateMsgs late = {&b, n, msgs, offsets};
     DevBuf pk, kr, dz, dt;
+    kr.secret = true;  // the ephemeral scalars k: zeroed before the staging block (device cache or pinned arena) is reused
     TRY(up(pk, pub_xy, n * 112));
     TRY(up(kr, k_rand, n * 56));
     CAPY_HIP(dz.alloc(n * 112));
@@ -1228,6 +1290,7 @@ int capy_key_decrypt_batch(int d, size_t n, const uint8_t *pws, size_t pw_len, c
                                                   pw_offsets ? pw_offsets + first : nullptr, z_xy + first * 112, msgs,
                                                   offsets + first, tags + first * 56, status + first));
     PackedBatch b;
+    b.msgs.secret = true;  // holds the decrypted plaintext: zeroed before the staging block is reused
     LateMsgs late = {&b, n, msgs, offsets};
     PackedKeys pw;
     TRY(pw.upload(n, pws, pw_len, pw_offsets));
@@ -1241,6 +1304,95 @@ int capy_key_decrypt_batch(int d, size_t n, const uint8_t *pws, size_t pw_len, c
     CAPY_HIP(hipStreamSynchronize(side));
     TRY(b.download(n, msgs, offsets));
     return down(status, st, n * 4);
+}
+
+// ---------------------------------------------------------------- the same calls with per-call options (capy_call_options)
+#define CAPY_WITH_OPTIONS(opt, call)         \
+    do {                                     \
+        CallOpts _o;                         \
+        TRY(parse_call_options((opt), _o));  \
+        OptScope _scope(_o);                 \
+        return (call);                       \
+    } while (0)
+#define CAPY_OPT_STREAM(opt) ((opt) ? (opt)->stream : nullptr)
+
+int capy_ed448_scalarmul_batch_ex(size_t n, const uint8_t *scalars_be, const uint8_t *points_xy, uint8_t *out_xy,
+                                  const capy_call_options *opt)
+{
+    CAPY_WITH_OPTIONS(opt, capy_ed448_scalarmul_batch(n, scalars_be, points_xy, out_xy));
+}
+int capy_ed448_scalarmul_batch_dev_ex(size_t n, const uint8_t *scalars_be, const uint8_t *points_xy, uint8_t *out_xy,
+                                      const capy_call_options *opt)
+{
+    CAPY_WITH_OPTIONS(opt, capy_ed448_scalarmul_batch_dev(n, scalars_be, points_xy, out_xy, CAPY_OPT_STREAM(opt)));
+}
+int capy_ed448_basemul_batch_ex(size_t n, const uint8_t *scalars_be, uint8_t *out_xy, const capy_call_options *opt)
+{
+    CAPY_WITH_OPTIONS(opt, capy_ed448_basemul_batch(n, scalars_be, out_xy));
+}
+int capy_ed448_basemul_batch_dev_ex(size_t n, const uint8_t *scalars_be, uint8_t *out_xy, const capy_call_options *opt)
+{
+    CAPY_WITH_OPTIONS(opt, capy_ed448_basemul_batch_dev(n, scalars_be, out_xy, CAPY_OPT_STREAM(opt)));
+}
+int capy_keypair_batch_ex(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint64_t *pw_offsets, uint8_t *pub_xy,
+                          const capy_call_options *opt)
+{
+    CAPY_WITH_OPTIONS(opt, capy_keypair_batch(d, n, pws, pw_len, pw_offsets, pub_xy));
+}
+int capy_schnorr_sign_batch_ex(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint64_t *pw_offsets,
+                               const uint8_t *msgs, const uint64_t *offsets, uint8_t *h, uint8_t *z_be,
+                               const capy_call_options *opt)
+{
+    CAPY_WITH_OPTIONS(opt, capy_schnorr_sign_batch(d, n, pws, pw_len, pw_offsets, msgs, offsets, h, z_be));
+}
+int capy_schnorr_verify_batch_ex(int d, size_t n, const uint8_t *pub_xy, const uint8_t *msgs, const uint64_t *offsets,
+                                 const uint8_t *h, const uint8_t *z_be, int32_t *status, const capy_call_options *opt)
+{
+    CAPY_WITH_OPTIONS(opt, capy_schnorr_verify_batch(d, n, pub_xy, msgs, offsets, h, z_be, status));
+}
+int capy_key_encrypt_batch_ex(int d, size_t n, const uint8_t *pub_xy, const uint8_t *k_rand, uint8_t *msgs,
+                              const uint64_t *offsets, uint8_t *z_xy, uint8_t *tags, const capy_call_options *opt)
+{
+    CAPY_WITH_OPTIONS(opt, capy_key_encrypt_batch(d, n, pub_xy, k_rand, msgs, offsets, z_xy, tags));
+}
+int capy_key_decrypt_batch_ex(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint64_t *pw_offsets,
+                              const uint8_t *z_xy, uint8_t *msgs, const uint64_t *offsets, const uint8_t *tags,
+                              int32_t *status, const capy_call_options *opt)
+{
+    CAPY_WITH_OPTIONS(opt, capy_key_decrypt_batch(d, n, pws, pw_len, pw_offsets, z_xy, msgs, offsets, tags, status));
+}
+int capy_keypair_batch_dev_ex(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint64_t *pw_offsets,
+                              uint8_t *pub_xy, const capy_call_options *opt)
+{
+    CAPY_WITH_OPTIONS(opt, capy_keypair_batch_dev(d, n, pws, pw_len, pw_offsets, pub_xy, CAPY_OPT_STREAM(opt)));
+}
+int capy_schnorr_sign_batch_dev_ex(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint64_t *pw_offsets,
+                                   const uint8_t *msgs, const uint64_t *offsets, uint64_t uniform_len, uint64_t msg_stride,
+                                   uint8_t *h, uint8_t *z_be, const capy_call_options *opt)
+{
+    CAPY_WITH_OPTIONS(opt, capy_schnorr_sign_batch_dev(d, n, pws, pw_len, pw_offsets, msgs, offsets, uniform_len, msg_stride, h, z_be,
+                                                       CAPY_OPT_STREAM(opt)));
+}
+int capy_schnorr_verify_batch_dev_ex(int d, size_t n, const uint8_t *pub_xy, const uint8_t *msgs, const uint64_t *offsets,
+                                     uint64_t uniform_len, uint64_t msg_stride, const uint8_t *h, const uint8_t *z_be,
+                                     int32_t *status, const capy_call_options *opt)
+{
+    CAPY_WITH_OPTIONS(opt, capy_schnorr_verify_batch_dev(d, n, pub_xy, msgs, offsets, uniform_len, msg_stride, h, z_be, status,
+                                                         CAPY_OPT_STREAM(opt)));
+}
+int capy_key_encrypt_batch_dev_ex(int d, size_t n, const uint8_t *pub_xy, const uint8_t *k_rand, uint8_t *msgs,
+                                  const uint64_t *offsets, uint64_t uniform_len, uint64_t msg_stride, uint8_t *z_xy,
+                                  uint8_t *tags, const capy_call_options *opt)
+{
+    CAPY_WITH_OPTIONS(opt, capy_key_encrypt_batch_dev(d, n, pub_xy, k_rand, msgs, offsets, uniform_len, msg_stride, z_xy, tags,
+                                                      CAPY_OPT_STREAM(opt)));
+}
+int capy_key_decrypt_batch_dev_ex(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint64_t *pw_offsets,
+                                  const uint8_t *z_xy, uint8_t *msgs, const uint64_t *offsets, uint64_t uniform_len,
+                                  uint64_t msg_stride, const uint8_t *tags, int32_t *status, const capy_call_options *opt)
+{
+    CAPY_WITH_OPTIONS(opt, capy_key_decrypt_batch_dev(d, n, pws, pw_len, pw_offsets, z_xy, msgs, offsets, uniform_len, msg_stride, tags,
+                                                      status, CAPY_OPT_STREAM(opt)));
 }
 
 }  // extern "C"

@@ -870,15 +870,19 @@ CAPY_HD inline Pt pt_add_affine_cached(const Pt &p, const Fe &x2, const Fe &y2, 
     return r;
 }
 
-// Doubling (dbl-2008-hwcd, a = 1).  E = 2XY is formed as ONE multiplication X * Y (r04), not as (X + Y)^2 - X^2 - Y^2:
-// a squaring is cheaper than a multiplication (237 against 310 VALU) but extracting the cross term from it costs a limb
-// sum, two limb-wise subtractions and a carry pass (129): 3 squarings + 4 multiplications (5 with T).
+// Doubling (dbl-2008-hwcd, a = 1): 4 squarings + 3 multiplications (4 with T).
+// CAPY_ED448_DBL_XY=1 forms E = 2XY as ONE multiplication X * Y instead of (X + Y)^2 - X^2 - Y^2 (3S + 4M): a squaring is
+// cheaper than a multiplication (237 against 310 VALU), but extracting the cross term from it costs a limb sum, two
+// limb-wise subtractions and a carry pass (129), so that form has 5 % FEWER instructions in the doubling loop (2036
+// against 2144) -- and 8 % MORE v_mad_u64_u32 (1104 against 1020), and runs at the same speed to within the noise of a
+// box (27.3 against 27.5 M/s, profiles/r04_ed448_fe_trim.txt): these kernels are bound by the ENERGY of their multiply-adds
+// (the clock follows the power limit), not by issue slots.  The default keeps the form with fewer multiply-adds.
 // pt_dbl_core leaves E and H to the caller: T3 = E H is only needed by an addition that follows, so a run of
 // doublings computes it once, after the last one (the optimiser used to sink that product out of the loop on its own;
 // with the pinned multiply-add chains of fe_mul it no longer does).
 // Bounds: A, B, C', XY are R (2^28 + 2^10); E, C, G <= 2^29 + 2^11; H <= 2^29.58; F reduced.
 #ifndef CAPY_ED448_DBL_XY
-#define CAPY_ED448_DBL_XY 1
+#define CAPY_ED448_DBL_XY 0
 #endif
 CAPY_HD inline void pt_dbl_core(Pt &r, Fe &E, Fe &H, const Pt &p)
 {

@@ -7,6 +7,7 @@
 #include <ctype.h>
 #include <condition_variable>
 #include <memory>
+#include <deque>
 #include <mutex>
 #include <thread>
 #include <sched.h>
@@ -28,6 +29,61 @@ int fail(int code, const std::string &msg)
 }
 
 // ------------------------------------------------------------------ multi-device sharding (see common.h)
+double debug_knob(const char *key, double dflt)
+{
+    static const std::vector<std::pair<std::string, double>> knobs = [] {
+        std::vector<std::pair<std::string, double>> v;
+        static const char *known[] = {"fused_max", "wide_max", "mixed_ratio", "uniform_waves", "ed448_pair", "ed448_wave_max",
+                                      "host_overlap", "host_arena", "worker_affinity"};
+        const char *e = getenv("CAPY_DEBUG");
+        std::string txt = e ? e : "";
+        size_t pos = 0;
+        while (pos < txt.size()) {
+            size_t end = txt.find(',', pos);
+            if (end == std::string::npos) end = txt.size();
+            const std::string item = txt.substr(pos, end - pos);
+            pos = end + 1;
+            const size_t eq = item.find('=');
+            if (item.empty()) continue;
+            const std::string k = item.substr(0, eq);
+            bool ok = false;
+            for (const char *n : known) ok = ok || k == n;
+            if (!ok || eq == std::string::npos) {
+                fprintf(stderr, "libcapyhip: CAPY_DEBUG: unknown or malformed item '%s' ignored\n", item.c_str());
+                continue;
+            }
+            v.emplace_back(k, atof(item.c_str() + eq + 1));
+        }
+        return v;
+    }();
+    for (const auto &kv : knobs)
+        if (kv.first == key) return kv.second;
+    return dflt;
+}
+
+CallOpts &thread_opts()
+{
+    static thread_local CallOpts o;
+    return o;
+}
+int parse_call_options(const capy_call_options *opt, CallOpts &out)
+{
+    out = thread_opts();  // nested calls inherit
+    if (!opt) return CAPY_OK;
+    if (opt->struct_size < sizeof(capy_call_options)) return fail(CAPY_ERR_ARG, "capy_call_options::struct_size is too small (use CAPY_CALL_OPTIONS_INIT)");
+    if (opt->hardened != CAPY_OPT_DEFAULT && opt->hardened != CAPY_HARDEN_OFF && opt->hardened != CAPY_HARDEN_ALL &&
+        opt->hardened != CAPY_HARDEN_PROTOCOL)
+        return fail(CAPY_ERR_ARG, "capy_call_options::hardened must be CAPY_OPT_DEFAULT or a CAPY_HARDEN_* value");
+    if (opt->scalar_star != CAPY_OPT_DEFAULT && (opt->scalar_star < 0 || opt->scalar_star > 2))
+        return fail(CAPY_ERR_ARG, "capy_call_options::scalar_star must be CAPY_OPT_DEFAULT, 0, 1 or 2");
+    if (opt->generator < 0) return fail(CAPY_ERR_ARG, "capy_call_options::generator must be a handle (0 = the process generator)");
+    if (opt->hardened != CAPY_OPT_DEFAULT) out.hardened = opt->hardened;
+    if (opt->scalar_star != CAPY_OPT_DEFAULT) out.scalar_star = opt->scalar_star;
+    out.generator = opt->generator;
+    out.stream = opt->stream;
+    return CAPY_OK;
+}
+
 static std::mutex g_dev_mu;
 static std::vector<int> g_dev_ids;  // empty: not configured
 // a worker of run_sharded never shards again (its body is the single-device form of the same entry point)
@@ -96,7 +152,7 @@ static bool parse_cpulist(const char *text, cpu_set_t *set)
 }
 static void pin_to_device_cpus(int device)
 {
-    if (getenv("CAPY_NO_WORKER_AFFINITY")) return;
+    if (debug_knob("worker_affinity", 1) == 0) return;
     char bdf[64] = {0};
     if (hipDeviceGetPCIBusId(bdf, sizeof bdf, device) != hipSuccess) {
         (void)hipGetLastError();
@@ -115,13 +171,33 @@ static void pin_to_device_cpus(int device)
     if (CPU_COUNT(&both) > 0) (void)sched_setaffinity(0, sizeof both, &both);
 }
 
+// completion flag of one submitted job; shared with the submitting thread, so it outlives a worker that is replaced
+struct Latch {
+    std::mutex mu;
+    std::condition_variable cv;
+    bool done = false;
+    void set()
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        done = true;
+        cv.notify_all();
+    }
+    void wait()
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return done; });
+    }
+};
 struct Worker {
     int device = 0;
     std::thread th;
     std::mutex mu;
     std::condition_variable cv;
-    std::function<void()> job;
-    bool has_job = false, done = false, quit = false;
+    // a FIFO per worker (r04): sharded calls from several host threads queue their shards and wait on their own
+    // latches, so the pool lock is held only while a call submits -- r03 held it for the whole call and serialised the
+    // callers, PCIe copies included
+    std::deque<std::pair<std::function<void()>, std::shared_ptr<Latch>>> q;
+    bool quit = false;
     void loop()
     {
         g_in_shard = true;  // a worker never shards again: its body is the single-device form of the entry point
@@ -130,30 +206,25 @@ struct Worker {
         pin_to_device_cpus(device);
         std::unique_lock<std::mutex> lk(mu);
         while (true) {
-            cv.wait(lk, [&] { return has_job || quit; });
-            if (quit) break;
+            cv.wait(lk, [&] { return !q.empty() || quit; });
+            if (q.empty()) break;  // quit, and every queued shard has run
+            auto item = std::move(q.front());
+            q.pop_front();
             lk.unlock();
-            job();
+            item.first();
+            item.second->set();
             lk.lock();
-            has_job = false;
-            done = true;
-            cv.notify_all();
         }
         lk.unlock();
         workspace_release();  // on this thread: its scratch pools and buffer cache (the list changed; the runtime is alive)
     }
-    void submit(std::function<void()> f)
+    std::shared_ptr<Latch> submit(std::function<void()> f)
     {
+        auto l = std::make_shared<Latch>();
         std::lock_guard<std::mutex> lk(mu);
-        job = std::move(f);
-        has_job = true;
-        done = false;
+        q.emplace_back(std::move(f), l);
         cv.notify_all();
-    }
-    void wait()
-    {
-        std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return done; });
+        return l;
     }
     void stop()
     {
@@ -166,12 +237,12 @@ struct Worker {
     }
 };
 struct WorkerPool {
-    std::mutex mu;  // one sharded call at a time
+    std::mutex mu;  // guards ids / workers; held while a call submits its shards, not while they run
     std::vector<int> ids;
     std::vector<std::unique_ptr<Worker>> workers;
     void reset(const std::vector<int> &want)
     {
-        for (auto &w : workers) w->stop();
+        for (auto &w : workers) w->stop();  // finishes what is queued first
         workers.clear();
         ids = want;
         for (int id : want) {
@@ -199,30 +270,47 @@ int run_sharded(const std::vector<int> &ids, size_t n, const uint64_t *byte_offs
                 const std::function<int(size_t, size_t)> &body)
 {
     const size_t world = ids.size();
-    std::lock_guard<std::mutex> pool_lock(g_pool.mu);
-    if (g_pool.ids != ids) g_pool.reset(ids);  // first call after capy_set_devices (or a changed list)
+    if (world == 1) {
+        // one device: on the calling thread, as a plain single-device call on that device (no worker, no lock)
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess) cur = -1;
+        if (cur != ids[0] && hipSetDevice(ids[0]) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(CAPY_ERR_HIP, "hipSetDevice(" + std::to_string(ids[0]) + ") failed");
+        }
+        g_in_shard = true;
+        const int rc = body(0, n);
+        g_in_shard = false;
+        if (cur >= 0 && cur != ids[0]) (void)hipSetDevice(cur);
+        return rc;
+    }
     const std::vector<size_t> b = shard_bounds(n, world, byte_offsets);
     std::vector<int> rcs(world, CAPY_OK);
     std::vector<std::string> errs(world);
-    std::vector<size_t> used;
-    for (size_t r = 0; r < world; r++) {
-        if (b[r + 1] <= b[r]) continue;
-        used.push_back(r);
-        g_pool.workers[r]->submit([&, r] {
-            int cur = -1;
-            if (hipGetDevice(&cur) != hipSuccess || cur != ids[r]) {
-                if (hipSetDevice(ids[r]) != hipSuccess) {
-                    (void)hipGetLastError();
-                    rcs[r] = CAPY_ERR_HIP;
-                    errs[r] = "hipSetDevice(" + std::to_string(ids[r]) + ") failed";
-                    return;
+    std::vector<std::shared_ptr<Latch>> latches;
+    const CallOpts opts = thread_opts();  // the caller's per-call options travel with its shards
+    {
+        std::lock_guard<std::mutex> pool_lock(g_pool.mu);
+        if (g_pool.ids != ids) g_pool.reset(ids);  // first call after capy_set_devices (or a changed list)
+        for (size_t r = 0; r < world; r++) {
+            if (b[r + 1] <= b[r]) continue;
+            latches.push_back(g_pool.workers[r]->submit([&, r] {
+                int cur = -1;
+                if (hipGetDevice(&cur) != hipSuccess || cur != ids[r]) {
+                    if (hipSetDevice(ids[r]) != hipSuccess) {
+                        (void)hipGetLastError();
+                        rcs[r] = CAPY_ERR_HIP;
+                        errs[r] = "hipSetDevice(" + std::to_string(ids[r]) + ") failed";
+                        return;
+                    }
                 }
-            }
-            rcs[r] = body(b[r], b[r + 1] - b[r]);
-            if (rcs[r]) errs[r] = g_err;
-        });
+                OptScope sc(opts);
+                rcs[r] = body(b[r], b[r + 1] - b[r]);
+                if (rcs[r]) errs[r] = g_err;
+            }));
+        }
     }
-    for (size_t r : used) g_pool.workers[r]->wait();
+    for (auto &l : latches) l->wait();
     for (size_t r = 0; r < world; r++)
         if (rcs[r]) return fail(rcs[r], "device " + std::to_string(ids[r]) + ": " + errs[r]);
     return CAPY_OK;
@@ -370,8 +458,7 @@ void *arena_take(size_t bytes, void **host)
     HostArena &a = t_arena;
     if (!a.tried) {
         a.tried = true;
-        const char *e = getenv("CAPY_HOST_ARENA");
-        if (!(e && e[0] == '0')) {
+        if (debug_knob("host_arena", 1) != 0) {
             void *h = nullptr, *d = nullptr;
             if (hipHostMalloc(&h, HostArena::SIZE, hipHostMallocMapped | hipHostMallocPortable) == hipSuccess &&
                 hipHostGetDevicePointer(&d, h, 0) == hipSuccess) {
@@ -597,11 +684,10 @@ static std::atomic<bool> g_fused_enabled{true};
 // 16 items per wave x one wave per SIMD with the plain round; beyond that the blocked round at raised priority pairs the
 // waves of a SIMD (r03, profiles/r03_chipfull.txt: 32 768 x 5 MiB 353 -> 451 GiB/s, 49 152 x 4 MiB 405 -> 472, 98 304 x
 // 1 MiB 432 -> 515 against the two-pass form; at 131 072 x 1 MiB the two passes win again, 541 vs 527).
-// CAPY_FUSED_MAX overrides for A/B.
+// CAPY_DEBUG=fused_max=N overrides for A/B.
 static const size_t FUSED_ONE_WAVE_ITEMS = 16384;
 static const size_t FUSED_MAX_ITEMS = [] {
-    const char *e = getenv("CAPY_FUSED_MAX");
-    const long v = e ? atol(e) : 98304;
+    const double v = debug_knob("fused_max", 98304);
     return (size_t)(v > 0 ? v : 98304);
 }();
 // Kernel choice by batch size relative to the device's SIMD count S (1024 on MI355X; measured crossovers, profiles/):
@@ -616,7 +702,7 @@ static std::atomic<bool> g_mixed_enabled{true};
 // largest batch that takes the one-wave-per-item encrypt kernel: one wave per SIMD (the digest kernel holds two items per
 // wave, so twice as many).  Measured r03 with the DPP theta (profiles/r03_wide_round_probe.txt): at one wave per SIMD the
 // wave-per-item kernels still win 1.2-1.3x (1024 x 5 MiB encrypt 0.163 s vs 0.211, 2048 x 5 MiB digest 0.164 vs 0.198),
-// at 1.5 waves per SIMD they lose (0.88x).  CAPY_WIDE_MAX overrides
+// at 1.5 waves per SIMD they lose (0.88x).  CAPY_DEBUG=wide_max=N overrides
 static size_t wide_max_items();
 
 // SIMDs of the current device (4 per CU)
@@ -637,21 +723,17 @@ static unsigned device_simds()
 
 static size_t wide_max_items()
 {
-    static const long forced = [] {
-        const char *e = getenv("CAPY_WIDE_MAX");
-        return e ? atol(e) : -1L;
-    }();
+    static const long forced = (long)debug_knob("wide_max", -1);
     return forced >= 0 ? (size_t)forced : device_simds();
 }
 
 // speed of the two-lane form relative to the one-lane form, per sponge, when both share the chip at one wave per SIMD.
 // Re-measured with the per-lane-load kernels for P = 2..6 phases (profiles/r02_mixed_ratio_sweep.txt): best at 1.46-1.47
-// for every P (+1.8 % over the 1.50 of round 1 at the headline batch); CAPY_MIXED_RATIO overrides
+// for every P (+1.8 % over the 1.50 of round 1 at the headline batch); CAPY_DEBUG=mixed_ratio=R overrides
 static double mixed_ratio()
 {
     static const double r = [] {
-        const char *e = getenv("CAPY_MIXED_RATIO");
-        double v = e ? atof(e) : 0.0;
+        const double v = debug_knob("mixed_ratio", 0.0);
         return (v >= 1.0 && v <= 2.0) ? v : 1.47;
     }();
     return r;
@@ -739,12 +821,11 @@ static int try_launch_mixed(int rw, const SpongeParams &p, bool forced, hipStrea
 
 // which kernel launch_sponge() picks: 1 one-lane latency-tuned, 2 two-lane, 3 rotating schedule, 4 one-lane issue-tuned,
 // 5 wave-quantisation split, 6 wave-per-item digest, 7 uniform-framing kernel
-// occupancy cap of the uniform-framing kernel in waves per SIMD (0: none, four fit; CAPY_UNIFORM_WAVES = 1..4 for A/B)
+// occupancy cap of the uniform-framing kernel in waves per SIMD (0: none, four fit; CAPY_DEBUG=uniform_waves=1..4 for A/B)
 static int uniform_waves()
 {
     static const int w = [] {
-        const char *e = getenv("CAPY_UNIFORM_WAVES");
-        const int v = e ? atoi(e) : 0;
+        const int v = (int)debug_knob("uniform_waves", 0);
         return (v >= 1 && v <= 4) ? v : 0;
     }();
     return w;
@@ -949,6 +1030,8 @@ int kmac_launch(int d, size_t n, const KeyView &kv, const MsgView &m,
 {
     if (!valid_d(d)) return fail(CAPY_ERR_UNSUPPORTED_SECPARAM, "unsupported security parameter");
     if (kv.key_len > CAPY_MAX_KEY_LEN) return fail(CAPY_ERR_ARG, "key too long");
+    // the kernels count output bytes in 32 bits (the reference takes l: usize, shake_functions.rs:79): refuse, never truncate
+    if (out_len > CAPY_MAX_OUT_LEN) return fail(CAPY_ERR_ARG, "output longer than 2^32 - 1 bytes per item (l_bits >= 2^35)");
     Framing f = cshake_framing(d);
     SpongeParams p;
     memset(&p, 0, sizeof p);
@@ -1007,6 +1090,7 @@ static int cshake_launch(int d, size_t n, const MsgView &m, size_t l_bits, const
                          const uint8_t *cs, size_t cs_len, uint8_t *outs, uint64_t out_stride, hipStream_t s,
                          bool body_has_trailer = false)
 {
+    if (l_bits / 8 > CAPY_MAX_OUT_LEN) return fail(CAPY_ERR_ARG, "output longer than 2^32 - 1 bytes per item (l_bits >= 2^35)");
     if (!valid_d(d)) return fail(CAPY_ERR_UNSUPPORTED_SECPARAM, "unsupported security parameter");
     if (fn_len == 0 && cs_len == 0 && !body_has_trailer)
         return fail(CAPY_ERR_UNSUPPORTED,
@@ -1605,6 +1689,7 @@ int capy_sha3_batch(int d, size_t n, const uint8_t *msgs, const uint64_t *offset
 int capy_cshake_batch(int d, size_t n, const uint8_t *xs, const uint64_t *offsets, size_t l_bits,
                       const uint8_t *fn_name, size_t fn_len, const uint8_t *custom, size_t custom_len, uint8_t *outs)
 {
+    if (l_bits / 8 > CAPY_MAX_OUT_LEN) return fail(CAPY_ERR_ARG, "output longer than 2^32 - 1 bytes per item (l_bits >= 2^35)");
     if (!valid_d(d)) return fail(CAPY_ERR_UNSUPPORTED_SECPARAM, "unsupported security parameter");
     if (n == 0) return CAPY_OK;
     if (!offsets || !outs) return fail(CAPY_ERR_ARG, "null argument");
@@ -1656,6 +1741,7 @@ int capy_cshake_batch_dev(int d, size_t n, const uint8_t *xs, const uint64_t *of
                           uint64_t msg_stride, size_t l_bits, const uint8_t *fn_name, size_t fn_len,
                           const uint8_t *custom, size_t custom_len, uint8_t *outs, uint64_t out_stride, void *stream)
 {
+    if (l_bits / 8 > CAPY_MAX_OUT_LEN) return fail(CAPY_ERR_ARG, "output longer than 2^32 - 1 bytes per item (l_bits >= 2^35)");
     if (n && !outs) return fail(CAPY_ERR_ARG, "null argument");
     if (n) CAPY_REQUIRE(msgs_ok(xs, offsets, uniform_len), "xs");
     if (out_stride < l_bits / 8) return fail(CAPY_ERR_ARG, "out_stride shorter than the output");
@@ -1668,6 +1754,7 @@ int capy_kmac_xof_batch_dev(int d, size_t n, const uint8_t *keys, size_t key_len
                             uint64_t msg_stride, size_t l_bits, const uint8_t *custom, size_t custom_len, uint8_t *outs,
                             uint64_t out_stride, void *stream)
 {
+    if (l_bits / 8 > CAPY_MAX_OUT_LEN) return fail(CAPY_ERR_ARG, "output longer than 2^32 - 1 bytes per item (l_bits >= 2^35)");
     if (n) {
         CAPY_REQUIRE(outs, "outs");
         CAPY_REQUIRE(out_stride >= l_bits / 8, "out_stride shorter than the output");
@@ -1684,6 +1771,7 @@ int capy_kmac_xof_batch(int d, size_t n, const uint8_t *keys, size_t key_len, co
                         const uint8_t *xs, const uint64_t *offsets, size_t l_bits, const uint8_t *custom, size_t custom_len,
                         uint8_t *outs)
 {
+    if (l_bits / 8 > CAPY_MAX_OUT_LEN) return fail(CAPY_ERR_ARG, "output longer than 2^32 - 1 bytes per item (l_bits >= 2^35)");
     if (!valid_d(d)) return fail(CAPY_ERR_UNSUPPORTED_SECPARAM, "unsupported security parameter");
     if (n == 0) return CAPY_OK;
     if (!outs) return fail(CAPY_ERR_ARG, "null argument");
@@ -1759,6 +1847,7 @@ static int sha3_crypt_host(bool encrypt, int d, size_t n, const uint8_t *pws, si
                                pw_offsets ? pw_offsets + first : nullptr, zs + first * 512, msgs, offsets + first,
                                tags + first * 64, status ? status + first : nullptr, ke_custom, ka_custom));
     PackedBatch b;
+    b.msgs.secret = !encrypt;  // decryption leaves plaintext in the staging block: zeroed before it is reused
     int rc = b.upload(n, msgs, offsets);
     if (rc) return rc;
     PackedKeys dpw;
@@ -1809,6 +1898,32 @@ int capy_kem_sponge_decrypt_batch(int d, size_t n, const uint8_t *secrets, size_
     if (!status) return fail(CAPY_ERR_ARG, "null status");
     return sha3_crypt_host(false, d, n, secrets, secret_len, nullptr, zs, msgs, offsets, const_cast<uint8_t *>(tags),
                            status, "KEMKE", "KEMKA");
+}
+
+int capy_kem_sponge_encrypt_batch_dev(int d, size_t n, const uint8_t *secrets, size_t secret_len, const uint8_t *zs,
+                                      uint8_t *msgs, const uint64_t *offsets, uint64_t uniform_len, uint64_t msg_stride,
+                                      uint8_t *tags, void *stream)
+{
+    if (n) {
+        CAPY_REQUIRE(zs && tags, "zs / tags");
+        CAPY_REQUIRE(keys_ok(secrets, secret_len, nullptr), "secrets");
+        CAPY_REQUIRE(msgs_ok(msgs, offsets, uniform_len), "msgs");
+    }
+    return sha3_crypt_dev(true, d, n, dev_keys(secrets, secret_len, nullptr), 0, zs, view_dev(msgs, offsets, uniform_len, msg_stride),
+                          tags, nullptr, (hipStream_t)stream, "KEMKE", "KEMKA");
+}
+
+int capy_kem_sponge_decrypt_batch_dev(int d, size_t n, const uint8_t *secrets, size_t secret_len, const uint8_t *zs,
+                                      uint8_t *msgs, const uint64_t *offsets, uint64_t uniform_len, uint64_t msg_stride,
+                                      const uint8_t *tags, int32_t *status, void *stream)
+{
+    if (n) {
+        CAPY_REQUIRE(zs && tags && status, "zs / tags / status");
+        CAPY_REQUIRE(keys_ok(secrets, secret_len, nullptr), "secrets");
+        CAPY_REQUIRE(msgs_ok(msgs, offsets, uniform_len), "msgs");
+    }
+    return sha3_crypt_dev(false, d, n, dev_keys(secrets, secret_len, nullptr), 0, zs, view_dev(msgs, offsets, uniform_len, msg_stride),
+                          const_cast<uint8_t *>(tags), status, (hipStream_t)stream, "KEMKE", "KEMKA");
 }
 
 // ---------------------------------------------------------------- measurement helpers

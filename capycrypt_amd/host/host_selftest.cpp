@@ -163,16 +163,19 @@ int main()
         for (size_t i = 0; i < ok.size(); i++) EXPECT(ok[i]);
         EXPECT(capy_set_devices(nullptr, 0) == CAPY_OK);
     }
-    // hardened mode (constant-address table lookups): same key pair, same signature
+    // hardened mode (constant-address table lookups): indexed kernels (CAPY_HARDEN_OFF) against constant-address lookups for
+    // every multiplication (CAPY_HARDEN_ALL) give the same key pair and the same signature; the default comes back after
     {
         Bytes pw = get_random_bytes(40);
         Message a(get_random_bytes(5000)), b(a.msg);
+        EXPECT(capy_ed448_set_hardened(CAPY_HARDEN_OFF) == CAPY_OK);
         KeyPair k1 = KeyPair::new_(pw, "k", SecParam::D256);
         a.sign(k1, SecParam::D256);
-        EXPECT(capy_ed448_set_hardened(1) == CAPY_OK);
+        EXPECT(capy_ed448_set_hardened(CAPY_HARDEN_ALL) == CAPY_OK);
         KeyPair k2 = KeyPair::new_(pw, "k", SecParam::D256);
         b.sign(k2, SecParam::D256);
-        EXPECT(capy_ed448_set_hardened(0) == CAPY_OK);
+        EXPECT(capy_ed448_set_hardened(2) == CAPY_ERR_ARG && capy_ed448_set_hardened(3) == CAPY_ERR_ARG);  // r03's values: refused
+        EXPECT(capy_ed448_set_hardened(CAPY_HARDEN_PROTOCOL) == CAPY_OK);
         EXPECT(k1.pub_key == k2.pub_key && a.sig->h == b.sig->h && a.sig->z == b.sig->z);
         b.verify(k1.pub_key);
     }

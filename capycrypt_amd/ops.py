@@ -189,13 +189,13 @@ def ed448_set_scalar_star(mode):
     L.check(L.lib().capy_ed448_set_scalar_star(int(mode)))
 
 
+HARDEN_OFF, HARDEN_ALL, HARDEN_PROTOCOL = L.CAPY_HARDEN_OFF, L.CAPY_HARDEN_ALL, L.CAPY_HARDEN_PROTOCOL
+
+
 def ed448_set_hardened(mode):
-    """Constant-address table lookups (include/capyhip.h: capy_ed448_set_hardened): 0 off, 1 secret scalars of the
-    protocol calls (the default), 3 every scalar multiplication incl. the raw calls; True means 3, False 0."""
-    if mode is True:
-        mode = 3
-    elif mode is False:
-        mode = 0
+    """Constant-address table lookups (include/capyhip.h: capy_ed448_set_hardened), process-wide default: HARDEN_OFF,
+    HARDEN_PROTOCOL (the default: secret scalars of the protocol calls) or HARDEN_ALL (raw scalarmul / basemul calls too).
+    A single call chooses for itself with options=CallOptions(hardened=...) (the *_ex entry points)."""
     L.check(L.lib().capy_ed448_set_hardened(int(mode)))
 
 

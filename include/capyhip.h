@@ -20,12 +20,17 @@
  *   return       0 = ok, <0 = CAPY_ERR_*; capy_last_error() gives the text (thread local)
  *   host forms   (no _dev suffix) take and return HOST buffers and block until the results are there.  Buffers of up to
  *                1 MiB go through a per-thread arena of pinned, device-mapped host memory (no copy calls: the kernels
- *                read and write it directly; CAPY_HOST_ARENA=0 switches it off), larger ones through cached staging
+ *                read and write it directly; CAPY_DEBUG=host_arena=0 switches it off), larger ones through cached staging
  *                blocks on the device.
  *   *_dev        same operation on buffers already resident in device memory, enqueued on `stream`
  *                (a hipStream_t passed as void*; NULL = the CALLING THREAD's default stream: the library is built with
  *                -fgpu-default-stream=per-thread since r03, so that host threads -- the library's own per-device workers
- *                among them -- do not serialise on one legacy stream), no host synchronisation and no device
+ *                among them -- do not serialise on one legacy stream.  NOTE for callers that hold a LEGACY default
+ *                stream, e.g. torch.cuda.current_stream().cuda_stream == 0 for torch's default stream: handle 0 passed
+ *                here means hipStreamPerThread, not the legacy stream.  Work on the two is still ordered by the
+ *                legacy stream's implicit synchronisation with every blocking stream, but not under stream capture
+ *                and not against work the caller put on a NON-blocking stream: pass that stream's handle then),
+ *                no host synchronisation and no device
  *                copy from host memory: internal scratch is pooled per (host thread, device, stream), grows by
  *                allocating (never by freeing) and is returned by capy_release_workspace(); secret intermediates
  *                in it (z||pw, ke||ka, s, k, the ECDH point) are zeroed on the stream at the end of the call.
@@ -56,6 +61,27 @@ extern "C" {
 #define CAPY_ITEM_OK 0
 #define CAPY_ITEM_FAIL 1 /* SHA3DecryptionFailure / KeyDecryptionError / SignatureVerificationFailure */
 
+/* Constant-address table lookups for Ed448 scalar multiplications (see capy_ed448_set_hardened).  The values are fixed:
+ * 1 meant "every multiplication" in the r02 library and keeps that meaning; 2 and 3 (r03 only) are refused. */
+#define CAPY_HARDEN_OFF 0      /* indexed kernels everywhere (benchmarks; single-tenant devices) */
+#define CAPY_HARDEN_ALL 1      /* every scalar multiplication, the raw scalarmul / basemul calls included */
+#define CAPY_HARDEN_PROTOCOL 4 /* DEFAULT: the multiplications by secret scalars inside the protocol calls */
+#define CAPY_OPT_DEFAULT (-1)
+
+/* Per-call options (r04): what the process-wide setters capy_ed448_set_hardened / _set_scalar_star / _set_generator fix
+ * for everybody, a single call can choose for itself through the *_ex entry points -- two host threads can then hold
+ * different modes at the same time.  Fields left at CAPY_OPT_DEFAULT / 0 / NULL take the process-wide setting.
+ * Initialise with CAPY_CALL_OPTIONS_INIT (struct_size lets the struct grow). */
+typedef struct capy_call_options {
+    uint32_t struct_size; /* sizeof(capy_call_options) */
+    int32_t hardened;     /* CAPY_HARDEN_* or CAPY_OPT_DEFAULT */
+    int32_t scalar_star;  /* 0, 1, 2 (capy_ed448_set_scalar_star) or CAPY_OPT_DEFAULT */
+    int32_t generator;    /* handle from capy_ed448_generator_create; 0 = the process generator */
+    void *stream;         /* *_dev_ex forms: the hipStream_t to enqueue on (NULL = the calling thread's default stream);
+                             ignored by the host-buffer forms */
+} capy_call_options;
+#define CAPY_CALL_OPTIONS_INIT {(uint32_t)sizeof(capy_call_options), CAPY_OPT_DEFAULT, CAPY_OPT_DEFAULT, 0, NULL}
+
 const char *capy_last_error(void);
 const char *capy_version(void);
 int capy_device_count(void);
@@ -84,6 +110,9 @@ int capy_release_workspace(void);
  * scalars, nonces, shared points, derived keys, z || pw) are non-zero now.  Synchronises `stream`.  Must be 0 once the
  * call has returned and the stream is idle. */
 int capy_debug_secret_scratch_nonzero(void *stream, uint64_t *nonzero_bytes);
+/* Test hook: which kernel family the calling thread's last variable-base / fixed-base launch took: 1 indexed lookups,
+ * 2 constant-address lookups, + 16 for the one-item-per-wave kernels of small batches; 0 = none yet. */
+int capy_debug_last_curve_kernel(int *variable_base, int *fixed_base);
 
 /* ------------------------------------------------------------------ sponge (src/sha3) */
 
@@ -147,6 +176,13 @@ int capy_kem_sponge_encrypt_batch(int d, size_t n, const uint8_t *secrets, size_
                                   uint8_t *msgs, const uint64_t *offsets, uint8_t *tags);
 int capy_kem_sponge_decrypt_batch(int d, size_t n, const uint8_t *secrets, size_t secret_len, const uint8_t *zs,
                                   uint8_t *msgs, const uint64_t *offsets, const uint8_t *tags, int32_t *status);
+/* device forms (r04): secrets at secrets + i*secret_len; messages as in capy_sha3_encrypt_batch_dev */
+int capy_kem_sponge_encrypt_batch_dev(int d, size_t n, const uint8_t *secrets, size_t secret_len, const uint8_t *zs,
+                                      uint8_t *msgs, const uint64_t *offsets, uint64_t uniform_len, uint64_t msg_stride,
+                                      uint8_t *tags, void *stream);
+int capy_kem_sponge_decrypt_batch_dev(int d, size_t n, const uint8_t *secrets, size_t secret_len, const uint8_t *zs,
+                                      uint8_t *msgs, const uint64_t *offsets, uint64_t uniform_len, uint64_t msg_stride,
+                                      const uint8_t *tags, int32_t *status, void *stream);
 
 /* ------------------------------------------------------------------ Ed448 (tiny_ed448_goldilocks boundary) */
 
@@ -162,6 +198,10 @@ int capy_ed448_scalarmul_batch_dev(size_t n, const uint8_t *scalars_be, const ui
  * next use.  Calls already in flight finish on the old tables (retired, not freed); meant to be called once at start-up. */
 int capy_ed448_set_generator(const uint8_t *xy);
 int capy_ed448_get_generator(uint8_t *xy);
+/* Register a further generator (same checks) for calls that select it through capy_call_options::generator; its
+ * fixed-base tables are built per device on first use.  The same point registered twice returns the same handle; handles
+ * stay valid for the life of the process (at most 63 of them). */
+int capy_ed448_generator_create(const uint8_t *xy, int *handle);
 /* The second hedge of that kind: Signable::sign computes its nonce as `bytes_to_scalar(k_bytes) * Scalar::from(4)`
  * (src/ecc/signable.rs:46) -- the crate's `*` operator on a value that is NOT reduced mod r, where every other call
  * site spells out mul_mod -- and then `k - h.mul_mod(&s)` (:54).  What `*` and `-` do to an unreduced Scalar cannot
@@ -179,21 +219,30 @@ int capy_ed448_add_batch(size_t n, const uint8_t *p_xy, const uint8_t *q_xy, uin
 /* out_i = [a_i] G + [b_i] P_i in one pass (the shape of verify, src/ecc/signable.rs:77) */
 int capy_ed448_double_scalarmul_batch(size_t n, const uint8_t *a_be, const uint8_t *b_be,
                                       const uint8_t *points_xy, uint8_t *out_xy);
+/* device forms (r04) */
+int capy_ed448_add_batch_dev(size_t n, const uint8_t *p_xy, const uint8_t *q_xy, uint8_t *out_xy, void *stream);
+int capy_ed448_double_scalarmul_batch_dev(size_t n, const uint8_t *a_be, const uint8_t *b_be, const uint8_t *points_xy,
+                                          uint8_t *out_xy, void *stream);
 
-/* Side-channel hardening: constant-address table lookups (process-wide).  An indexed window table makes the ADDRESS
- * stream of a scalar multiplication depend on the scalar's digits (control flow is uniform either way): a cache-timing
- * channel on a GPU shared with untrusted tenants; the reference's curve crate advertises fixed-time lookups
- * (tests/integration_tests.rs:131-134).  In the constant-address form every row of the window table is read per window
- * and the wanted one kept by masking (variable base: the 17-row per-item table, 4-bit windows in the batched kernels;
- * fixed base: a second shared table with 5-bit windows, 17 entries read per window by scalar loads); the sign is applied
- * by masks; no address and no branch depends on a scalar.  Results are bit-identical with the indexed kernels.
- *   mode 1 (DEFAULT since r03): the multiplications by SECRET scalars inside the protocol calls -- capy_keypair_*,
+/* Side-channel hardening: constant-address table lookups (process-wide default; per call: capy_call_options::hardened).
+ * An indexed window table makes the ADDRESS stream of a scalar multiplication depend on the scalar's digits (control flow
+ * is uniform either way): a cache-timing channel on a GPU shared with untrusted tenants; the reference's curve crate
+ * advertises fixed-time lookups (tests/integration_tests.rs:131-134).  In the constant-address form every row of the
+ * window table is read per window and the wanted one kept by masking (variable base: the 17-row per-item table, 4-bit
+ * windows in the batched kernels; fixed base: a second shared table with 5-bit windows, 17 entries read per window by
+ * scalar loads, or 7-bit windows picked by a one-hot product on the matrix cores); the sign is applied by masks; no
+ * address and no branch depends on a scalar (evidence: profiles/r04_constant_address_counters.txt,
+ * tests/test_constant_address.py).  Results are bit-identical with the indexed kernels.
+ *   CAPY_HARDEN_PROTOCOL (4, DEFAULT): the multiplications by SECRET scalars inside the protocol calls -- capy_keypair_*,
  *          capy_schnorr_sign_* (the nonce k), capy_key_encrypt_* (the ephemeral k, both multiplications),
  *          capy_key_decrypt_* (the private scalar) -- at every batch size (the one-item-per-wave kernels have
  *          constant-address forms too).  Verification and the raw capy_ed448_scalarmul / basemul calls, whose scalars
  *          the library takes to be public, keep the indexed kernels.
- *   mode 3: also the raw scalarmul / basemul calls (for callers that pass secrets through them).
- *   mode 0: indexed kernels everywhere (benchmarks; single-tenant devices).   mode 2: raw calls only.
+ *   CAPY_HARDEN_ALL (1): also the raw scalarmul / basemul calls (for callers that pass secrets through them) -- the
+ *          meaning 1 had in the r02 library.
+ *   CAPY_HARDEN_OFF (0): indexed kernels everywhere.
+ *   2 and 3 (r03's "raw calls only" / "everything") are refused with CAPY_ERR_ARG: r03 had silently narrowed 1 to the
+ *   protocol calls, so a caller written against either release gets an error rather than a changed meaning.
  * Cost against the indexed kernels (profiles/r03_ed448_hardened.txt, r03_ed448_fb7_mfma.txt): variable base 1.2-1.3x;
  * fixed base 1.7x (65 additions instead of 39: the batched kernel picks its 7-bit-window table entries with a one-hot
  * byte matrix product on the matrix cores, csrc/ed448_fb7.h), 1.5x for the one-item-per-wave kernels of small batches;
@@ -250,6 +299,41 @@ int capy_key_decrypt_batch_dev(int d, size_t n, const uint8_t *pws, size_t pw_le
                                const uint8_t *z_xy, uint8_t *msgs, const uint64_t *offsets, uint64_t uniform_len,
                                uint64_t msg_stride, const uint8_t *tags, int32_t *status, void *stream);
 
+/* The same calls with per-call options (r04; opt may be NULL = no options).  Host-buffer forms: same arguments + opt.
+ * Device-buffer forms: the stream comes from opt->stream. */
+int capy_ed448_scalarmul_batch_ex(size_t n, const uint8_t *scalars_be, const uint8_t *points_xy, uint8_t *out_xy,
+                                  const capy_call_options *opt);
+int capy_ed448_scalarmul_batch_dev_ex(size_t n, const uint8_t *scalars_be, const uint8_t *points_xy, uint8_t *out_xy,
+                                      const capy_call_options *opt);
+int capy_ed448_basemul_batch_ex(size_t n, const uint8_t *scalars_be, uint8_t *out_xy, const capy_call_options *opt);
+int capy_ed448_basemul_batch_dev_ex(size_t n, const uint8_t *scalars_be, uint8_t *out_xy, const capy_call_options *opt);
+int capy_keypair_batch_ex(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint64_t *pw_offsets, uint8_t *pub_xy,
+                          const capy_call_options *opt);
+int capy_schnorr_sign_batch_ex(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint64_t *pw_offsets,
+                               const uint8_t *msgs, const uint64_t *offsets, uint8_t *h, uint8_t *z_be,
+                               const capy_call_options *opt);
+int capy_schnorr_verify_batch_ex(int d, size_t n, const uint8_t *pub_xy, const uint8_t *msgs, const uint64_t *offsets,
+                                 const uint8_t *h, const uint8_t *z_be, int32_t *status, const capy_call_options *opt);
+int capy_key_encrypt_batch_ex(int d, size_t n, const uint8_t *pub_xy, const uint8_t *k_rand, uint8_t *msgs,
+                              const uint64_t *offsets, uint8_t *z_xy, uint8_t *tags, const capy_call_options *opt);
+int capy_key_decrypt_batch_ex(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint64_t *pw_offsets,
+                              const uint8_t *z_xy, uint8_t *msgs, const uint64_t *offsets, const uint8_t *tags,
+                              int32_t *status, const capy_call_options *opt);
+int capy_keypair_batch_dev_ex(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint64_t *pw_offsets,
+                              uint8_t *pub_xy, const capy_call_options *opt);
+int capy_schnorr_sign_batch_dev_ex(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint64_t *pw_offsets,
+                                   const uint8_t *msgs, const uint64_t *offsets, uint64_t uniform_len, uint64_t msg_stride,
+                                   uint8_t *h, uint8_t *z_be, const capy_call_options *opt);
+int capy_schnorr_verify_batch_dev_ex(int d, size_t n, const uint8_t *pub_xy, const uint8_t *msgs, const uint64_t *offsets,
+                                     uint64_t uniform_len, uint64_t msg_stride, const uint8_t *h, const uint8_t *z_be,
+                                     int32_t *status, const capy_call_options *opt);
+int capy_key_encrypt_batch_dev_ex(int d, size_t n, const uint8_t *pub_xy, const uint8_t *k_rand, uint8_t *msgs,
+                                  const uint64_t *offsets, uint64_t uniform_len, uint64_t msg_stride, uint8_t *z_xy,
+                                  uint8_t *tags, const capy_call_options *opt);
+int capy_key_decrypt_batch_dev_ex(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint64_t *pw_offsets,
+                                  const uint8_t *z_xy, uint8_t *msgs, const uint64_t *offsets, uint64_t uniform_len,
+                                  uint64_t msg_stride, const uint8_t *tags, int32_t *status, const capy_call_options *opt);
+
 /* ------------------------------------------------------------------ measurement helpers */
 
 /* Tuning / test knob: GPU lanes per sponge. 0 = automatic (a wave per item or per two items for batches of at most
@@ -264,7 +348,7 @@ int capy_set_sponge_lanes(int lanes);
  * 2 sponge_kernel_k2<RW,0>, 3 sponge_mixed_kernel<RW> launched *phases times, 4 sponge_kernel<RW,true,0>,
  * 5 a full-chip head on sponge_kernel<RW,false,0> plus a remainder on kind 2 or 3 (*phases = launches in all),
  * 6 sponge_wide_digest_kernel<RW> (two items per wave: batches of up to two items per SIMD, any message length),
- * 7 sponge_short_kernel<RW> (more than 128 items per SIMD of at most four rate blocks each). */
+ * 7 sponge_uniform_kernel<RW> (more than 128 items per SIMD, wave-uniform framing: csrc/sponge_uniform.h). */
 int capy_sha3_launch_plan(int d, size_t n, uint64_t uniform_len, uint64_t msg_stride, int *kind, int *phases);
 /* Fill a device buffer with the harness PRNG (SplitMix64 counter mode, seed + 8-byte word index). */
 int capy_fill_random_dev(uint8_t *dst, uint64_t nbytes, uint64_t seed, void *stream);

@@ -1,0 +1,302 @@
+"""GPU tests of the C-ABI additions of round 4 (include/capyhip.h): per-call options (capy_call_options, *_ex entry
+points) against the process-wide setters, generator handles, the device-buffer forms that were missing (KEM sponge half,
+point addition, verify-shaped double multiplication), the output-length range check, and the edge scalars of the
+twisted-curve fixed-base kernels.  Parity is against the oracle and against the existing entry points."""
+import ctypes as C
+import random
+import threading
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+R = (1 << 446) - 0x8335dc163bb124b65129c96fde933d8d723a70aadc873d6d54a7bb0d
+
+
+@pytest.fixture(scope="module")
+def capy():
+    import capycrypt_amd
+
+    from capycrypt_amd import _lib
+
+    assert _lib.lib().capy_device_count() >= 1, "no GPU visible"
+    return capycrypt_amd
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+
+    return oracle
+
+
+def _last_kernels(lib):
+    vb, fb = C.c_int(0), C.c_int(0)
+    lib.capy_debug_last_curve_kernel(C.byref(vb), C.byref(fb))
+    return vb.value & 15, fb.value & 15  # 1 indexed, 2 constant-address (bit 4: the wave-per-item family)
+
+
+def test_hardened_values_and_kernel_choice_of_raw_calls(capy, O):
+    """CAPY_HARDEN_ALL (1, the r02 meaning) covers the raw scalarmul / basemul calls, CAPY_HARDEN_PROTOCOL (4,
+    the default) only the secret scalars of the protocol calls, r03's 2 and 3 are refused -- asserted on the kernel
+    family each call really launched (capy_debug_last_curve_kernel), with identical results in every mode."""
+    from capycrypt_amd import _lib
+
+    lib = _lib.lib()
+    rng = random.Random(0xAB1)
+    n = 70
+    ks = [rng.randbytes(56) for _ in range(n)]
+    pts = [O.ed448_basemul(rng.randbytes(56)) for _ in range(n)]
+    pws = [rng.randbytes(20) for _ in range(n)]
+    for bad in (2, 3, 5, -1):
+        assert lib.capy_ed448_set_hardened(bad) == _lib.CAPY_ERR_ARG
+    want = {capy.ops.HARDEN_OFF: ((1, 1), 1), capy.ops.HARDEN_PROTOCOL: ((1, 1), 2), capy.ops.HARDEN_ALL: ((2, 2), 2)}
+    res = {}
+    try:
+        for mode, (raw, proto) in want.items():
+            capy.ops.ed448_set_hardened(mode)
+            vb = capy.ops.ed448_scalarmul_batch(ks, pts)
+            fb = capy.ops.ed448_basemul_batch(ks)
+            assert _last_kernels(lib) == raw, mode
+            pub = capy.ops.keypair_batch(pws, 256)
+            assert _last_kernels(lib)[1] == proto, mode
+            res[mode] = (vb, fb, pub)
+    finally:
+        capy.ops.ed448_set_hardened(capy.ops.HARDEN_PROTOCOL)
+    assert res[capy.ops.HARDEN_OFF] == res[capy.ops.HARDEN_PROTOCOL] == res[capy.ops.HARDEN_ALL]
+    assert res[capy.ops.HARDEN_OFF][1][:5] == [O.ed448_basemul(k) for k in ks[:5]]
+
+
+def test_call_options_let_two_threads_differ(capy, O):
+    """capy_call_options through the *_ex entry points: two host threads run the same calls at the same time, one with
+    indexed lookups and one with constant-address lookups for everything, while the process default stays in force for
+    calls without options.  Each thread sees its own kernel family; all results are equal."""
+    from capycrypt_amd import _lib
+
+    lib = _lib.lib()
+    rng = random.Random(0xAB2)
+    n = 96
+    ks = b"".join(rng.randbytes(56) for _ in range(n))
+    pws = b"".join(rng.randbytes(32) for _ in range(n))
+    msgs = [rng.randbytes(100) for _ in range(n)]
+    mbuf, moff = _lib.pack(msgs)
+    out = {}
+    errs = []
+
+    def worker(name, hardened):
+        try:
+            opt = _lib.CallOptions(hardened=hardened)
+            fams = set()
+            for _ in range(4):
+                fb = (C.c_uint8 * (n * 112))()
+                _lib.check(lib.capy_ed448_basemul_batch_ex(n, ks, fb, C.byref(opt)))
+                fams.add(_last_kernels(lib)[1])
+                pub = (C.c_uint8 * (n * 112))()
+                _lib.check(lib.capy_keypair_batch_ex(512, n, pws, 32, None, pub, C.byref(opt)))
+                fams.add(_last_kernels(lib)[1])
+                h, z = (C.c_uint8 * (n * 56))(), (C.c_uint8 * (n * 56))()
+                _lib.check(lib.capy_schnorr_sign_batch_ex(512, n, pws, 32, None, mbuf, moff, h, z, C.byref(opt)))
+                st = (C.c_int32 * n)()
+                _lib.check(lib.capy_schnorr_verify_batch_ex(512, n, pub, mbuf, moff, h, z, st, C.byref(opt)))
+                assert not any(st)
+            out[name] = (bytes(fb), bytes(pub), bytes(h), bytes(z), fams)
+        except Exception as e:  # noqa: BLE001
+            errs.append((name, repr(e)))
+
+    ts = [threading.Thread(target=worker, args=("off", _lib.CAPY_HARDEN_OFF)),
+          threading.Thread(target=worker, args=("all", _lib.CAPY_HARDEN_ALL))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    assert out["off"][4] == {1} and out["all"][4] == {2}
+    assert out["off"][:4] == out["all"][:4]
+    # a call without options still follows the process default (raw call: indexed; key pair: constant-address)
+    fb = (C.c_uint8 * (n * 112))()
+    _lib.check(lib.capy_ed448_basemul_batch(n, ks, fb))
+    assert _last_kernels(lib)[1] == 1 and bytes(fb) == out["off"][0]
+    # malformed options are refused
+    bad = _lib.CallOptions(hardened=3)
+    assert lib.capy_ed448_basemul_batch_ex(n, ks, fb, C.byref(bad)) == _lib.CAPY_ERR_ARG
+    short = _lib.CallOptions()
+    short.struct_size = 8
+    assert lib.capy_ed448_basemul_batch_ex(n, ks, fb, C.byref(short)) == _lib.CAPY_ERR_ARG
+    unknown = _lib.CallOptions(generator=63)
+    assert lib.capy_ed448_basemul_batch_ex(n, ks, fb, C.byref(unknown)) == _lib.CAPY_ERR_ARG
+
+
+def test_generator_handles(capy, O):
+    """capy_ed448_generator_create + capy_call_options::generator: a second generator G' = [5]G serves fixed-base
+    multiplications, key pairs, signatures and verification of the calls that select it (indexed and constant-address
+    tables, lane and wave kernels), next to the process generator, which is untouched."""
+    from capycrypt_amd import _lib
+
+    lib = _lib.lib()
+    rng = random.Random(0xAB3)
+    g2 = O.ed448_basemul((5).to_bytes(56, "big"))
+    handle = C.c_int(-1)
+    _lib.check(lib.capy_ed448_generator_create(g2, C.byref(handle)))
+    again = C.c_int(-1)
+    _lib.check(lib.capy_ed448_generator_create(g2, C.byref(again)))
+    assert handle.value >= 1 and again.value == handle.value
+    # a point outside the prime-order subgroup is refused
+    p = (1 << 448) - (1 << 224) - 1
+    order2 = (0).to_bytes(56, "little") + (p - 1).to_bytes(56, "little")
+    assert lib.capy_ed448_generator_create(order2, C.byref(again)) == _lib.CAPY_ERR_ARG
+    for n in (40, 9000):  # wave-per-item and lane-per-item kernels
+        ks = [rng.randbytes(56) for _ in range(n)]
+        kb = b"".join(ks)
+        for hardened in (_lib.CAPY_HARDEN_OFF, _lib.CAPY_HARDEN_ALL):
+            opt = _lib.CallOptions(hardened=hardened, generator=handle.value)
+            fb2 = (C.c_uint8 * (n * 112))()
+            _lib.check(lib.capy_ed448_basemul_batch_ex(n, kb, fb2, C.byref(opt)))
+            want = capy.ops.ed448_scalarmul_batch(ks, [g2] * n)
+            assert [bytes(fb2[112 * i:112 * i + 112]) for i in range(n)] == want, (n, hardened)
+        fb1 = capy.ops.ed448_basemul_batch(ks[:8])
+        assert fb1 == [O.ed448_basemul(k) for k in ks[:8]]
+    # a signature made with G' verifies with G' and fails with G
+    n = 33
+    pws = b"".join(rng.randbytes(24) for _ in range(n))
+    msgs = [rng.randbytes(rng.randrange(0, 300)) for _ in range(n)]
+    mbuf, moff = _lib.pack(msgs)
+    opt = _lib.CallOptions(generator=handle.value)
+    pub, h, z = (C.c_uint8 * (n * 112))(), (C.c_uint8 * (n * 56))(), (C.c_uint8 * (n * 56))()
+    _lib.check(lib.capy_keypair_batch_ex(512, n, pws, 24, None, pub, C.byref(opt)))
+    _lib.check(lib.capy_schnorr_sign_batch_ex(512, n, pws, 24, None, mbuf, moff, h, z, C.byref(opt)))
+    st = (C.c_int32 * n)()
+    _lib.check(lib.capy_schnorr_verify_batch_ex(512, n, pub, mbuf, moff, h, z, st, C.byref(opt)))
+    assert not any(st)
+    _lib.check(lib.capy_schnorr_verify_batch(512, n, pub, mbuf, moff, h, z, st))
+    assert all(st)
+
+
+def test_new_device_buffer_forms(capy, O):
+    """capy_ed448_add_batch_dev, capy_ed448_double_scalarmul_batch_dev, capy_kem_sponge_{encrypt,decrypt}_batch_dev (r04)
+    against their host-buffer forms and the oracle."""
+    import torch
+
+    from capycrypt_amd import _lib
+
+    lib = _lib.lib()
+    rng = random.Random(0xAB4)
+
+    def dev(b):
+        return torch.tensor(list(b), dtype=torch.uint8, device="cuda") if b else torch.zeros(8, dtype=torch.uint8, device="cuda")
+
+    for n in (50, 9000):
+        a = [rng.randbytes(56) for _ in range(n)]
+        b = [rng.randbytes(56) for _ in range(n)]
+        pts = capy.ops.ed448_basemul_batch([rng.randbytes(56) for _ in range(n)])
+        qts = capy.ops.ed448_basemul_batch([rng.randbytes(56) for _ in range(n)])
+        dp, dq, da, db = dev(b"".join(pts)), dev(b"".join(qts)), dev(b"".join(a)), dev(b"".join(b))
+        o1 = torch.zeros(n * 112, dtype=torch.uint8, device="cuda")
+        o2 = torch.zeros(n * 112, dtype=torch.uint8, device="cuda")
+        _lib.check(lib.capy_ed448_add_batch_dev(n, dp.data_ptr(), dq.data_ptr(), o1.data_ptr(), None))
+        _lib.check(lib.capy_ed448_double_scalarmul_batch_dev(n, da.data_ptr(), db.data_ptr(), dp.data_ptr(), o2.data_ptr(), None))
+        torch.cuda.synchronize()
+        h1, h2 = (C.c_uint8 * (n * 112))(), (C.c_uint8 * (n * 112))()
+        _lib.check(lib.capy_ed448_add_batch(n, b"".join(pts), b"".join(qts), h1))
+        _lib.check(lib.capy_ed448_double_scalarmul_batch(n, b"".join(a), b"".join(b), b"".join(pts), h2))
+        assert bytes(o1.cpu().numpy()) == bytes(h1) and bytes(o2.cpu().numpy()) == bytes(h2)
+        for i in (0, n // 2, n - 1):
+            assert bytes(h1[112 * i:112 * i + 112]) == O.ed448_add(pts[i], qts[i])
+    assert lib.capy_ed448_add_batch_dev(4, None, None, None, None) == _lib.CAPY_ERR_ARG
+    # KEM sponge half on device buffers: uniform messages, then ragged ones through offsets
+    n, L, stride = 300, 1000, 1008
+    secrets, zs = rng.randbytes(n * 32), rng.randbytes(n * 512)
+    raw = rng.randbytes(n * stride)
+    dsec, dz = dev(secrets), dev(zs)
+    work = dev(raw)
+    tags = torch.zeros(n * 64, dtype=torch.uint8, device="cuda")
+    _lib.check(lib.capy_kem_sponge_encrypt_batch_dev(512, n, dsec.data_ptr(), 32, dz.data_ptr(), work.data_ptr(), None, L, stride,
+                                                     tags.data_ptr(), None))
+    torch.cuda.synchronize()
+    msgs = [raw[i * stride:i * stride + L] for i in range(n)]
+    hbuf, hoff = _lib.pack(msgs)
+    htags = (C.c_uint8 * (n * 64))()
+    _lib.check(lib.capy_kem_sponge_encrypt_batch(512, n, secrets, 32, zs, hbuf, hoff, htags))
+    hw = bytes(work.cpu().numpy())
+    assert b"".join(hw[i * stride:i * stride + L] for i in range(n)) == bytes(hbuf)[:n * L]
+    assert bytes(tags.cpu().numpy()) == bytes(htags)
+    assert all(hw[i * stride + L:(i + 1) * stride] == raw[i * stride + L:(i + 1) * stride] for i in range(n))
+    status = torch.full((n,), 9, dtype=torch.int32, device="cuda")
+    tags[64 * 7] ^= 1
+    _lib.check(lib.capy_kem_sponge_decrypt_batch_dev(512, n, dsec.data_ptr(), 32, dz.data_ptr(), work.data_ptr(), None, L, stride,
+                                                     tags.data_ptr(), status.data_ptr(), None))
+    torch.cuda.synchronize()
+    st = status.cpu().numpy()
+    assert st[7] == 1 and int(st.sum()) == 1
+    back = bytes(work.cpu().numpy())
+    for i in range(n):
+        want = hw if i == 7 else raw
+        assert back[i * stride:i * stride + L] == want[i * stride:i * stride + L], i
+
+
+def test_output_length_is_range_checked(capy):
+    """l_bits / 8 used to be narrowed to 32 bits without a check (the reference takes l: usize,
+    src/sha3/shake_functions.rs:79); an output of 2^32 bytes or more per item is now refused, not truncated."""
+    import torch
+
+    from capycrypt_amd import _lib
+
+    lib = _lib.lib()
+    key, out = torch.zeros(64, dtype=torch.uint8, device="cuda"), torch.zeros(64, dtype=torch.uint8, device="cuda")
+    big = 1 << 35
+    assert lib.capy_kmac_xof_batch_dev(512, 1, key.data_ptr(), 64, 64, None, None, None, 0, 0, big, b"S", 1, out.data_ptr(),
+                                       1 << 32, None) == _lib.CAPY_ERR_ARG
+    assert lib.capy_cshake_batch_dev(512, 1, key.data_ptr(), None, 8, 8, big, b"N", 1, b"S", 1, out.data_ptr(), 1 << 32,
+                                     None) == _lib.CAPY_ERR_ARG
+    hk, ho = (C.c_uint8 * 64)(), (C.c_uint8 * 64)()
+    off = (C.c_uint64 * 2)(0, 0)
+    assert lib.capy_kmac_xof_batch(512, 1, hk, 64, None, hk, off, big, b"S", 1, ho) == _lib.CAPY_ERR_ARG
+    assert lib.capy_cshake_batch(512, 1, hk, off, big, b"N", 1, b"S", 1, ho) == _lib.CAPY_ERR_ARG
+    # the largest length below the limit is accepted as far as the arguments go (a tiny out_stride then fails the next check)
+    assert lib.capy_kmac_xof_batch_dev(512, 1, key.data_ptr(), 64, 64, None, None, None, 0, 0, big - 8, b"S", 1, out.data_ptr(),
+                                       64, None) == _lib.CAPY_ERR_ARG
+    assert b"out_stride" in lib.capy_last_error()
+
+
+def test_twisted_fixed_base_kernels_on_edge_scalars(capy, O):
+    """the fixed base accumulates on the twisted curve E' (a = -1, non-square; d' = -39082 is a square), whose
+    7M additions are complete only on the odd-order subgroup the tables live in.  Scalars k = 0, 1, r - 1, r, r + 1, 2r,
+    2^448 - 1 and their neighbours -- where the accumulator passes through or ends at the identity -- must come out right
+    from every kernel that works on E': fb_kernel<true> and fb_ct7_kernel<true> (one item per lane) and, from 262 144
+    items, fb2_kernel<false, true> and fb_ct7_pair_kernel<true> (two items per lane, ragged tail)."""
+    import torch
+
+    from capycrypt_amd import _lib
+
+    lib = _lib.lib()
+    edge = [0, 1, 2, R - 2, R - 1, R, R + 1, 2 * R - 1, 2 * R, 2 * R + 1, 3 * R, 4 * R - 1, (1 << 448) - 1, (1 << 448) - 2, 1 << 447,
+            (1 << 446), 4 * R, 4 * R + 3]
+    edge = [k % (1 << 448) for k in edge]
+    want = {k: O.ed448_basemul(k.to_bytes(56, "big")) for k in edge}
+    ident = (0).to_bytes(56, "little") + (1).to_bytes(56, "little")
+    assert want[0] == ident and want[R] == ident and want[2 * R] == ident
+    sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    try:
+        _lib.check(lib.capy_ed448_set_wave_max(0))  # lane-per-item kernels at every size
+        for n in (len(edge), 9000, (1 << 18) + 37):
+            sc = torch.empty(n * 56, dtype=torch.uint8, device="cuda")
+            _lib.check(lib.capy_fill_random_dev(sc.data_ptr(), n * 56, 4242, sp))
+            flat = sc.view(n, 56)
+            eb = torch.tensor(list(b"".join(k.to_bytes(56, "big") for k in edge)), dtype=torch.uint8, device="cuda").view(-1, 56)
+            flat[:len(edge)] = eb            # first lanes of the first wave
+            flat[n - len(edge):] = eb        # the ragged tail
+            outs = []
+            for mode in (capy.ops.HARDEN_OFF, capy.ops.HARDEN_ALL):
+                capy.ops.ed448_set_hardened(mode)
+                o = torch.zeros(n * 112, dtype=torch.uint8, device="cuda")
+                _lib.check(lib.capy_ed448_basemul_batch_dev(n, sc.data_ptr(), o.data_ptr(), sp))
+                torch.cuda.synchronize()
+                outs.append(o)
+            assert torch.equal(outs[0], outs[1]), n
+            ho = bytes(outs[0].cpu().numpy())
+            for j, k in enumerate(edge):
+                assert ho[112 * j:112 * j + 112] == want[k], (n, hex(k))
+                t = n - len(edge) + j
+                assert ho[112 * t:112 * t + 112] == want[k], (n, "tail", hex(k))
+    finally:
+        capy.ops.ed448_set_hardened(capy.ops.HARDEN_PROTOCOL)
+        _lib.check(lib.capy_ed448_set_wave_max(-1))

@@ -595,9 +595,9 @@ def test_generator_can_be_replaced(capy, O):
 
 
 def test_hardened_mode_is_bit_identical(capy, O):
-    """capy_ed448_set_hardened: mode 1 (the default) runs the multiplications by secret scalars inside the protocol calls
-    on the constant-address kernels (every row of the window table read per window, no address depends on a scalar),
-    mode 3 the raw multiplications as well, mode 0 none.  Every result must be the same in all three and equal the
+    """capy_ed448_set_hardened: CAPY_HARDEN_PROTOCOL (the default) runs the multiplications by secret scalars inside the
+    protocol calls on the constant-address kernels (every row of the window table read per window, no address depends on
+    a scalar), CAPY_HARDEN_ALL the raw multiplications as well, CAPY_HARDEN_OFF none.  Every result must be the same in all three and equal the
     oracle's: raw operations, key pairs, signatures, ECDHIES -- with the one-item-per-wave kernels and without (the
     autouse fixture), i.e. through wave::*<true> and vb_ct_kernel / fb_ct7_kernel (the fixed base with its lookups on the
     matrix cores, csrc/ed448_fb7.h; a full-size ragged batch of it: test_hardened_pair_kernels_match)."""
@@ -619,14 +619,14 @@ def test_hardened_mode_is_bit_identical(capy, O):
         return r
 
     try:
-        capy.ops.ed448_set_hardened(0)
+        capy.ops.ed448_set_hardened(capy.ops.HARDEN_OFF)
         plain = run()
-        capy.ops.ed448_set_hardened(1)
+        capy.ops.ed448_set_hardened(capy.ops.HARDEN_PROTOCOL)
         default = run()
-        capy.ops.ed448_set_hardened(3)
+        capy.ops.ed448_set_hardened(capy.ops.HARDEN_ALL)
         hard = run()
     finally:
-        capy.ops.ed448_set_hardened(1)
+        capy.ops.ed448_set_hardened(capy.ops.HARDEN_PROTOCOL)
     for k in plain:
         assert hard[k] == plain[k], k
         assert default[k] == plain[k], k
@@ -661,7 +661,7 @@ def test_scalar_star_modes_match_oracle(capy, O):
 def test_hardened_pair_kernels_match(capy, O, ed448_kernel_family):
     """The kernels of batches from 262 144 items: two items per lane sharing one inversion (vb2_kernel, fb2_kernel<false>)
     against their constant-address counterparts (vb_ct_kernel, fb_ct7_kernel: 7-bit windows selected by a one-hot matrix
-    product, every one of the 262 214 results compared).  CAPY_ED448_PAIR cannot be switched at
+    product, every one of the 262 214 results compared).  CAPY_DEBUG=ed448_pair cannot be switched at
     run time, so a batch of the real threshold size (with a ragged last wave) runs once in mode 0 and once in mode 3 and
     must agree item by item; a sample is checked against the oracle."""
     import ctypes as C
@@ -683,7 +683,7 @@ def test_hardened_pair_kernels_match(capy, O, ed448_kernel_family):
     pts = torch.empty(n * 112, dtype=torch.uint8, device=dev)
     outs = {}
     try:
-        for mode in (0, 3):
+        for mode in (0, 1):  # CAPY_HARDEN_OFF, CAPY_HARDEN_ALL
             capy.ops.ed448_set_hardened(mode)
             if mode == 0:
                 _lib.check(lib.capy_ed448_basemul_batch_dev(n, tsc.data_ptr(), pts.data_ptr(), sp))
@@ -694,9 +694,9 @@ def test_hardened_pair_kernels_match(capy, O, ed448_kernel_family):
             torch.cuda.synchronize()
             outs[mode] = (vb, fb)
     finally:
-        capy.ops.ed448_set_hardened(1)
-    assert torch.equal(outs[0][0], outs[3][0]) and torch.equal(outs[0][1], outs[3][1])
-    sch, pth, vbh = bytes(sc.cpu().numpy()), bytes(pts.cpu().numpy()), bytes(outs[3][0].cpu().numpy())
+        capy.ops.ed448_set_hardened(capy.ops.HARDEN_PROTOCOL)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    sch, pth, vbh = bytes(sc.cpu().numpy()), bytes(pts.cpu().numpy()), bytes(outs[1][0].cpu().numpy())
     for i in (0, 63, 64, 127, 128, n - 71, n - 1):
         assert vbh[112 * i:112 * i + 112] == O.ed448_scalarmul(sch[56 * i:56 * i + 56], pth[112 * i:112 * i + 112]), i
 
@@ -754,7 +754,7 @@ def test_wave_kernels_equal_lane_kernels_on_edge_cases(capy, O, ed448_kernel_fam
     pts[3], pts[4], pts[5] = ident, order2, (5).to_bytes(56, "little") + (7).to_bytes(56, "little")
     results = []
     try:
-        for wmax, mode in ((0, 0), (1 << 20, 0), (0, 3), (1 << 20, 3)):  # lane / wave kernels, indexed / constant-address
+        for wmax, mode in ((0, 0), (1 << 20, 0), (0, 1), (1 << 20, 1)):  # lane / wave kernels, indexed / constant-address
             _lib.check(lib.capy_ed448_set_wave_max(wmax))
             capy.ops.ed448_set_hardened(mode)
             vb = capy.ops.ed448_scalarmul_batch(kb, pts)
@@ -763,7 +763,7 @@ def test_wave_kernels_equal_lane_kernels_on_edge_cases(capy, O, ed448_kernel_fam
             _lib.check(lib.capy_ed448_double_scalarmul_batch(n, b"".join(kb[::-1]), b"".join(kb), b"".join(pts), out))
             results.append((vb, fb, bytes(out)))
     finally:
-        capy.ops.ed448_set_hardened(1)
+        capy.ops.ed448_set_hardened(capy.ops.HARDEN_PROTOCOL)
     for idx, other in enumerate(results[1:]):
         # the constant-address lane kernel uses 4-bit windows: a different operation sequence, which must agree on the
         # curve only -- the non-curve point (item 5) is compared between the two indexed families alone
@@ -795,12 +795,12 @@ def test_matrix_core_fixed_base_on_structured_scalars(capy, O, ed448_kernel_fami
     kb = [k.to_bytes(56, "big") for k in ks]
     try:
         _lib.check(lib.capy_ed448_set_wave_max(0))
-        capy.ops.ed448_set_hardened(3)
+        capy.ops.ed448_set_hardened(capy.ops.HARDEN_ALL)
         hard = capy.ops.ed448_basemul_batch(kb)
-        capy.ops.ed448_set_hardened(0)
+        capy.ops.ed448_set_hardened(capy.ops.HARDEN_OFF)
         plain = capy.ops.ed448_basemul_batch(kb)
     finally:
-        capy.ops.ed448_set_hardened(1)
+        capy.ops.ed448_set_hardened(capy.ops.HARDEN_PROTOCOL)
         _lib.check(lib.capy_ed448_set_wave_max(-1))
     assert hard == plain
     for i in list(range(0, 22)) + list(range(22, len(ks), 17)):

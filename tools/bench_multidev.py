@@ -59,7 +59,7 @@ z_h = (C.c_uint8 * (n * 56))()
 st_h = (C.c_int32 * n)()
 dig_h = (C.c_uint8 * (n * 32))()
 _lib.check(lib.capy_keypair_batch(512, n, pws_h, 64, None, pubs_h))
-print("# hardened mode %s" % os.environ.get("CAPY_HARDENED_MODE", "1 (default)"))
+print("# hardened mode %s" % os.environ.get("CAPY_HARDENED_MODE", "4 = CAPY_HARDEN_PROTOCOL (default)"))
 if "CAPY_HARDENED_MODE" in os.environ:
     _lib.check(lib.capy_ed448_set_hardened(int(os.environ["CAPY_HARDENED_MODE"])))
 run("config 5 sign   2^16 x 1 KiB", lambda: lib.capy_schnorr_sign_batch(512, n, pws_h, 64, None, msgs_h, offs_h, h_h, z_h), 9)

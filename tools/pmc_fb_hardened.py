@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Fixed-base (default) or variable-base (OP=vb) multiplication with constant-address lookups alone
-(capy_ed448_set_hardened(3)), N items, for counter passes."""
+(capy_ed448_set_hardened(1)  # CAPY_HARDEN_ALL), N items, for counter passes."""
 import ctypes as C
 import os
 import sys
@@ -20,7 +20,7 @@ _lib.check(lib.capy_fill_random_dev(sc.data_ptr(), sc.numel(), 4, sp))
 out = torch.empty(n * 112, dtype=torch.uint8, device=dev)
 pts = torch.empty(n * 112, dtype=torch.uint8, device=dev)
 _lib.check(lib.capy_ed448_basemul_batch_dev(n, sc.data_ptr(), pts.data_ptr(), sp))
-_lib.check(lib.capy_ed448_set_hardened(3))
+_lib.check(lib.capy_ed448_set_hardened(1)  # CAPY_HARDEN_ALL)
 vb = os.environ.get("OP", "fb") == "vb"
 
 
