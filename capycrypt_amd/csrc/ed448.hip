@@ -478,7 +478,6 @@ static const uint8_t G_XY[112] = {
 // generators at the same time.  Every context owns its fixed-base tables, built lazily per device.
 struct GenCtx {
     uint8_t xy[112];
-    int order_r = -1;                    // -1 not yet known, 0 / 1 (the twisted-curve tables need the prime order r)
     uint32_t *gtab[64] = {nullptr};      // indexed 12-bit table on E
     uint32_t *gtab_ct[64] = {nullptr};   // the hardened table (FBCT_WBITS-bit windows), built on first hardened use
     uint32_t *gtab_tw[64] = {nullptr};   // the indexed 12-bit table on the twisted curve (lane-per-item fixed base)
@@ -557,32 +556,10 @@ static int build_gtab(const uint8_t *gen_xy, int rows, int entries, int wbits, u
 #ifndef CAPY_ED448_FB_TWISTED
 #define CAPY_ED448_FB_TWISTED 1
 #endif
-static int generator_has_order_r(GenCtx *g, bool *yes)  // caller holds g_gtab_mu
-{
-    if (g->order_r < 0) {
-        static const uint32_t R_WORDS[14] = {0xab5844f3u, 0x2378c292u, 0x8dc58f55u, 0x216cc272u, 0xaed63690u, 0xc44edb49u, 0x7cca23e9u,
-                                             0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0x3fffffffu};
-        uint8_t r_be[56], out[112];
-        sc_to_be(r_be, R_WORDS);
-        DevBuf dsc, dpt, dout, dtab;
-        CAPY_HIP(dsc.alloc(56));
-        CAPY_HIP(dpt.alloc(112));
-        CAPY_HIP(dout.alloc(112));
-        CAPY_HIP(dtab.alloc(VB_TABLE_DWORDS * 4));
-        CAPY_HIP(dsc.put(r_be, 56));
-        CAPY_HIP(dpt.put(g->xy, 112));
-        hipLaunchKernelGGL(vb_kernel, dim3(1), dim3(64), 0, nullptr, (uint64_t)1, dsc.as<uint8_t>(), (uint64_t)56, dpt.as<uint8_t>(),
-                           (uint64_t)112, dout.as<uint8_t>(), dtab.as<uint32_t>());
-        CAPY_HIP(hipGetLastError());
-        CAPY_HIP(dout.get(out, 112));
-        bool ident = out[56] == 1;  // (0, 1): x all zero, y = 1 little-endian
-        for (int i = 0; i < 112; i++)
-            if (i != 56 && out[i] != 0) ident = false;
-        g->order_r = ident ? 1 : 0;
-    }
-    *yes = CAPY_ED448_FB_TWISTED && g->order_r == 1;
-    return CAPY_OK;
-}
+// Every generator has passed check_generator (prime order r), so the twisted-curve tables are always available; the
+// lane-per-item fixed-base kernels are instantiated for that form only (r04: the E-only fallback for generators of other
+// orders could not be reached any more and was removed with its four kernel instances).
+constexpr bool FB_TW = CAPY_ED448_FB_TWISTED != 0;
 
 static int ensure_gtab7(const uint8_t **out, bool *twisted)
 {
@@ -593,9 +570,7 @@ static int ensure_gtab7(const uint8_t **out, bool *twisted)
     GenCtx *g = current_gen();
     if (!g) return fail(CAPY_ERR_ARG, "unknown generator handle");
     if (!g->gtab7[dev]) {
-        bool tw = false;
-        const int rco = generator_has_order_r(g, &tw);
-        if (rco) return rco;
+        const bool tw = FB_TW;
         g->gtab7_twisted[dev] = tw;
         uint32_t *lin = nullptr;
         const int rc = build_gtab(g->xy, FB7_ROWS, FB7_ENTRIES, FB7_WBITS, &lin, tw);
@@ -629,11 +604,7 @@ static int ensure_gtab(const uint32_t **out, bool hardened_table = false, bool *
     std::lock_guard<std::mutex> lk(g_gtab_mu);
     GenCtx *g = current_gen();
     if (!g) return fail(CAPY_ERR_ARG, "unknown generator handle");
-    bool tw = false;
-    if (twisted && *twisted && !hardened_table) {
-        const int rco = generator_has_order_r(g, &tw);
-        if (rco) return rco;
-    }
+    const bool tw = twisted && *twisted && !hardened_table && FB_TW;
     if (twisted) *twisted = tw;
     uint32_t **slot = hardened_table ? &g->gtab_ct[dev] : (tw ? &g->gtab_tw[dev] : &g->gtab[dev]);
     if (!*slot) {
@@ -658,20 +629,16 @@ static int fb_launch(size_t n, const uint8_t *scalars, uint8_t *out, hipStream_t
         bool tw = false;
         const int rc7 = ensure_gtab7(&gt7, &tw);
         if (rc7) return rc7;
+        if (tw != FB_TW) return fail(CAPY_ERR_HIP, "internal: fixed-base table form");
         if (n >= pair_min_items()) {
             const size_t blocks = (n + 127) / 128;
             CAPY_WS(park, uint32_t *, s, WS_TABLE, blocks * 64 * 48 * 4);
-            if (tw)
-                hipLaunchKernelGGL(fb_ct7_pair_kernel<true>, dim3((unsigned)blocks), dim3(64), 0, s, (uint64_t)n, scalars, out, gt7, park);
-            else
-                hipLaunchKernelGGL(fb_ct7_pair_kernel<false>, dim3((unsigned)blocks), dim3(64), 0, s, (uint64_t)n, scalars, out, gt7, park);
+            hipLaunchKernelGGL(fb_ct7_pair_kernel<FB_TW>, dim3((unsigned)blocks), dim3(64), 0, s, (uint64_t)n, scalars, out, gt7, park);
             // the parked PROJECTIVE results of secret multiples must not outlive the call (a projective representation
             // of [k]G says more about k than the affine point does)
             CAPY_HIP(hipMemsetAsync(park, 0, blocks * 64 * 48 * 4, s));
-        } else if (tw) {
-            hipLaunchKernelGGL(fb_ct7_kernel<true>, grid64(n), dim3(64), 0, s, (uint64_t)n, scalars, out, gt7);
         } else {
-            hipLaunchKernelGGL(fb_ct7_kernel<false>, grid64(n), dim3(64), 0, s, (uint64_t)n, scalars, out, gt7);
+            hipLaunchKernelGGL(fb_ct7_kernel<FB_TW>, grid64(n), dim3(64), 0, s, (uint64_t)n, scalars, out, gt7);
         }
         CAPY_HIP(hipGetLastError());
         return CAPY_OK;
@@ -691,16 +658,12 @@ static int fb_launch(size_t n, const uint8_t *scalars, uint8_t *out, hipStream_t
     } else if (n >= pair_min_items()) {
         if (ct)
             hipLaunchKernelGGL((fb2_kernel<true, false>), pair_grid, dim3(64), 0, s, (uint64_t)n, scalars, out, gt);
-        else if (tw)
-            hipLaunchKernelGGL((fb2_kernel<false, true>), pair_grid, dim3(64), 0, s, (uint64_t)n, scalars, out, gt);
         else
-            hipLaunchKernelGGL((fb2_kernel<false, false>), pair_grid, dim3(64), 0, s, (uint64_t)n, scalars, out, gt);
+            hipLaunchKernelGGL((fb2_kernel<false, FB_TW>), pair_grid, dim3(64), 0, s, (uint64_t)n, scalars, out, gt);
     } else if (ct) {
         hipLaunchKernelGGL(fb_ct_kernel, grid64(n), dim3(64), 0, s, (uint64_t)n, scalars, out, gt);
-    } else if (tw) {
-        hipLaunchKernelGGL(fb_kernel<true>, grid64(n), dim3(64), 0, s, (uint64_t)n, scalars, out, gt);
     } else {
-        hipLaunchKernelGGL(fb_kernel<false>, grid64(n), dim3(64), 0, s, (uint64_t)n, scalars, out, gt);
+        hipLaunchKernelGGL(fb_kernel<FB_TW>, grid64(n), dim3(64), 0, s, (uint64_t)n, scalars, out, gt);
     }
     CAPY_HIP(hipGetLastError());
     return CAPY_OK;
