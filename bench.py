@@ -81,6 +81,9 @@ def parse():
     ap.add_argument("--ed448-pairs", type=int, default=1 << 18, help="(scalar, point) pairs per GPU (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--crossover", action="store_true",
+                    help="instead of the benchmark: per-call latency of the HOST-buffer ABI for n = 1 .. 64 items against the "
+                         "CPU port per item -- the dispatch rule of the Rust shim (INTEGRATION.md section 3)")
     return ap.parse_args()
 
 
@@ -208,8 +211,85 @@ def cpu_baseline_ed448(seconds, sample):
     return n / (time.perf_counter() - t0)
 
 
+def crossover(a):
+    """Where a caller that holds n items should switch from the reference's own CPU path to the batched GPU call: the
+    host-buffer entry points (PCIe included: what the Rust shim calls) timed per CALL for small n, the CPU port of the
+    same operation timed per ITEM on one host thread (the cpu_baseline leg: the only place this file touches oracle/)."""
+    import random
+
+    import torch  # noqa: F401  (shares torch's HIP runtime with the library)
+
+    from capycrypt_amd import _lib
+    from oracle import oracle as O
+
+    lib = _lib.lib()
+    _lib.check(lib.capy_set_device(0))
+    rng = random.Random(0xCA9C0007)
+    O.select_keccak(True)  # the reference's in-place four-rounds-per-trip form
+
+    def gpu_time(fn, reps):
+        fn()
+        best = 1e9
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            best = min(best, time.perf_counter() - t0)
+        return best
+
+    def cpu_time(fn, min_s=1.0):
+        fn()
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < min_s:
+            fn()
+            n += 1
+        return (time.perf_counter() - t0) / n
+
+    print("# bench.py --crossover: per-call latency of the host-buffer C ABI (PCIe inclusive, one MI355X) against the CPU port per item")
+    print("# (C port of the reference's sponge on its in-place keccak, oracle Ed448, gcc -O3, one thread of %s)" % _cpu_model())
+    rows = []
+    for label, L, ns in (("5 MiB", MSG_BYTES, (1, 2, 4, 8, 16, 32, 64)), ("1 KiB", 1024, (1, 2, 4, 16, 64, 256))):
+        msg = rng.randbytes(L)
+        pw = rng.randbytes(32)
+        pub = O.keypair_pub(pw, 512)
+        h0, z0 = O.sign(pw, msg, 512)
+        cpu = {"sha3": cpu_time(lambda: O.sha3(msg, 256)), "tagged_hash": cpu_time(lambda: O.kmac_xof(pw, msg, 512, b"T", 512)),
+               "sign": cpu_time(lambda: O.sign(pw, msg, 512)), "verify": cpu_time(lambda: O.verify(pub, msg, 512, h0, z0))}
+        print("\n## messages of %s; CPU port per item: %s" % (label, "  ".join("%s %.3f ms" % (k, v * 1e3) for k, v in cpu.items())))
+        print("%6s | %s" % ("n", " | ".join("%-24s" % (k + ": GPU call ms (x CPU)") for k in cpu)))
+        first_win = {k: None for k in cpu}
+        for n in ns:
+            msgs = [rng.randbytes(L) for _ in range(n)]
+            buf, off = _lib.pack(msgs)
+            pws = b"".join(rng.randbytes(32) for _ in range(n))
+            dig = (C.c_uint8 * (n * 32))()
+            tag = (C.c_uint8 * (n * 64))()
+            pubs = (C.c_uint8 * (n * 112))()
+            hh, zz = (C.c_uint8 * (n * 56))(), (C.c_uint8 * (n * 56))()
+            st = (C.c_int32 * n)()
+            _lib.check(lib.capy_keypair_batch(512, n, pws, 32, None, pubs))
+            g = {"sha3": gpu_time(lambda: _lib.check(lib.capy_sha3_batch(256, n, buf, off, dig)), 3),
+                 "tagged_hash": gpu_time(lambda: _lib.check(lib.capy_kmac_xof_batch(512, n, pws, 32, None, buf, off, 512, b"T", 1, tag)), 3),
+                 "sign": gpu_time(lambda: _lib.check(lib.capy_schnorr_sign_batch(512, n, pws, 32, None, buf, off, hh, zz)), 3),
+                 "verify": gpu_time(lambda: _lib.check(lib.capy_schnorr_verify_batch(512, n, pubs, buf, off, hh, zz, st)), 3)}
+            assert not any(st)
+            cells = []
+            for k in cpu:
+                ratio = n * cpu[k] / g[k]
+                if ratio > 1.0 and first_win[k] is None:
+                    first_win[k] = n
+                cells.append("%9.3f (%6.2fx)       " % (g[k] * 1e3, ratio))
+            print("%6d | %s" % (n, " | ".join(cells)), flush=True)
+        rows.append((label, cpu, first_win))
+    print("\n## dispatch rule: smallest measured n per call from which the batched GPU call beats n CPU calls")
+    for label, cpu, fw in rows:
+        print("%s: %s" % (label, "  ".join("%s n >= %s" % (k, fw[k] if fw[k] is not None else "> largest n measured") for k in cpu)))
+    O.select_keccak(False)
+
+
 def main():
     a = parse()
+    if a.crossover:
+        return crossover(a)
     # the first `import torch` on a fresh box pages the image in (minutes on a bad day): heartbeat on stderr
     import threading
 
@@ -415,7 +495,7 @@ def main():
     kname = {1: "sponge_kernel<17, false, 0>", 2: "sponge_kernel_k2<17, 0>", 3: "sponge_mixed_kernel<17>",
              4: "sponge_kernel<17, true, 0>",
              5: "sponge_kernel<17, false, 0> head + remainder (wave-quantisation split)",
-             6: "sponge_wide_digest_kernel<17>", 7: "sponge_uniform_kernel<17>"}[kind.value]
+             6: "sponge_wide_digest_kernel<17>", 7: "sponge_uniform_kernel<17>", 8: "sponge_rot_kernel<17>"}[kind.value]
     launches = phases.value if kind.value != 5 else 1  # a split launch is priced as one step-long launch
 
     # HBM traffic of the dominant kernel: PMC counters cannot be collected from inside the timed process, so the

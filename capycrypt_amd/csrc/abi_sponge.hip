@@ -1,0 +1,292 @@
+// abi_sponge.hip — the C-ABI entry points of the sponge path (include/capyhip.h: SHA3 / cSHAKE / KMACXOF / sha3_encrypt /
+// sha3_decrypt / KEM sponge half): argument checks, sharding, host <-> device staging, then sponge_launch.hip.
+#include <string.h>
+#include <algorithm>
+#include <atomic>
+#include <string>
+#include <vector>
+#include "common.h"
+#include "sponge_host.h"
+
+namespace capy {
+
+
+
+}  // namespace capy
+
+using namespace capy;
+
+extern "C" {
+
+// ---------------------------------------------------------------- SHA3
+int capy_sha3_batch_dev(int d, size_t n, const uint8_t *msgs, const uint64_t *offsets, uint64_t uniform_len,
+                        uint64_t msg_stride, uint8_t *digests, void *stream)
+{
+    if (n) {
+        CAPY_REQUIRE(digests, "digests");
+        CAPY_REQUIRE(msgs_ok(msgs, offsets, uniform_len), "msgs");
+    }
+    return sha3_launch(d, n, view_dev(msgs, offsets, uniform_len, msg_stride), digests, (uint64_t)(d / 8),
+                       (hipStream_t)stream);
+}
+
+int capy_sha3_batch(int d, size_t n, const uint8_t *msgs, const uint64_t *offsets, uint8_t *digests)
+{
+    if (!valid_d(d)) return fail(CAPY_ERR_UNSUPPORTED_SECPARAM, "unsupported security parameter");
+    if (n == 0) return CAPY_OK;
+    if (!offsets || !digests) return fail(CAPY_ERR_ARG, "null argument");
+    CAPY_SHARD(n, offsets, capy_sha3_batch(d, count, msgs, offsets + first, digests + first * (size_t)(d / 8)));
+    PackedBatch b;
+    int rc = b.upload(n, msgs, offsets);
+    if (rc) return rc;
+    DevBuf out;
+    const size_t dl = d / 8;
+    CAPY_HIP(out.alloc(n * dl));
+    rc = sha3_launch(d, n, view_of(b), out.as<uint8_t>(), dl, nullptr);
+    if (rc) return rc;
+    CAPY_HIP(out.get(digests, n * dl));
+    return CAPY_OK;
+}
+
+// ---------------------------------------------------------------- cSHAKE / KMACXOF
+int capy_cshake_batch(int d, size_t n, const uint8_t *xs, const uint64_t *offsets, size_t l_bits,
+                      const uint8_t *fn_name, size_t fn_len, const uint8_t *custom, size_t custom_len, uint8_t *outs)
+{
+    if (l_bits / 8 > CAPY_MAX_OUT_LEN) return fail(CAPY_ERR_ARG, "output longer than 2^32 - 1 bytes per item (l_bits >= 2^35)");
+    if (!valid_d(d)) return fail(CAPY_ERR_UNSUPPORTED_SECPARAM, "unsupported security parameter");
+    if (n == 0) return CAPY_OK;
+    if (!offsets || !outs) return fail(CAPY_ERR_ARG, "null argument");
+    CAPY_SHARD(n, offsets, capy_cshake_batch(d, count, xs, offsets + first, l_bits, fn_name, fn_len, custom, custom_len,
+                                             outs + first * (l_bits / 8)));
+    PackedBatch b;
+    int rc;
+    const bool empty_ns = fn_len == 0 && custom_len == 0;
+    if (empty_ns) {
+        // cshake(x, l, "", "", d), shake_functions.rs:59-61: the reference runs shake() on the framed buffer, drops its
+        // digest and KEEPS its mutation -- the SHA3 suffix (06, or 86 when the length is 135 mod 136) and, when the
+        // result is not a multiple of the SHA3-d rate (1600 - 2d)/8, pad10*1 up to it -- and then absorbs that buffer
+        // at capacity d.  Unreachable through the public API (kmac_xof passes N = "KMAC"); reproduced here by giving
+        // every message its trailer on the host and absorbing it without a further suffix.
+        const uint64_t w = (1600 - (uint64_t)d) / 8, r1 = (1600 - 2 * (uint64_t)d) / 8;
+        std::vector<uint8_t> ys;
+        std::vector<uint64_t> yoff(n + 1, 0);
+        for (size_t i = 0; i < n; i++) {
+            if (offsets[i + 1] < offsets[i]) return fail(CAPY_ERR_ARG, "offsets must be non-decreasing");
+            const uint64_t len = offsets[i + 1] - offsets[i];
+            if (len) ys.insert(ys.end(), xs + offsets[i], xs + offsets[i + 1]);
+            ys.push_back(0x04);
+            uint64_t L = w + len + 1;  // bytepad(encode_string("") || encode_string(""), w) is exactly one block of w bytes
+            ys.push_back((136 - L % 136) == 1 ? 0x86 : 0x06);
+            L += 1;
+            if (L % r1) {
+                const uint64_t q = r1 - L % r1;
+                ys.insert(ys.end(), q, 0);
+                ys.back() = 0x80;
+            }
+            yoff[i + 1] = ys.size();
+        }
+        rc = b.upload(n, ys.data(), yoff.data());
+    } else {
+        rc = b.upload(n, xs, offsets);
+    }
+    if (rc) return rc;
+    const size_t ol = l_bits / 8, os = (ol + 7) & ~(size_t)7;
+    DevBuf out;
+    CAPY_HIP(out.alloc(n * os));
+    rc = cshake_launch(d, n, view_of(b), l_bits, fn_name, fn_len, custom, custom_len, out.as<uint8_t>(), os, nullptr,
+                       empty_ns);
+    if (rc) return rc;
+    if (ol) CAPY_HIP(copy_rows_out(outs, ol, out, os, n));
+    return CAPY_OK;
+}
+
+int capy_cshake_batch_dev(int d, size_t n, const uint8_t *xs, const uint64_t *offsets, uint64_t uniform_len,
+                          uint64_t msg_stride, size_t l_bits, const uint8_t *fn_name, size_t fn_len,
+                          const uint8_t *custom, size_t custom_len, uint8_t *outs, uint64_t out_stride, void *stream)
+{
+    if (l_bits / 8 > CAPY_MAX_OUT_LEN) return fail(CAPY_ERR_ARG, "output longer than 2^32 - 1 bytes per item (l_bits >= 2^35)");
+    if (n && !outs) return fail(CAPY_ERR_ARG, "null argument");
+    if (n) CAPY_REQUIRE(msgs_ok(xs, offsets, uniform_len), "xs");
+    if (out_stride < l_bits / 8) return fail(CAPY_ERR_ARG, "out_stride shorter than the output");
+    return cshake_launch(d, n, view_dev(xs, offsets, uniform_len, msg_stride), l_bits, fn_name, fn_len, custom,
+                         custom_len, outs, out_stride, (hipStream_t)stream);
+}
+
+int capy_kmac_xof_batch_dev(int d, size_t n, const uint8_t *keys, size_t key_len, uint64_t key_stride,
+                            const uint64_t *key_offsets, const uint8_t *xs, const uint64_t *offsets, uint64_t uniform_len,
+                            uint64_t msg_stride, size_t l_bits, const uint8_t *custom, size_t custom_len, uint8_t *outs,
+                            uint64_t out_stride, void *stream)
+{
+    if (l_bits / 8 > CAPY_MAX_OUT_LEN) return fail(CAPY_ERR_ARG, "output longer than 2^32 - 1 bytes per item (l_bits >= 2^35)");
+    if (n) {
+        CAPY_REQUIRE(outs, "outs");
+        CAPY_REQUIRE(out_stride >= l_bits / 8, "out_stride shorter than the output");
+        CAPY_REQUIRE(keys_ok(keys, key_len, key_offsets), "keys");
+        CAPY_REQUIRE(msgs_ok(xs, offsets, uniform_len), "xs");
+    }
+    KeyView kv = fixed_keys(keys, key_len, key_stride);
+    kv.key_offsets = key_offsets;
+    return kmac_launch(d, n, kv, view_dev(xs, offsets, uniform_len, msg_stride), true, custom, custom_len, 0, outs,
+                       out_stride, l_bits / 8, nullptr, (hipStream_t)stream);
+}
+
+int capy_kmac_xof_batch(int d, size_t n, const uint8_t *keys, size_t key_len, const uint64_t *key_offsets,
+                        const uint8_t *xs, const uint64_t *offsets, size_t l_bits, const uint8_t *custom, size_t custom_len,
+                        uint8_t *outs)
+{
+    if (l_bits / 8 > CAPY_MAX_OUT_LEN) return fail(CAPY_ERR_ARG, "output longer than 2^32 - 1 bytes per item (l_bits >= 2^35)");
+    if (!valid_d(d)) return fail(CAPY_ERR_UNSUPPORTED_SECPARAM, "unsupported security parameter");
+    if (n == 0) return CAPY_OK;
+    if (!outs) return fail(CAPY_ERR_ARG, "null argument");
+    CAPY_SHARD(n, offsets,
+               capy_kmac_xof_batch(d, count, key_offsets ? keys : keys + first * key_len, key_len,
+                                   key_offsets ? key_offsets + first : nullptr, xs, offsets ? offsets + first : nullptr,
+                                   l_bits, custom, custom_len, outs + first * (l_bits / 8)));
+    std::vector<uint64_t> zero_off;
+    if (!offsets) {  // every x_i empty
+        zero_off.assign(n + 1, 0);
+        offsets = zero_off.data();
+    }
+    PackedBatch b;
+    int rc = b.upload(n, xs, offsets);
+    if (rc) return rc;
+    PackedKeys k;
+    rc = k.upload(n, keys, key_len, key_offsets);
+    if (rc) return rc;
+    DevBuf out;
+    const size_t ol = l_bits / 8, os = (ol + 7) & ~(size_t)7;
+    CAPY_HIP(out.alloc(n * os));
+    rc = kmac_launch(d, n, k.view, view_of(b), true, custom, custom_len, 0, out.as<uint8_t>(), os, ol, nullptr, nullptr);
+    if (rc) return rc;
+    if (ol) CAPY_HIP(copy_rows_out(outs, ol, out, os, n));
+    return CAPY_OK;
+}
+
+// ---------------------------------------------------------------- sha3_encrypt / sha3_decrypt
+static KeyView dev_keys(const uint8_t *pws, size_t pw_len, const uint64_t *pw_offsets)
+{
+    KeyView kv = fixed_keys(pws, pw_len, pw_len);
+    kv.key_offsets = pw_offsets;
+    return kv;
+}
+
+int capy_sha3_encrypt_batch_dev(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint64_t *pw_offsets,
+                                uint64_t pws_bytes, const uint8_t *zs, uint8_t *msgs, const uint64_t *offsets,
+                                uint64_t uniform_len, uint64_t msg_stride, uint8_t *tags, void *stream)
+{
+    if (n) {
+        CAPY_REQUIRE(zs && tags, "zs / tags");
+        CAPY_REQUIRE(keys_ok(pws, pw_len, pw_offsets), "pws");
+        CAPY_REQUIRE(msgs_ok(msgs, offsets, uniform_len), "msgs");
+    }
+    return sha3_crypt_dev(true, d, n, dev_keys(pws, pw_len, pw_offsets), pws_bytes, zs,
+                          view_dev(msgs, offsets, uniform_len, msg_stride), tags, nullptr, (hipStream_t)stream);
+}
+
+int capy_sha3_decrypt_batch_dev(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint64_t *pw_offsets,
+                                uint64_t pws_bytes, const uint8_t *zs, uint8_t *msgs, const uint64_t *offsets,
+                                uint64_t uniform_len, uint64_t msg_stride, const uint8_t *tags, int32_t *status,
+                                void *stream)
+{
+    if (n) {
+        CAPY_REQUIRE(zs && tags && status, "zs / tags / status");
+        CAPY_REQUIRE(keys_ok(pws, pw_len, pw_offsets), "pws");
+        CAPY_REQUIRE(msgs_ok(msgs, offsets, uniform_len), "msgs");
+    }
+    return sha3_crypt_dev(false, d, n, dev_keys(pws, pw_len, pw_offsets), pws_bytes, zs,
+                          view_dev(msgs, offsets, uniform_len, msg_stride), const_cast<uint8_t *>(tags), status,
+                          (hipStream_t)stream);
+}
+
+static int sha3_crypt_host(bool encrypt, int d, size_t n, const uint8_t *pws, size_t pw_len, const uint64_t *pw_offsets,
+                           const uint8_t *zs, uint8_t *msgs, const uint64_t *offsets, uint8_t *tags, int32_t *status,
+                           const char *ke_custom = "SKE", const char *ka_custom = "SKA")
+{
+    if (!valid_d(d)) return fail(CAPY_ERR_UNSUPPORTED_SECPARAM, "unsupported security parameter");
+    if (n == 0) return CAPY_OK;
+    if (!offsets || !zs || !tags) return fail(CAPY_ERR_ARG, "null argument");
+    CAPY_SHARD(n, offsets,
+               sha3_crypt_host(encrypt, d, count, pw_offsets ? pws : pws + first * pw_len, pw_len,
+                               pw_offsets ? pw_offsets + first : nullptr, zs + first * 512, msgs, offsets + first,
+                               tags + first * 64, status ? status + first : nullptr, ke_custom, ka_custom));
+    PackedBatch b;
+    b.msgs.secret = !encrypt;  // decryption leaves plaintext in the staging block: zeroed before it is reused
+    int rc = b.upload(n, msgs, offsets);
+    if (rc) return rc;
+    PackedKeys dpw;
+    rc = dpw.upload(n, pws, pw_len, pw_offsets);
+    if (rc) return rc;
+    DevBuf dz, dtag, dst;
+    CAPY_HIP(dz.alloc(n * 512));
+    CAPY_HIP(dtag.alloc(n * 64));
+    CAPY_HIP(dst.alloc(n * 4));
+    CAPY_HIP(dz.put(zs, n * 512));
+    if (!encrypt) CAPY_HIP(dtag.put(tags, n * 64));
+    rc = sha3_crypt_dev(encrypt, d, n, dpw.view, dpw.total, dz.as<uint8_t>(), view_of(b), dtag.as<uint8_t>(),
+                        dst.as<int32_t>(), nullptr, ke_custom, ka_custom);
+    if (rc) return rc;
+    CAPY_HIP(hipStreamSynchronize(nullptr));
+    rc = b.download(n, msgs, offsets);
+    if (rc) return rc;
+    if (encrypt)
+        CAPY_HIP(dtag.get(tags, n * 64));
+    else
+        CAPY_HIP(dst.get(status, n * 4));
+    return CAPY_OK;
+}
+
+int capy_sha3_encrypt_batch(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint64_t *pw_offsets,
+                            const uint8_t *zs, uint8_t *msgs, const uint64_t *offsets, uint8_t *tags)
+{
+    return sha3_crypt_host(true, d, n, pws, pw_len, pw_offsets, zs, msgs, offsets, tags, nullptr);
+}
+
+int capy_sha3_decrypt_batch(int d, size_t n, const uint8_t *pws, size_t pw_len, const uint64_t *pw_offsets,
+                            const uint8_t *zs, uint8_t *msgs, const uint64_t *offsets, const uint8_t *tags, int32_t *status)
+{
+    if (!status) return fail(CAPY_ERR_ARG, "null status");
+    return sha3_crypt_host(false, d, n, pws, pw_len, pw_offsets, zs, msgs, offsets, const_cast<uint8_t *>(tags), status);
+}
+
+// ---------------------------------------------------------------- KEMEncryptable, sponge half
+int capy_kem_sponge_encrypt_batch(int d, size_t n, const uint8_t *secrets, size_t secret_len, const uint8_t *zs,
+                                  uint8_t *msgs, const uint64_t *offsets, uint8_t *tags)
+{
+    return sha3_crypt_host(true, d, n, secrets, secret_len, nullptr, zs, msgs, offsets, tags, nullptr, "KEMKE", "KEMKA");
+}
+
+int capy_kem_sponge_decrypt_batch(int d, size_t n, const uint8_t *secrets, size_t secret_len, const uint8_t *zs,
+                                  uint8_t *msgs, const uint64_t *offsets, const uint8_t *tags, int32_t *status)
+{
+    if (!status) return fail(CAPY_ERR_ARG, "null status");
+    return sha3_crypt_host(false, d, n, secrets, secret_len, nullptr, zs, msgs, offsets, const_cast<uint8_t *>(tags),
+                           status, "KEMKE", "KEMKA");
+}
+
+int capy_kem_sponge_encrypt_batch_dev(int d, size_t n, const uint8_t *secrets, size_t secret_len, const uint8_t *zs,
+                                      uint8_t *msgs, const uint64_t *offsets, uint64_t uniform_len, uint64_t msg_stride,
+                                      uint8_t *tags, void *stream)
+{
+    if (n) {
+        CAPY_REQUIRE(zs && tags, "zs / tags");
+        CAPY_REQUIRE(keys_ok(secrets, secret_len, nullptr), "secrets");
+        CAPY_REQUIRE(msgs_ok(msgs, offsets, uniform_len), "msgs");
+    }
+    return sha3_crypt_dev(true, d, n, dev_keys(secrets, secret_len, nullptr), 0, zs, view_dev(msgs, offsets, uniform_len, msg_stride),
+                          tags, nullptr, (hipStream_t)stream, "KEMKE", "KEMKA");
+}
+
+int capy_kem_sponge_decrypt_batch_dev(int d, size_t n, const uint8_t *secrets, size_t secret_len, const uint8_t *zs,
+                                      uint8_t *msgs, const uint64_t *offsets, uint64_t uniform_len, uint64_t msg_stride,
+                                      const uint8_t *tags, int32_t *status, void *stream)
+{
+    if (n) {
+        CAPY_REQUIRE(zs && tags && status, "zs / tags / status");
+        CAPY_REQUIRE(keys_ok(secrets, secret_len, nullptr), "secrets");
+        CAPY_REQUIRE(msgs_ok(msgs, offsets, uniform_len), "msgs");
+    }
+    return sha3_crypt_dev(false, d, n, dev_keys(secrets, secret_len, nullptr), 0, zs, view_dev(msgs, offsets, uniform_len, msg_stride),
+                          const_cast<uint8_t *>(tags), status, (hipStream_t)stream, "KEMKE", "KEMKA");
+}
+
+}  // extern "C"

@@ -42,7 +42,7 @@ struct OptScope {
 
 // Debug / A-B knobs (r04: ONE environment variable, parsed once when the library first needs a knob):
 //   CAPY_DEBUG="key=value,key=value,..."   e.g. CAPY_DEBUG="uniform_waves=3,fused_max=65536"
-// keys: fused_max, wide_max, mixed_ratio, uniform_waves (sponge launch thresholds); ed448_pair (0 / 1), ed448_wave_max,
+// keys: fused_max, wide_max, mixed_ratio, uniform_waves, rot (0), rot_ratio (sponge launch thresholds); ed448_pair (0 / 1), ed448_wave_max,
 // host_overlap (0), host_arena (0), worker_affinity (0).  Unknown keys are reported once on stderr.  A knob that is not
 // set returns `dflt`.  These are measurement switches, not product settings (those are function arguments / call options).
 double debug_knob(const char *key, double dflt);
@@ -130,6 +130,11 @@ void *workspace(hipStream_t stream, WsSlot slot, size_t bytes);  // nullptr on a
 void workspace_release();                                           // free this thread's scratch (synchronises)
 void workspace_scrub(hipStream_t stream, WsSlot slot, size_t bytes);  // zero a slot's first bytes, stream-ordered
 void workspace_scrub_many(hipStream_t stream, const WsSlot *slots, const size_t *bytes, int count);  // the same, one launch
+// a slot of the calling thread's scratch as a typed pointer, or return CAPY_ERR_HIP from the enclosing function
+#define CAPY_WS(var, type, stream, slot, bytes)                                      \
+    type var = reinterpret_cast<type>(capy::workspace(stream, slot, bytes));          \
+    if (!var) return capy::fail(CAPY_ERR_HIP, "workspace allocation failed")
+
 // Scrubs the named slots when the enclosing function returns -- on EVERY path, also the early error returns (a failed
 // launch must not leave z || pw, ke || ka, a secret scalar or an ECDH point behind in scratch that later calls reuse).
 struct WsScrubGuard {

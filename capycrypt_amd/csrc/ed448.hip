@@ -12,9 +12,6 @@
 
 namespace capy {
 
-#define CAPY_WS(var, type, stream, slot, bytes)                                 \
-    type var = reinterpret_cast<type>(capy::workspace(stream, slot, bytes));     \
-    if (!var) return capy::fail(CAPY_ERR_HIP, "workspace allocation failed")
 
 // ------------------------------------------------------------------ kernels (one item per lane)
 #ifndef CAPY_ED448_WAVES

@@ -40,6 +40,31 @@ struct PackedKeys {
     int upload(size_t n, const uint8_t *keys, size_t key_len, const uint64_t *offsets);
 };
 
+// ---- sponge_launch.hip
+// SHA3-d / cSHAKE over device buffers; sha3_encrypt / sha3_decrypt composition (ke_custom / ka_custom: "SKE" / "SKA",
+// "KEMKE" / "KEMKA" for the KEM sponge half)
+int sha3_launch(int d, size_t n, const MsgView &m, uint8_t *digests, uint64_t out_stride, hipStream_t s);
+int cshake_launch(int d, size_t n, const MsgView &m, size_t l_bits, const uint8_t *fn, size_t fn_len, const uint8_t *cs,
+                  size_t cs_len, uint8_t *outs, uint64_t out_stride, hipStream_t s, bool body_has_trailer = false);
+int sha3_crypt_dev(bool encrypt, int d, size_t n, const KeyView &pw, uint64_t pws_bytes, const uint8_t *zs, const MsgView &m,
+                   uint8_t *tags, int32_t *status, hipStream_t s, const char *ke_custom = "SKE", const char *ka_custom = "SKA");
+unsigned sponge_debug_flags();  // the A/B bits of capy_set_sponge_lanes
+// Dispatch order of the 64-item groups of a length-sorted ragged batch: rank-major over the full neighbourhoods of
+// 4096 items -- first every neighbourhood's longest group, then every second-longest, ... (longest-processing-time first
+// for the grid as a whole, while each group still reads from one neighbourhood).  Shared by the device sort
+// (sponge_launch.hip) and the host sort of PackedBatch::upload (workspace.hip).
+constexpr int ORDER_CHUNK_SHIFT = 12;
+__host__ __device__ __forceinline__ uint32_t order_spread(uint32_t pos, uint64_t n)
+{
+    const uint32_t full = (uint32_t)(n >> ORDER_CHUNK_SHIFT);  // complete neighbourhoods
+    const uint32_t c = pos >> ORDER_CHUNK_SHIFT;
+    if (c >= full) return pos;  // partial last neighbourhood: plain sorted order, at the end
+    const uint32_t r = (pos >> 6) & 63u;
+    return ((r * full + c) << 6) + (pos & 63u);
+}
+// ---- workspace.hip
+hipError_t copy_rows_out(uint8_t *dst, size_t row, const DevBuf &b, size_t stride, size_t n);
+
 MsgView view_of(const PackedBatch &b);
 MsgView view_dev(const uint8_t *msgs, const uint64_t *offsets, uint64_t uniform_len, uint64_t msg_stride);
 

@@ -17,6 +17,9 @@ hipError_t launch_sponge_k2(int rw, int mode, const SpongeParams &p, hipStream_t
 // one- and two-lane waves side by side, one phase of the rotating schedule (sponge_mixed.h); rw in {9,13,17,18,19,21}
 struct MixedParams;
 hipError_t launch_sponge_mixed(int rw, const MixedParams &q, unsigned waves, hipStream_t s);
+// one phase of the rotating-occupancy schedule for 64 S < n < 128 S sponges (sponge_rot.h); rw in {9,13,17,18,19,21}
+struct RotParams;
+hipError_t launch_sponge_rot(int rw, const RotParams &q, unsigned cus, size_t lds_bytes, hipStream_t s);
 struct FusedParams;
 hipError_t launch_sponge_fused(int rw, const FusedParams &fp, hipStream_t s);
 // digests of very small batches of long messages: two items per wave, a sponge spread over 25 lanes (sponge_wide.h);

@@ -251,6 +251,52 @@ def test_config2_keystream_units(capy, O):
     assert len(set(got)) == len(got)
 
 
+@pytest.mark.parametrize("d,n,L,stride", [(256, 73728, 80000, 80000), (256, 66001, 70001, 70008), (512, 100000, 40003, 40008),
+                                          (384, 120000, 60000, 60000), (224, 81920, 90007, 90008)])
+def test_rotating_occupancy_schedule_matches_one_lane_kernel(capy, sponge_lanes, d, n, L, stride):
+    """r04: uniform digest batches between one and two one-lane waves per SIMD (64 S < n < 128 S) with long messages take
+    the rotating-occupancy schedule (sponge_rot.h: P phase launches of 512-lane workgroups, one per compute unit, a
+    rotating subset of them doubled up, + a resume launch).  Every digest must equal the one-lane kernel's (forced lanes =
+    1: one launch of the paired latency-tuned instance), and hashlib's where the reference is FIPS 202 for that length."""
+    import ctypes as C
+    import hashlib
+
+    import torch
+
+    from capycrypt_amd import _lib
+
+    if sponge_lanes != 1:
+        pytest.skip("sets the kernel choice itself")
+    lib = _lib.lib()
+    msgs = _dev_rand(n * stride, 13)
+    outs = []
+    for lanes in (1, 0):
+        _lib.check(lib.capy_set_sponge_lanes(lanes))
+        kind, phases = C.c_int(0), C.c_int(0)
+        _lib.check(lib.capy_sha3_launch_plan(d, n, L, stride, C.byref(kind), C.byref(phases)))
+        assert (kind.value, phases.value >= 2) == ((8, True) if lanes == 0 else (1, False)), (kind.value, phases.value)
+        dig = torch.zeros(n * (d // 8), dtype=torch.uint8, device="cuda")
+        _lib.check(lib.capy_sha3_batch_dev(d, n, msgs.data_ptr(), None, L, stride, dig.data_ptr(), None))
+        torch.cuda.synchronize()
+        outs.append(dig)
+    assert torch.equal(outs[0], outs[1]), (d, n, L)
+    if d == 256:
+        hd = bytes(outs[1].cpu().numpy())
+        for i in (0, 255, 256, n // 2 + 3, n - 257, n - 1):
+            assert hd[32 * i:32 * i + 32] == hashlib.sha3_256(bytes(msgs[i * stride:i * stride + L].cpu().numpy())).digest(), i
+    # the keyed form (KMACXOF: head blocks by a head-only launch first) against the one-lane kernel
+    keys = _dev_rand(n * 64, 14)
+    ko = []
+    for lanes in (1, 0):
+        _lib.check(lib.capy_set_sponge_lanes(lanes))
+        out = torch.zeros(n * 64, dtype=torch.uint8, device="cuda")
+        _lib.check(lib.capy_kmac_xof_batch_dev(d, n, keys.data_ptr(), 64, 64, None, msgs.data_ptr(), None, L, stride, 512, b"T", 1,
+                                               out.data_ptr(), 64, None))
+        torch.cuda.synchronize()
+        ko.append(out)
+    assert torch.equal(ko[0], ko[1]), (d, n, L, "kmac")
+
+
 @pytest.mark.parametrize("d", [512, 256, 384, 224])
 def test_long_squeeze_leaves_as_whole_lines(capy, O, d):
     """r04: XOF squeezes of at least one 128-byte line per item leave the one-lane kernels as whole lines assembled in
