@@ -4,7 +4,7 @@
 # Writes raw rocprofv3 output under gpurun_out/ and the summaries under profiles/<round>_*.
 # Counter passes are separate runs (rocprofv3 refuses / mis-handles large counter sets; never mix --pmc with traces).
 set -o pipefail
-R=${1:-r03}
+R=${1:-r04}
 export TMPDIR=/tmp
 OUT=gpurun_out
 mkdir -p $OUT profiles
@@ -18,7 +18,7 @@ for C in "FETCH_SIZE" "WRITE_SIZE" \
     timeout -k 10 300 rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_${R}_$n -o pmc -- \
         python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/pmc_$n.log 2>&1 || echo "PMC pass $n failed"
 done
-# two more kernels for the summary: the short-message kernel (2^22 x 64 B) and the wave-per-item
+# two more kernels for the summary: the uniform-framing kernel on short messages (2^22 x 64 B) and the wave-per-item
 # sha3_encrypt kernel on BASELINE config 3 as specified (128 x 5 MiB); SQ counters only
 SQC="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE"
 timeout -k 10 200 rocprofv3 --pmc $SQC --output-format csv -d $OUT/pmc_${R}_short -o pmc -- \
