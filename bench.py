@@ -606,7 +606,9 @@ def main():
                 ach = waves * e["valu_insts_per_wave"] / (ed["kernel_ms"] * 1e-3)
                 clk = e.get("effective_clock_GHz", 2.4)
                 ceil_ = 1024 * clk * 1e9 / 4.0
-                ed["roofline"] = {"bound": "valu (integer multiply-add issue)", "kernel": kn.split("(")[0],
+                ed["roofline"] = {"bound": "valu (32x32+64 multiply-adds; r04: their ENERGY binds, not their issue slots -- 4.6 % "
+                                           "fewer instructions with 8 % more multiply-adds ran no faster, profiles/r04_ed448_fe_trim.txt)",
+                                  "kernel": kn.split("(")[0],
                                   "valu_insts_per_unit": insts_unit, "achieved": ach / 1e9, "unit": "G wave-instructions/s",
                                   "peak": ceil_ / 1e9, "frac": ach / ceil_, "clock_GHz": clk,
                                   "peak_note": "1024 SIMDs x clock / 4 cycles per instruction (single-wave issue rate)",

@@ -145,18 +145,17 @@ def kem_sponge_decrypt_batch(secrets, zs, cts, tags, d):
 
 
 # ------------------------------------------------------------------ Ed448
-def ed448_scalarmul_batch(scalars_be, points_xy):
+def ed448_scalarmul_batch(scalars_be, points_xy, options=None):
     n = len(scalars_be)
     out = (C.c_uint8 * max(1, 112 * n))()
-    L.check(L.lib().capy_ed448_scalarmul_batch(n, _fixed(n, scalars_be, 56, "scalars"),
-                                               _fixed(n, points_xy, 112, "points"), out))
+    _call("capy_ed448_scalarmul_batch", options, n, _fixed(n, scalars_be, 56, "scalars"), _fixed(n, points_xy, 112, "points"), out)
     return _rows(bytes(out), n, 112)
 
 
-def ed448_basemul_batch(scalars_be):
+def ed448_basemul_batch(scalars_be, options=None):
     n = len(scalars_be)
     out = (C.c_uint8 * max(1, 112 * n))()
-    L.check(L.lib().capy_ed448_basemul_batch(n, _fixed(n, scalars_be, 56, "scalars"), out))
+    _call("capy_ed448_basemul_batch", options, n, _fixed(n, scalars_be, 56, "scalars"), out)
     return _rows(bytes(out), n, 112)
 
 
@@ -190,6 +189,26 @@ def ed448_set_scalar_star(mode):
 
 
 HARDEN_OFF, HARDEN_ALL, HARDEN_PROTOCOL = L.CAPY_HARDEN_OFF, L.CAPY_HARDEN_ALL, L.CAPY_HARDEN_PROTOCOL
+CallOptions = L.CallOptions  # per-call options (capy_call_options): hardened, scalar_star, generator, stream
+
+
+def _call(name, options, *args):
+    """name(*args), or name + "_ex"(*args, &options) when per-call options are given (include/capyhip.h, r04)."""
+    if options is None:
+        L.check(getattr(L.lib(), name)(*args))
+    else:
+        if not isinstance(options, L.CallOptions):
+            raise TypeError("options must be a capycrypt_amd.ops.CallOptions")
+        L.check(getattr(L.lib(), name + "_ex")(*args, C.byref(options)))
+
+
+def ed448_generator_create(xy):
+    """Register a further generator (a point of the prime order r) -> handle for CallOptions(generator=handle)."""
+    if len(bytes(xy)) != 112:
+        raise ValueError("the generator is 112 bytes (affine x || y, little-endian)")
+    h = C.c_int(-1)
+    L.check(L.lib().capy_ed448_generator_create(L.buf(xy), C.byref(h)))
+    return h.value
 
 
 def ed448_set_hardened(mode):
@@ -212,17 +231,17 @@ def ed448_get_generator():
     return bytes(out)
 
 
-def keypair_batch(pws, d):
+def keypair_batch(pws, d, options=None):
     """KeyPair::new, /root/reference/src/ecc/keypair.rs:41-51 -> public keys; one password per key, any lengths."""
     d = _d(d)
     n = len(pws)
     pbuf, plen, poffs = _keys(n, pws, "passwords")
     out = (C.c_uint8 * max(1, 112 * n))()
-    L.check(L.lib().capy_keypair_batch(d, n, pbuf, plen, poffs, out))
+    _call("capy_keypair_batch", options, d, n, pbuf, plen, poffs, out)
     return _rows(bytes(out), n, 112)
 
 
-def schnorr_sign_batch(pws, msgs, d):
+def schnorr_sign_batch(pws, msgs, d, options=None):
     """Signable::sign, /root/reference/src/ecc/signable.rs:40-57 -> [(h, z)]."""
     d = _d(d)
     n = len(msgs)
@@ -230,44 +249,43 @@ def schnorr_sign_batch(pws, msgs, d):
     data, offs = L.pack(msgs)
     h = (C.c_uint8 * max(1, 56 * n))()
     z = (C.c_uint8 * max(1, 56 * n))()
-    L.check(L.lib().capy_schnorr_sign_batch(d, n, pbuf, plen, poffs, data, offs, h, z))
+    _call("capy_schnorr_sign_batch", options, d, n, pbuf, plen, poffs, data, offs, h, z)
     return list(zip(_rows(bytes(h), n, 56), _rows(bytes(z), n, 56)))
 
 
-def schnorr_verify_batch(pubs, msgs, sigs, d):
+def schnorr_verify_batch(pubs, msgs, sigs, d, options=None):
     """Signable::verify, /root/reference/src/ecc/signable.rs:72-86 -> ok flags."""
     d = _d(d)
     n = len(msgs)
     _count(n, sigs, "signatures")
     data, offs = L.pack(msgs)
     status = (C.c_int32 * max(1, n))()
-    L.check(L.lib().capy_schnorr_verify_batch(d, n, _fixed(n, pubs, 112, "public keys"), data, offs,
-                                              _fixed(n, [s[0] for s in sigs], 56, "signature hashes"),
-                                              _fixed(n, [s[1] for s in sigs], 56, "signature scalars"), status))
+    _call("capy_schnorr_verify_batch", options, d, n, _fixed(n, pubs, 112, "public keys"), data, offs,
+          _fixed(n, [s[0] for s in sigs], 56, "signature hashes"), _fixed(n, [s[1] for s in sigs], 56, "signature scalars"), status)
     return [status[i] == 0 for i in range(n)]
 
 
-def key_encrypt_batch(pubs, k_rands, msgs, d):
+def key_encrypt_batch(pubs, k_rands, msgs, d, options=None):
     """KeyEncryptable::key_encrypt, /root/reference/src/ecc/encryptable.rs:34-50 -> (ciphertexts, Z points, tags)."""
     d = _d(d)
     n = len(msgs)
     data, offs = L.pack(msgs)
     zxy = (C.c_uint8 * max(1, 112 * n))()
     tags = (C.c_uint8 * max(1, 56 * n))()
-    L.check(L.lib().capy_key_encrypt_batch(d, n, _fixed(n, pubs, 112, "public keys"), _fixed(n, k_rands, 56, "nonces"),
-                                           data, offs, zxy, tags))
+    _call("capy_key_encrypt_batch", options, d, n, _fixed(n, pubs, 112, "public keys"), _fixed(n, k_rands, 56, "nonces"), data, offs,
+          zxy, tags)
     raw = bytes(data)
     return ([raw[offs[i]:offs[i + 1]] for i in range(n)], _rows(bytes(zxy), n, 112), _rows(bytes(tags), n, 56))
 
 
-def key_decrypt_batch(pws, zxys, cts, tags, d):
+def key_decrypt_batch(pws, zxys, cts, tags, d, options=None):
     """KeyEncryptable::key_decrypt, /root/reference/src/ecc/encryptable.rs:72-94 -> (messages, ok flags)."""
     d = _d(d)
     n = len(cts)
     pbuf, plen, poffs = _keys(n, pws, "passwords")
     data, offs = L.pack(cts)
     status = (C.c_int32 * max(1, n))()
-    L.check(L.lib().capy_key_decrypt_batch(d, n, pbuf, plen, poffs, _fixed(n, zxys, 112, "nonce points"), data, offs,
-                                           _fixed(n, tags, 56, "tags"), status))
+    _call("capy_key_decrypt_batch", options, d, n, pbuf, plen, poffs, _fixed(n, zxys, 112, "nonce points"), data, offs,
+          _fixed(n, tags, 56, "tags"), status)
     raw = bytes(data)
     return [raw[offs[i]:offs[i + 1]] for i in range(n)], [status[i] == 0 for i in range(n)]

@@ -300,3 +300,25 @@ def test_twisted_fixed_base_kernels_on_edge_scalars(capy, O):
     finally:
         capy.ops.ed448_set_hardened(capy.ops.HARDEN_PROTOCOL)
         _lib.check(lib.capy_ed448_set_wave_max(-1))
+
+
+def test_python_mirror_takes_call_options(capy, O):
+    """capycrypt_amd.ops: options=CallOptions(...) routes a helper through the *_ex entry point."""
+    rng = random.Random(0xAB5)
+    n = 20
+    pws = [rng.randbytes(rng.randrange(0, 40)) for _ in range(n)]
+    msgs = [rng.randbytes(rng.randrange(0, 200)) for _ in range(n)]
+    off = capy.ops.CallOptions(hardened=capy.ops.HARDEN_OFF)
+    hard = capy.ops.CallOptions(hardened=capy.ops.HARDEN_ALL)
+    pub = capy.ops.keypair_batch(pws, 384, options=off)
+    assert pub == capy.ops.keypair_batch(pws, 384, options=hard) == capy.ops.keypair_batch(pws, 384)
+    assert pub[:3] == [O.keypair_pub(pw, 384) for pw in pws[:3]]
+    sigs = capy.ops.schnorr_sign_batch(pws, msgs, 384, options=hard)
+    assert sigs == capy.ops.schnorr_sign_batch(pws, msgs, 384, options=off)
+    assert all(capy.ops.schnorr_verify_batch(pub, msgs, sigs, 384, options=off))
+    g2 = O.ed448_basemul((7).to_bytes(56, "big"))
+    h = capy.ops.ed448_generator_create(g2)
+    ks = [rng.randbytes(56) for _ in range(n)]
+    assert capy.ops.ed448_basemul_batch(ks, options=capy.ops.CallOptions(generator=h)) == capy.ops.ed448_scalarmul_batch(ks, [g2] * n)
+    with pytest.raises(TypeError):
+        capy.ops.keypair_batch(pws, 384, options={"hardened": 1})
