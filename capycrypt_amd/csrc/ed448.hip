@@ -8,6 +8,7 @@
 #include "ed448_algo.h"
 #include "ed448_wave.h"
 #include "ed448_fb7.h"
+#include "ed448_quad.h"
 #include "sponge_host.h"
 
 namespace capy {
@@ -54,6 +55,39 @@ __global__ __launch_bounds__(64, CAPY_ED448_WAVES) void vb_kernel(uint64_t n, co
     const Pt P = pt_from_affine_bytes(points_xy + i * point_stride);
     const Pt r = vb_scalarmul(scalars_be + i * scalar_stride, P, table_ws + i * VB_TABLE_DWORDS, pf);
     pt_to_affine_bytes(out_xy + i * 112, r);
+}
+
+// four lanes per item (ed448_quad.h): batches between the one-item-per-wave and the one-item-per-lane kernels
+__global__ __launch_bounds__(64, 2) void vb_quad_kernel(uint64_t n, const uint8_t *scalars_be, uint64_t scalar_stride,
+                                                        const uint8_t *points_xy, uint64_t point_stride, uint8_t *out_xy,
+                                                        uint32_t *table_ws)
+{
+#if defined(__HIP_DEVICE_COMPILE__)  // (the quad primitives are DPP: device pass only)
+    const uint64_t slot = ((uint64_t)blockIdx.x * 64 + threadIdx.x) >> 2;  // the quad's own table slot (n rounded up to 16 of them)
+    const uint64_t i = slot < n ? slot : n - 1;                            // quads past the batch redo the last item, write nothing
+    const uint32_t q = threadIdx.x & 3;
+    const Fe r = quad::scalarmul(scalars_be + i * scalar_stride, points_xy + i * point_stride, table_ws + slot * VB_TABLE_DWORDS, q);
+    // affine: every lane inverts Z (a serial chain either way), lanes 0 and 1 write x and y
+    const Fe zi = fe_inv_out(quad::fe_perm<2, 2, 2, 2>(r));
+    const Fe c = fe_mul(r, zi);
+    if (q < 2 && slot < n) fe_to_bytes(out_xy + i * 112 + q * 56, c);
+#endif
+}
+
+// [a]G + [b]P with four lanes per item (the shape of verify, /root/reference/src/ecc/signable.rs:77)
+__global__ __launch_bounds__(64, 2) void dsm_quad_kernel(uint64_t n, const uint8_t *a_be, const uint8_t *b_be, const uint8_t *points_xy,
+                                                         uint8_t *out_xy, uint32_t *table_ws, const uint32_t *gtab)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint64_t slot = ((uint64_t)blockIdx.x * 64 + threadIdx.x) >> 2;
+    const uint64_t i = slot < n ? slot : n - 1;
+    const uint32_t q = threadIdx.x & 3;
+    Fe r = quad::scalarmul(b_be + i * 56, points_xy + i * 112, table_ws + slot * VB_TABLE_DWORDS, q);
+    r = quad::add_fixed_base(r, a_be + i * 56, gtab, q);
+    const Fe zi = fe_inv_out(quad::fe_perm<2, 2, 2, 2>(r));
+    const Fe c = fe_mul(r, zi);
+    if (q < 2 && slot < n) fe_to_bytes(out_xy + i * 112 + q * 56, c);
+#endif
 }
 
 // hardened form: constant-address table lookups (ed448_algo.h: vb_add_digit_ct); also serves [k]G with point_stride 0
@@ -417,20 +451,50 @@ static size_t wave_max_items()
     return env >= 0 ? (size_t)env : (size_t)CAPY_ED448_WAVE_MAX_DEFAULT;
 }
 
+// Four lanes per item (ed448_quad.h) for quad_min < n <= quad_max public-scalar multiplications: below, a wave per item is
+// faster still; above, every SIMD holds more than two quad waves and the lane-per-item kernels' throughput wins.
+// CAPY_DEBUG=ed448_quad_min=A,ed448_quad_max=B override (max = 0: never).
+static std::atomic<long> g_quad_min{-1}, g_quad_max{-1};  // capy_ed448_set_quad_range; negative: the defaults
+static size_t quad_min_items()
+{
+    const long f = g_quad_min.load();
+    if (f >= 0) return (size_t)f;
+    static const long v = (long)debug_knob("ed448_quad_min", 4096);
+    return (size_t)(v < 0 ? 0 : v);
+}
+static size_t quad_max_items()
+{
+    const long f = g_quad_max.load();
+    if (f >= 0) return (size_t)f;
+    static const long v = (long)debug_knob("ed448_quad_max", 32768);
+    return (size_t)(v < 0 ? 0 : v);
+}
+
 // secret: the scalars are key material (see harden())
 static int vb_launch(size_t n, const uint8_t *scalars, uint64_t scalar_stride, const uint8_t *points,
                      uint64_t point_stride, uint8_t *out, hipStream_t s, bool secret)
 {
     if (!n) return CAPY_OK;
     const bool ct = harden(secret);
-    t_last_vb_kernel = (ct ? 2 : 1) + (n <= wave_max_items() ? 16 : 0);
-    if (n <= wave_max_items()) {
+    const bool wave_family = n <= wave_max_items() && (ct || n <= quad_min_items() || n > quad_max_items());
+    t_last_vb_kernel = (ct ? 2 : 1) + (wave_family ? 16 : 0);
+    if (wave_family) {
         if (ct)
             hipLaunchKernelGGL(wave::vb_wave_kernel<true>, dim3((unsigned)n), dim3(64), 0, s, (uint64_t)n, scalars, scalar_stride,
                                points, point_stride, out);
         else
             hipLaunchKernelGGL(wave::vb_wave_kernel<false>, dim3((unsigned)n), dim3(64), 0, s, (uint64_t)n, scalars, scalar_stride,
                                points, point_stride, out);
+        CAPY_HIP(hipGetLastError());
+        return CAPY_OK;
+    }
+    // four lanes per item between the two families (indexed lookups only): r04, profiles/r04_ed448_quad.txt
+    if (!ct && n > quad_min_items() && n <= quad_max_items()) {
+        t_last_vb_kernel = 1 + 32;
+        const size_t slots = (n + 15) / 16 * 16;
+        CAPY_WS(qtab, uint32_t *, s, WS_TABLE, slots * VB_TABLE_DWORDS * 4);
+        hipLaunchKernelGGL(vb_quad_kernel, dim3((unsigned)(slots / 16)), dim3(64), 0, s, (uint64_t)n, scalars, scalar_stride, points,
+                           point_stride, out, qtab);
         CAPY_HIP(hipGetLastError());
         return CAPY_OK;
     }
@@ -672,6 +736,13 @@ static int dsm_launch(size_t n, const uint8_t *a, const uint8_t *b, const uint8_
     const uint32_t *gt = nullptr;
     int rc = ensure_gtab(&gt);
     if (rc) return rc;
+    if (n > quad_min_items() && n <= quad_max_items()) {  // four lanes per item (ed448_quad.h)
+        const size_t slots = (n + 15) / 16 * 16;
+        CAPY_WS(qtab, uint32_t *, s, WS_TABLE, slots * VB_TABLE_DWORDS * 4);
+        hipLaunchKernelGGL(dsm_quad_kernel, dim3((unsigned)(slots / 16)), dim3(64), 0, s, (uint64_t)n, a, b, points, out, qtab, gt);
+        CAPY_HIP(hipGetLastError());
+        return CAPY_OK;
+    }
     if (n <= wave_max_items()) {
         hipLaunchKernelGGL(wave::dsm_wave_kernel, dim3((unsigned)n), dim3(64), 0, s, (uint64_t)n, a, b, points, out, gt);
         CAPY_HIP(hipGetLastError());
@@ -928,6 +999,13 @@ int capy_ed448_add_batch(size_t n, const uint8_t *p_xy, const uint8_t *q_xy, uin
 int capy_ed448_set_wave_max(long max_items)
 {
     g_wave_max.store(max_items < 0 ? -1 : max_items);
+    return CAPY_OK;
+}
+
+int capy_ed448_set_quad_range(long min_items, long max_items)
+{
+    g_quad_min.store(min_items < 0 ? -1 : min_items);
+    g_quad_max.store(max_items < 0 ? -1 : max_items);
     return CAPY_OK;
 }
 

@@ -255,6 +255,12 @@ int capy_ed448_set_hardened(int mode);
  * batches switch at 5/16 of the value, with constant-address lookups at 7/16).  0 = never, negative = the built-in
  * default (8192).  Results are bit-identical either way; the constant-address (hardened) forms exist for both. */
 int capy_ed448_set_wave_max(long max_items);
+/* Tuning / A-B switch (process-wide): batches of min_items < n <= max_items public-scalar multiplications (the raw
+ * scalarmul / double_scalarmul calls, verification) take the four-lanes-per-item kernels (csrc/ed448_quad.h: X, Y, Z, T of
+ * the accumulator in the four lanes of a quad, the field multiplications of a formula level side by side; 2.3x lower
+ * latency than one item per lane, less throughput).  Defaults 4096 / 32768 (negative restores them; max = 0: never).
+ * Results are bit-identical either way. */
+int capy_ed448_set_quad_range(long min_items, long max_items);
 
 /* status[i] = CAPY_ITEM_OK iff point i has canonical coordinates (both < p) and lies on the curve.  The multiplication
  * and protocol entry points do NOT validate their point inputs (results for off-curve or non-canonical input are

@@ -322,3 +322,67 @@ def test_python_mirror_takes_call_options(capy, O):
     assert capy.ops.ed448_basemul_batch(ks, options=capy.ops.CallOptions(generator=h)) == capy.ops.ed448_scalarmul_batch(ks, [g2] * n)
     with pytest.raises(TypeError):
         capy.ops.keypair_batch(pws, 384, options={"hardened": 1})
+
+
+def test_four_lanes_per_item_kernels_equal_the_other_families(capy, O):
+    """csrc/ed448_quad.h (r04): batches of 4096 < n <= 32768 public-scalar multiplications put X, Y, Z, T of the accumulator
+    into the four lanes of a quad.  Variable base and the verify-shaped double multiplication must give the bytes of the
+    lane-per-item / wave-per-item kernels (capy_ed448_set_quad_range(0, 0) switches the family off) at sizes with full
+    and ragged last waves, on edge scalars (0, 1, r - 1, r, 2^448 - 1), the identity, a point of order 2 and random points;
+    a sample is checked against the oracle, and the protocol call that uses it (verify) accepts what sign produced."""
+    import torch
+
+    from capycrypt_amd import _lib
+
+    lib = _lib.lib()
+    rng = random.Random(0xAB6)
+    sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = (1 << 448) - (1 << 224) - 1
+    ident = (0).to_bytes(56, "little") + (1).to_bytes(56, "little")
+    order2 = (0).to_bytes(56, "little") + (p - 1).to_bytes(56, "little")
+    edge_k = [0, 1, 2, R - 1, R, R + 1, (1 << 448) - 1, 1 << 447]
+    fam = C.c_int(0)
+    try:
+        for n in (4097, 9000, 16384, 32768):
+            sc = torch.empty(n * 56, dtype=torch.uint8, device="cuda")
+            asc = torch.empty(n * 56, dtype=torch.uint8, device="cuda")
+            tsc = torch.empty(n * 56, dtype=torch.uint8, device="cuda")
+            for t, seed in ((sc, 1), (asc, 2), (tsc, 3)):
+                _lib.check(lib.capy_fill_random_dev(t.data_ptr(), n * 56, 500 + seed + n, sp))
+            eb = torch.tensor(list(b"".join(k.to_bytes(56, "big") for k in edge_k)), dtype=torch.uint8, device="cuda")
+            sc[:eb.numel()] = eb
+            sc[(n - len(edge_k)) * 56:] = eb
+            pts = torch.empty(n * 112, dtype=torch.uint8, device="cuda")
+            _lib.check(lib.capy_ed448_set_quad_range(0, 0))
+            _lib.check(lib.capy_ed448_basemul_batch_dev(n, tsc.data_ptr(), pts.data_ptr(), sp))
+            special = torch.tensor(list(ident + order2), dtype=torch.uint8, device="cuda")
+            pts[8 * 112:10 * 112] = special
+            outs = {}
+            for name, rng_ in (("other", (0, 0)), ("quad", (-1, -1))):
+                _lib.check(lib.capy_ed448_set_quad_range(*rng_))
+                vb = torch.zeros(n * 112, dtype=torch.uint8, device="cuda")
+                ds = torch.zeros(n * 112, dtype=torch.uint8, device="cuda")
+                _lib.check(lib.capy_ed448_scalarmul_batch_dev(n, sc.data_ptr(), pts.data_ptr(), vb.data_ptr(), sp))
+                lib.capy_debug_last_curve_kernel(C.byref(fam), None)
+                assert (fam.value == 33) == (name == "quad"), (n, name, fam.value)
+                _lib.check(lib.capy_ed448_double_scalarmul_batch_dev(n, asc.data_ptr(), sc.data_ptr(), pts.data_ptr(), ds.data_ptr(), sp))
+                torch.cuda.synchronize()
+                outs[name] = (vb, ds)
+            assert torch.equal(outs["other"][0], outs["quad"][0]), n
+            assert torch.equal(outs["other"][1], outs["quad"][1]), n
+            hs, hp, hv = bytes(sc.cpu().numpy()), bytes(pts.cpu().numpy()), bytes(outs["quad"][0].cpu().numpy())
+            for i in list(range(0, 10)) + [n // 2, n - 3, n - 1]:
+                assert hv[112 * i:112 * i + 112] == O.ed448_scalarmul(hs[56 * i:56 * i + 56], hp[112 * i:112 * i + 112]), (n, i)
+        # verify (double multiplication inside the protocol call) on a batch in the quad range
+        n = 5000
+        pws = [rng.randbytes(16) for _ in range(n)]
+        msgs = [rng.randbytes(40) for _ in range(n)]
+        pub = capy.ops.keypair_batch(pws, 256)
+        sigs = capy.ops.schnorr_sign_batch(pws, msgs, 256)
+        ok = capy.ops.schnorr_verify_batch(pub, msgs, sigs, 256)
+        assert all(ok)
+        sigs[7] = (sigs[7][0], bytes(56))
+        ok = capy.ops.schnorr_verify_batch(pub, msgs, sigs, 256)
+        assert not ok[7] and sum(ok) == n - 1
+    finally:
+        _lib.check(lib.capy_ed448_set_quad_range(-1, -1))
