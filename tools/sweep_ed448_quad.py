@@ -1,10 +1,9 @@
 #!/usr/bin/env python3
-"""Variable-base multiplication over batch sizes in and around the regime of the four-lanes-per-item kernel
-(csrc/ed448_quad.h): ms per call and a digest of the outputs, so that two runs -- CAPY_DEBUG=ed448_quad_max=0 (never) against
-CAPY_DEBUG=ed448_quad_min=0,ed448_quad_max=100000000 (always) -- can be compared line by line.
-usage: python3 tools/sweep_ed448_quad.py [n ...]"""
+"""Variable-base multiplication and the verify-shaped double multiplication over batch sizes in and around the regime of
+the four-lanes-per-item kernels (csrc/ed448_quad.h), family off (capy_ed448_set_quad_range(0, 0)) against forced on
+(capy_ed448_set_quad_range(0, 2^30)): ms per call, and whether the outputs are byte-identical.
+usage: python3 tools/sweep_ed448_quad.py [n ...]   -> profiles/r04_ed448_quad.txt"""
 import ctypes as C
-import hashlib
 import os
 import sys
 
@@ -17,30 +16,41 @@ lib = _lib.lib()
 dev = torch.device("cuda", 0)
 st = torch.cuda.current_stream()
 sp = C.c_void_p(st.cuda_stream)
-ns = [int(a) for a in sys.argv[1:]] or [1024, 2048, 3072, 4096, 6144, 8192, 12288, 16384, 24576, 32768, 40960, 49152, 65536]
+ns = [int(a) for a in sys.argv[1:]] or [1024, 2048, 4096, 6144, 8192, 12288, 16384, 24576, 32768, 40960, 49152, 65536]
 nmax = max(ns)
-sc = torch.empty(nmax * 56, dtype=torch.uint8, device=dev)
-tsc = torch.empty(nmax * 56, dtype=torch.uint8, device=dev)
-_lib.check(lib.capy_fill_random_dev(sc.data_ptr(), nmax * 56, 4, sp))
-_lib.check(lib.capy_fill_random_dev(tsc.data_ptr(), nmax * 56, 41, sp))
+sc, asc, tsc = (torch.empty(nmax * 56, dtype=torch.uint8, device=dev) for _ in range(3))
+for t, seed in ((sc, 4), (asc, 5), (tsc, 41)):
+    _lib.check(lib.capy_fill_random_dev(t.data_ptr(), nmax * 56, seed, sp))
 pts = torch.empty(nmax * 112, dtype=torch.uint8, device=dev)
 _lib.check(lib.capy_ed448_basemul_batch_dev(nmax, tsc.data_ptr(), pts.data_ptr(), sp))
-out = torch.empty(nmax * 112, dtype=torch.uint8, device=dev)
-fam = C.c_int(0)
-print("# CAPY_DEBUG=%s" % os.environ.get("CAPY_DEBUG", ""))
-for n in ns:
-    def run():
-        _lib.check(lib.capy_ed448_scalarmul_batch_dev(n, sc.data_ptr(), pts.data_ptr(), out.data_ptr(), sp))
-    run()
+
+
+def timed(fn):
+    fn()
     torch.cuda.synchronize()
     best = 1e9
     for _ in range(3):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(st)
-        run()
+        fn()
         e1.record(st)
         torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1))
-    lib.capy_debug_last_curve_kernel(C.byref(fam), None)
-    dig = hashlib.sha256(bytes(out[:n * 112].cpu().numpy())).hexdigest()[:16]
-    print("n = %6d  %8.3f ms  %7.2f M/s  family %2d  outputs %s" % (n, best, n / best / 1e3, fam.value, dig), flush=True)
+    return best
+
+
+print("#      n | variable base: other ms   quad ms   speed-up | [a]G + [b]P: other ms   quad ms   speed-up | identical")
+for n in ns:
+    res = {}
+    for name, rng in (("other", (0, 0)), ("quad", (0, 1 << 30))):
+        _lib.check(lib.capy_ed448_set_quad_range(*rng))
+        vb = torch.zeros(n * 112, dtype=torch.uint8, device=dev)
+        ds = torch.zeros(n * 112, dtype=torch.uint8, device=dev)
+        t_vb = timed(lambda: _lib.check(lib.capy_ed448_scalarmul_batch_dev(n, sc.data_ptr(), pts.data_ptr(), vb.data_ptr(), sp)))
+        t_ds = timed(lambda: _lib.check(lib.capy_ed448_double_scalarmul_batch_dev(n, asc.data_ptr(), sc.data_ptr(), pts.data_ptr(),
+                                                                                  ds.data_ptr(), sp)))
+        res[name] = (t_vb, t_ds, vb, ds)
+    same = torch.equal(res["other"][2], res["quad"][2]) and torch.equal(res["other"][3], res["quad"][3])
+    o, q = res["other"], res["quad"]
+    print("%8d | %21.3f %9.3f %9.2fx | %20.3f %9.3f %9.2fx | %s" % (n, o[0], q[0], o[0] / q[0], o[1], q[1], o[1] / q[1], same), flush=True)
+_lib.check(lib.capy_ed448_set_quad_range(-1, -1))
