@@ -49,6 +49,14 @@ inline SecParam sec_param_try_from(size_t value)
 inline uint32_t bytepad_value(SecParam d) { return (1600u - (uint32_t)d) / 8u; }  // src/lib.rs:137-144
 
 namespace detail {
+// Per-call options (capy_call_options, include/capyhip.h) for the calling thread: every Ed448 protocol call below goes
+// through the library's *_ex entry point with the options of the innermost live OptionsScope (none: process defaults).
+inline const capy_call_options *&opts_slot()
+{
+    static thread_local const capy_call_options *p = nullptr;
+    return p;
+}
+inline const capy_call_options *opts() { return opts_slot(); }
 inline void check(int rc)
 {
     if (rc == CAPY_ERR_UNSUPPORTED_SECPARAM) throw OperationError("UnsupportedSecurityParameter");
@@ -99,6 +107,16 @@ struct Signature {  // src/ecc/signable.rs:17-24
 
 using Point = Bytes;  // affine (x || y), 2 x 56-byte little-endian; stands in for ExtendedPoint at the boundary
 
+// RAII: the Ed448 protocol calls of this thread run with `o` (hardened mode, Scalar * Scalar reading, generator handle)
+// until the scope ends:  { OptionsScope s(o); msg.sign(key, d); }   Two host threads can hold different options.
+struct OptionsScope {
+    const capy_call_options *saved;
+    explicit OptionsScope(const capy_call_options &o) : saved(detail::opts_slot()) { detail::opts_slot() = &o; }
+    OptionsScope(const OptionsScope &) = delete;
+    OptionsScope &operator=(const OptionsScope &) = delete;
+    ~OptionsScope() { detail::opts_slot() = saved; }
+};
+
 struct KeyPair {  // src/ecc/keypair.rs:11-22
     std::string owner;
     Point pub_key;
@@ -111,7 +129,7 @@ struct KeyPair {  // src/ecc/keypair.rs:11-22
         KeyPair kp;
         kp.owner = owner;
         kp.pub_key.resize(112);
-        detail::check(capy_keypair_batch((int)d, 1, detail::ptr(pw), pw.size(), nullptr, kp.pub_key.data()));
+        detail::check(capy_keypair_batch_ex((int)d, 1, detail::ptr(pw), pw.size(), nullptr, kp.pub_key.data(), detail::opts()));
         kp.priv_key = pw;
         char buf[32];
         std::time_t t = std::time(nullptr);
@@ -181,8 +199,8 @@ struct Message {  // src/lib.rs:63-94; every operation is in place, as in the re
     {  // src/ecc/signable.rs:40-57
         const uint64_t off[2] = {0, msg.size()};
         Signature s{Bytes(56), Bytes(56)};
-        detail::check(capy_schnorr_sign_batch((int)dd, 1, detail::ptr(key.priv_key), key.priv_key.size(), nullptr,
-                                              detail::ptr(msg), off, s.h.data(), s.z.data()));
+        detail::check(capy_schnorr_sign_batch_ex((int)dd, 1, detail::ptr(key.priv_key), key.priv_key.size(), nullptr,
+                                              detail::ptr(msg), off, s.h.data(), s.z.data(), detail::opts()));
         sig = s;
         d = dd;
     }
@@ -194,8 +212,8 @@ struct Message {  // src/lib.rs:63-94; every operation is in place, as in the re
             throw OperationError("SignatureVerificationFailure");
         const uint64_t off[2] = {0, msg.size()};
         int32_t status = 0;
-        detail::check(capy_schnorr_verify_batch((int)*d, 1, pub_key.data(), detail::ptr(msg), off, sig->h.data(),
-                                                sig->z.data(), &status));
+        detail::check(capy_schnorr_verify_batch_ex((int)*d, 1, pub_key.data(), detail::ptr(msg), off, sig->h.data(),
+                                                sig->z.data(), &status, detail::opts()));
         if (status != CAPY_ITEM_OK) throw OperationError("SignatureVerificationFailure");
     }
 
@@ -207,8 +225,8 @@ struct Message {  // src/lib.rs:63-94; every operation is in place, as in the re
         const uint64_t off[2] = {0, msg.size()};
         Point z(112);
         digest.assign(56, 0);
-        detail::check(capy_key_encrypt_batch((int)dd, 1, pub_key.data(), k.data(), detail::ptr(msg), off, z.data(),
-                                             digest.data()));
+        detail::check(capy_key_encrypt_batch_ex((int)dd, 1, pub_key.data(), k.data(), detail::ptr(msg), off, z.data(),
+                                             digest.data(), detail::opts()));
         asym_nonce = z;
     }
     void key_decrypt(const Bytes &pw)
@@ -219,8 +237,8 @@ struct Message {  // src/lib.rs:63-94; every operation is in place, as in the re
         const uint64_t off[2] = {0, msg.size()};
         int32_t status = 0;
         Bytes tag = digest;
-        detail::check(capy_key_decrypt_batch((int)*d, 1, detail::ptr(pw), pw.size(), nullptr, asym_nonce->data(),
-                                             detail::ptr(msg), off, tag.data(), &status));
+        detail::check(capy_key_decrypt_batch_ex((int)*d, 1, detail::ptr(pw), pw.size(), nullptr, asym_nonce->data(),
+                                             detail::ptr(msg), off, tag.data(), &status, detail::opts()));
         if (status != CAPY_ITEM_OK) throw OperationError("KeyDecryptionError");
     }
 };
@@ -354,7 +372,7 @@ inline std::vector<KeyPair> keypair_new_many(const std::vector<Bytes> &pws, cons
 {
     detail::Packed k = detail::pack_bytes(pws);
     Bytes pubs(pws.size() * 112 + 1);
-    detail::check(capy_keypair_batch((int)dd, pws.size(), detail::ptr(k.data), 0, k.offs.data(), pubs.data()));
+    detail::check(capy_keypair_batch_ex((int)dd, pws.size(), detail::ptr(k.data), 0, k.offs.data(), pubs.data(), detail::opts()));
     std::vector<KeyPair> out(pws.size());
     const std::string now = detail::now_string();
     for (size_t i = 0; i < pws.size(); i++) {
@@ -372,8 +390,8 @@ inline void sign_many(const std::vector<Message *> &ms, const std::vector<const 
     detail::Packed p = detail::pack_msgs(ms);
     detail::Packed k = detail::pack(keys.begin(), keys.end(), [](const KeyPair *kp) -> const Bytes & { return kp->priv_key; });
     Bytes h(ms.size() * 56 + 1), z(ms.size() * 56 + 1);
-    detail::check(capy_schnorr_sign_batch((int)dd, ms.size(), detail::ptr(k.data), 0, k.offs.data(), detail::ptr(p.data),
-                                          p.offs.data(), h.data(), z.data()));
+    detail::check(capy_schnorr_sign_batch_ex((int)dd, ms.size(), detail::ptr(k.data), 0, k.offs.data(), detail::ptr(p.data),
+                                          p.offs.data(), h.data(), z.data(), detail::opts()));
     for (size_t i = 0; i < ms.size(); i++) {
         ms[i]->sig = Signature{Bytes(h.begin() + 56 * i, h.begin() + 56 * (i + 1)), Bytes(z.begin() + 56 * i, z.begin() + 56 * (i + 1))};
         ms[i]->d = dd;
@@ -401,8 +419,8 @@ inline std::vector<bool> verify_many(const std::vector<Message *> &ms, const std
         z.insert(z.end(), c.begin(), c.end());
     }
     std::vector<int32_t> st(ms.size(), CAPY_ITEM_FAIL);
-    detail::check(capy_schnorr_verify_batch((int)*ms[0]->d, ms.size(), pk.data(), detail::ptr(p.data), p.offs.data(), h.data(),
-                                            z.data(), st.data()));
+    detail::check(capy_schnorr_verify_batch_ex((int)*ms[0]->d, ms.size(), pk.data(), detail::ptr(p.data), p.offs.data(), h.data(),
+                                            z.data(), st.data(), detail::opts()));
     std::vector<bool> ok(ms.size());
     for (size_t i = 0; i < ms.size(); i++) ok[i] = wellformed[i] && st[i] == CAPY_ITEM_OK;
     return ok;
@@ -422,8 +440,8 @@ inline void key_encrypt_many(const std::vector<Message *> &ms, const std::vector
         ks.insert(ks.end(), k.begin(), k.end());
     }
     Bytes zs(ms.size() * 112 + 1), tags(ms.size() * 56 + 1);
-    detail::check(capy_key_encrypt_batch((int)dd, ms.size(), detail::ptr(pk), detail::ptr(ks), detail::ptr(p.data),
-                                         p.offs.data(), zs.data(), tags.data()));
+    detail::check(capy_key_encrypt_batch_ex((int)dd, ms.size(), detail::ptr(pk), detail::ptr(ks), detail::ptr(p.data),
+                                         p.offs.data(), zs.data(), tags.data(), detail::opts()));
     detail::unpack_msgs(p, ms);
     for (size_t i = 0; i < ms.size(); i++) {
         ms[i]->asym_nonce = Point(zs.begin() + 112 * i, zs.begin() + 112 * (i + 1));
@@ -449,8 +467,8 @@ inline std::vector<bool> key_decrypt_many(const std::vector<Message *> &ms, cons
         tags.insert(tags.end(), t.begin(), t.end());
     }
     std::vector<int32_t> st(ms.size(), CAPY_ITEM_FAIL);
-    detail::check(capy_key_decrypt_batch((int)*ms[0]->d, ms.size(), detail::ptr(k.data), 0, k.offs.data(), zs.data(),
-                                         detail::ptr(p.data), p.offs.data(), tags.data(), st.data()));
+    detail::check(capy_key_decrypt_batch_ex((int)*ms[0]->d, ms.size(), detail::ptr(k.data), 0, k.offs.data(), zs.data(),
+                                         detail::ptr(p.data), p.offs.data(), tags.data(), st.data(), detail::opts()));
     std::vector<bool> ok(ms.size());
     for (size_t i = 0; i < ms.size(); i++) {
         ok[i] = st[i] == CAPY_ITEM_OK && ms[i]->digest.size() == 56 && ms[i]->asym_nonce->size() == 112;

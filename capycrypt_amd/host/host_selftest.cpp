@@ -175,6 +175,15 @@ int main()
         KeyPair k2 = KeyPair::new_(pw, "k", SecParam::D256);
         b.sign(k2, SecParam::D256);
         EXPECT(capy_ed448_set_hardened(2) == CAPY_ERR_ARG && capy_ed448_set_hardened(3) == CAPY_ERR_ARG);  // r03's values: refused
+        // per-call options through the mirror: the same signature with indexed lookups chosen for this scope only
+        {
+            capy_call_options o = CAPY_CALL_OPTIONS_INIT;
+            o.hardened = CAPY_HARDEN_OFF;
+            OptionsScope scope(o);
+            Message c(a.msg);
+            c.sign(k1, SecParam::D256);
+            EXPECT(c.sig->h == a.sig->h && c.sig->z == a.sig->z);
+        }
         EXPECT(capy_ed448_set_hardened(CAPY_HARDEN_PROTOCOL) == CAPY_OK);
         EXPECT(k1.pub_key == k2.pub_key && a.sig->h == b.sig->h && a.sig->z == b.sig->z);
         b.verify(k1.pub_key);
