@@ -72,6 +72,7 @@ SIGNATURES = {
     "capy_ed448_set_hardened": (C.c_int, [C.c_int]),
     "capy_ed448_set_wave_max": (C.c_int, [C.c_long]),
     "capy_ed448_set_quad_range": (C.c_int, [C.c_long, C.c_long]),
+    "capy_ed448_set_duo_range": (C.c_int, [C.c_long, C.c_long]),
     "capy_ed448_set_generator": (C.c_int, [vp]),
     "capy_ed448_get_generator": (C.c_int, [vp]),
     "capy_ed448_set_scalar_star": (C.c_int, [C.c_int]),

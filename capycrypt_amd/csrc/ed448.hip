@@ -9,6 +9,7 @@
 #include "ed448_wave.h"
 #include "ed448_fb7.h"
 #include "ed448_quad.h"
+#include "ed448_duo.h"
 #include "sponge_host.h"
 
 namespace capy {
@@ -90,6 +91,49 @@ __global__ __launch_bounds__(64, 2) void dsm_quad_kernel(uint64_t n, const uint8
 #endif
 }
 
+// four lanes per item with constant-address lookups, the table in LDS (ed448_quad.h): secret scalars, 4 k .. 32 k items
+__global__ __launch_bounds__(64, 1) void vb_quad_ct_kernel(uint64_t n, const uint8_t *scalars_be, uint64_t scalar_stride,
+                                                           const uint8_t *points_xy, uint64_t point_stride, uint8_t *out_xy)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ uint32_t tab[quad::QUAD_CT_LDS_DWORDS];
+    const uint64_t slot = ((uint64_t)blockIdx.x * 64 + threadIdx.x) >> 2;
+    const uint64_t i = slot < n ? slot : n - 1;  // quads past the batch redo the last item, write nothing
+    const uint32_t q = threadIdx.x & 3;
+    const Fe r = quad::scalarmul_ct(scalars_be + i * scalar_stride, points_xy + i * point_stride, tab, q);
+    const Fe zi = fe_inv_out(quad::fe_perm<2, 2, 2, 2>(r));
+    const Fe c = fe_mul(r, zi);
+    if (q < 2 && slot < n) fe_to_bytes(out_xy + i * 112 + q * 56, c);
+#endif
+}
+
+// two lanes per item (ed448_duo.h): 16 k .. 32 k items, one wave of 32 items per SIMD at 32 768
+__global__ __launch_bounds__(64, 1) void vb_duo_kernel(uint64_t n, const uint8_t *scalars_be, uint64_t scalar_stride,
+                                                       const uint8_t *points_xy, uint64_t point_stride, uint8_t *out_xy,
+                                                       uint32_t *table_ws)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint64_t slot = ((uint64_t)blockIdx.x * 64 + threadIdx.x) >> 1;  // the pair's own table slot (n rounded up to 32 of them)
+    const uint64_t i = slot < n ? slot : n - 1;                            // pairs past the batch redo the last item, write nothing
+    const bool p = threadIdx.x & 1;
+    const duo::Half r = duo::scalarmul(scalars_be + i * scalar_stride, points_xy + i * point_stride, table_ws + slot * VB_TABLE_DWORDS, p);
+    duo::store_affine(out_xy + i * 112, r, p, slot < n);
+#endif
+}
+
+__global__ __launch_bounds__(64, 1) void dsm_duo_kernel(uint64_t n, const uint8_t *a_be, const uint8_t *b_be, const uint8_t *points_xy,
+                                                        uint8_t *out_xy, uint32_t *table_ws, const uint32_t *gtab)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint64_t slot = ((uint64_t)blockIdx.x * 64 + threadIdx.x) >> 1;
+    const uint64_t i = slot < n ? slot : n - 1;
+    const bool p = threadIdx.x & 1;
+    duo::Half r = duo::scalarmul(b_be + i * 56, points_xy + i * 112, table_ws + slot * VB_TABLE_DWORDS, p);
+    r = duo::add_fixed_base(r, a_be + i * 56, gtab, p);
+    duo::store_affine(out_xy + i * 112, r, p, slot < n);
+#endif
+}
+
 // hardened form: constant-address table lookups (ed448_algo.h: vb_add_digit_ct); also serves [k]G with point_stride 0
 __global__ __launch_bounds__(64, CAPY_ED448_WAVES) void vb_ct_kernel(uint64_t n, const uint8_t *scalars_be, uint64_t scalar_stride,
                                                    const uint8_t *points_xy, uint64_t point_stride, uint8_t *out_xy,
@@ -164,17 +208,14 @@ __global__ __launch_bounds__(64, CAPY_ED448_WAVES) void fb_ct7_pair_kernel(uint6
         r0.Z.l[4 * q] = vz.x, r0.Z.l[4 * q + 1] = vz.y, r0.Z.l[4 * q + 2] = vz.z, r0.Z.l[4 * q + 3] = vz.w;
     }
     r0.T = fe_zero();  // not needed for the conversion
-    if (base + 64 < n) {
-        if constexpr (TW)
-            pt_tw_pair_to_affine_bytes(out_xy + base * 112, out_xy + (base + 64) * 112, r0, r1);
-        else
-            pt_pair_to_affine_bytes(out_xy + base * 112, out_xy + (base + 64) * 112, r0, r1);
-    } else if (base < n) {
-        if constexpr (TW)
-            pt_tw_to_affine_bytes(out_xy + base * 112, r0);
-        else
-            pt_to_affine_bytes(out_xy + base * 112, r0);
-    }
+    // No predicate on the stores: lanes past the batch hold the last item (i0) and a missing second item repeats the first
+    // (i1 = i0), so they write bytes that are already there.  (With the stores under two nested lane masks the register
+    // allocator parks the second store's address in a register that held scalar-derived limbs on the path around the first
+    // block: harmless -- those lanes are off -- but the static constant-address check cannot tell, tools/ct_taint.py.)
+    if constexpr (TW)
+        pt_tw_pair_to_affine_bytes(out_xy + i0 * 112, out_xy + i1 * 112, r0, r1);
+    else
+        pt_pair_to_affine_bytes(out_xy + i0 * 112, out_xy + i1 * 112, r0, r1);
 #endif
 }
 
@@ -213,57 +254,10 @@ __global__ __launch_bounds__(64, CAPY_ED448_WAVES) void fb_kernel(uint64_t n, co
         pt_to_affine_bytes(out_xy + i * 112, r);
 }
 
-// Two items per lane sharing one inversion (pt_pair_to_affine_bytes): a wave takes 128 consecutive items, lane l the
-// items base + l and base + 64 + l.  The first result waits in LDS (one column per lane) while the second is computed
-// by the same loop body, so the code is not duplicated.  Used when the batch still fills the chip at half the waves.
-struct PtXYZ {
-    uint32_t w[48][64];  // X, Y, Z limbs x lanes
-};
-__device__ __forceinline__ void park_xyz(PtXYZ &s, const Pt &p)
-{
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-        s.w[i][threadIdx.x] = p.X.l[i];
-        s.w[16 + i][threadIdx.x] = p.Y.l[i];
-        s.w[32 + i][threadIdx.x] = p.Z.l[i];
-    }
-}
-__device__ __forceinline__ Pt unpark_xyz(const PtXYZ &s)
-{
-    Pt p;
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-        p.X.l[i] = s.w[i][threadIdx.x];
-        p.Y.l[i] = s.w[16 + i][threadIdx.x];
-        p.Z.l[i] = s.w[32 + i][threadIdx.x];
-        p.T.l[i] = 0;
-    }
-    return p;
-}
-
-__global__ __launch_bounds__(64, CAPY_ED448_WAVES) void vb2_kernel(uint64_t n, const uint8_t *scalars_be, uint64_t scalar_stride,
-                                                 const uint8_t *points_xy, uint64_t point_stride, uint8_t *out_xy,
-                                                 uint32_t *table_ws)
-{
-    __shared__ PtXYZ parked;
-    const uint64_t base = (uint64_t)blockIdx.x * 128 + threadIdx.x;
-    if (base >= n) return;
-    Pt r = pt_identity();
-#pragma unroll 1
-    for (int j = 0; j < 2; j++) {
-        // the second item of a ragged last wave repeats the first (its result is not written)
-        const uint64_t i = (j == 1 && base + 64 < n) ? base + 64 : base;
-        const Pt P = pt_from_affine_bytes(points_xy + i * point_stride);
-        r = vb_scalarmul(scalars_be + i * scalar_stride, P, table_ws + i * VB_TABLE_DWORDS);
-        if (j == 0) park_xyz(parked, r);
-    }
-    const Pt r0 = unpark_xyz(parked);
-    if (base + 64 < n) {
-        pt_pair_to_affine_bytes(out_xy + base * 112, out_xy + (base + 64) * 112, r0, r);
-    } else {
-        pt_to_affine_bytes(out_xy + base * 112, r0);
-    }
-}
+// Two items per lane sharing one inversion: PtXYZ / park_xyz / unpark_xyz (ed448_algo.h).  The variable-base kernel of that
+// shape, vb2_kernel, is compiled in its own translation unit (ed448_vb2.hip) with pinned multiply-add chains.
+int vb2_launch(size_t n, const uint8_t *scalars, uint64_t scalar_stride, const uint8_t *points, uint64_t point_stride, uint8_t *out,
+               uint32_t *table_ws, hipStream_t s);
 
 template <bool CT, bool TW = false>  // CT: gtab is the hardened 5-bit table (VALU scan); TW (indexed only): the twisted table
 __global__ __launch_bounds__(64, CAPY_ED448_WAVES) void fb2_kernel(uint64_t n, const uint8_t *scalars_be, uint8_t *out_xy,
@@ -470,13 +464,42 @@ static size_t quad_max_items()
     return (size_t)(v < 0 ? 0 : v);
 }
 
+// Two lanes per item (ed448_duo.h) for duo_min < n <= duo_max public-scalar multiplications (checked before the quad range):
+// one wave of 32 items per SIMD at 32 768 items, where the quad kernels need two.  CAPY_DEBUG=ed448_duo_min=A,ed448_duo_max=B.
+static std::atomic<long> g_duo_min{-1}, g_duo_max{-1};  // capy_ed448_set_duo_range; negative: the defaults
+static size_t duo_min_items()
+{
+    const long f = g_duo_min.load();
+    if (f >= 0) return (size_t)f;
+    static const long v = (long)debug_knob("ed448_duo_min", 16384);
+    return (size_t)(v < 0 ? 0 : v);
+}
+static size_t duo_max_items()
+{
+    const long f = g_duo_max.load();
+    if (f >= 0) return (size_t)f;
+    static const long v = (long)debug_knob("ed448_duo_max", 32768);
+    return (size_t)(v < 0 ? 0 : v);
+}
+// the constant-address quad kernel (secret scalars): quad_min < n <= this.  One round of waves up to 16 384 items (LDS: four
+// waves per compute unit); beyond, a second round -- still ahead of the one-item-per-lane hardened kernel up to 32 768.
+static size_t quad_ct_max_items()
+{
+    if (g_quad_max.load() >= 0) return (size_t)g_quad_max.load();  // capy_ed448_set_quad_range moves both
+    static const long v = (long)debug_knob("ed448_quad_ct_max", 32768);
+    return (size_t)(v < 0 ? 0 : v);
+}
+static bool duo_range(size_t n) { return n > duo_min_items() && n <= duo_max_items(); }
+static bool quad_range(size_t n) { return !duo_range(n) && n > quad_min_items() && n <= quad_max_items(); }
+
 // secret: the scalars are key material (see harden())
 static int vb_launch(size_t n, const uint8_t *scalars, uint64_t scalar_stride, const uint8_t *points,
                      uint64_t point_stride, uint8_t *out, hipStream_t s, bool secret)
 {
     if (!n) return CAPY_OK;
     const bool ct = harden(secret);
-    const bool wave_family = n <= wave_max_items() && (ct || n <= quad_min_items() || n > quad_max_items());
+    const bool quad_ct = ct && n > quad_min_items() && n <= quad_ct_max_items();
+    const bool wave_family = n <= wave_max_items() && !quad_ct && (ct || !(duo_range(n) || quad_range(n)));
     t_last_vb_kernel = (ct ? 2 : 1) + (wave_family ? 16 : 0);
     if (wave_family) {
         if (ct)
@@ -488,8 +511,26 @@ static int vb_launch(size_t n, const uint8_t *scalars, uint64_t scalar_stride, c
         CAPY_HIP(hipGetLastError());
         return CAPY_OK;
     }
+    // four lanes per item, constant-address lookups in LDS: r04, profiles/r04_ed448_quad_ct.txt
+    if (quad_ct) {
+        t_last_vb_kernel = 2 + 32;
+        hipLaunchKernelGGL(vb_quad_ct_kernel, dim3((unsigned)((n + 15) / 16)), dim3(64), 0, s, (uint64_t)n, scalars, scalar_stride, points,
+                           point_stride, out);
+        CAPY_HIP(hipGetLastError());
+        return CAPY_OK;
+    }
+    // two lanes per item (indexed lookups only): r04, profiles/r04_ed448_duo.txt
+    if (!ct && duo_range(n)) {
+        t_last_vb_kernel = 1 + 64;
+        const size_t slots = (n + 31) / 32 * 32;
+        CAPY_WS(dtab, uint32_t *, s, WS_TABLE, slots * VB_TABLE_DWORDS * 4);
+        hipLaunchKernelGGL(vb_duo_kernel, dim3((unsigned)(slots / 32)), dim3(64), 0, s, (uint64_t)n, scalars, scalar_stride, points,
+                           point_stride, out, dtab);
+        CAPY_HIP(hipGetLastError());
+        return CAPY_OK;
+    }
     // four lanes per item between the two families (indexed lookups only): r04, profiles/r04_ed448_quad.txt
-    if (!ct && n > quad_min_items() && n <= quad_max_items()) {
+    if (!ct && quad_range(n)) {
         t_last_vb_kernel = 1 + 32;
         const size_t slots = (n + 15) / 16 * 16;
         CAPY_WS(qtab, uint32_t *, s, WS_TABLE, slots * VB_TABLE_DWORDS * 4);
@@ -500,7 +541,6 @@ static int vb_launch(size_t n, const uint8_t *scalars, uint64_t scalar_stride, c
     }
     // whole waves: the constant-address table of a wave is interleaved across its 64 lanes
     CAPY_WS(tab, uint32_t *, s, WS_TABLE, (n + 63) / 64 * 64 * VB_TABLE_DWORDS * 4);
-    const dim3 pair_grid((unsigned)((n + 127) / 128));
     if (ct) {
         // one item per lane at every size: two items per lane with a shared inversion (vb2_kernel<true>) took 20.7 ms for
         // 2^18 items against 12.9 ms here (profiles/r03_ed448_hardened.txt) -- at two waves per SIMD the 17-row scans
@@ -509,8 +549,7 @@ static int vb_launch(size_t n, const uint8_t *scalars, uint64_t scalar_stride, c
         hipLaunchKernelGGL(vb_ct_kernel, grid64(n), dim3(64), 0, s, (uint64_t)n, scalars, scalar_stride, points, point_stride,
                            out, tab);
     } else if (n >= pair_min_items()) {
-        hipLaunchKernelGGL(vb2_kernel, pair_grid, dim3(64), 0, s, (uint64_t)n, scalars, scalar_stride, points, point_stride,
-                           out, tab);
+        return vb2_launch(n, scalars, scalar_stride, points, point_stride, out, tab, s);
     } else {
         hipLaunchKernelGGL(vb_kernel, grid64(n), dim3(64), 0, s, (uint64_t)n, scalars, scalar_stride, points, point_stride,
                            out, tab);
@@ -736,7 +775,14 @@ static int dsm_launch(size_t n, const uint8_t *a, const uint8_t *b, const uint8_
     const uint32_t *gt = nullptr;
     int rc = ensure_gtab(&gt);
     if (rc) return rc;
-    if (n > quad_min_items() && n <= quad_max_items()) {  // four lanes per item (ed448_quad.h)
+    if (duo_range(n)) {  // two lanes per item (ed448_duo.h)
+        const size_t slots = (n + 31) / 32 * 32;
+        CAPY_WS(dtab, uint32_t *, s, WS_TABLE, slots * VB_TABLE_DWORDS * 4);
+        hipLaunchKernelGGL(dsm_duo_kernel, dim3((unsigned)(slots / 32)), dim3(64), 0, s, (uint64_t)n, a, b, points, out, dtab, gt);
+        CAPY_HIP(hipGetLastError());
+        return CAPY_OK;
+    }
+    if (quad_range(n)) {  // four lanes per item (ed448_quad.h)
         const size_t slots = (n + 15) / 16 * 16;
         CAPY_WS(qtab, uint32_t *, s, WS_TABLE, slots * VB_TABLE_DWORDS * 4);
         hipLaunchKernelGGL(dsm_quad_kernel, dim3((unsigned)(slots / 16)), dim3(64), 0, s, (uint64_t)n, a, b, points, out, qtab, gt);
@@ -1002,6 +1048,12 @@ int capy_ed448_set_wave_max(long max_items)
     return CAPY_OK;
 }
 
+int capy_ed448_set_duo_range(long min_items, long max_items)
+{
+    g_duo_min.store(min_items < 0 ? -1 : min_items);
+    g_duo_max.store(max_items < 0 ? -1 : max_items);
+    return CAPY_OK;
+}
 int capy_ed448_set_quad_range(long min_items, long max_items)
 {
     g_quad_min.store(min_items < 0 ? -1 : min_items);

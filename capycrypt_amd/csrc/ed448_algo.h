@@ -89,6 +89,36 @@ __device__ __forceinline__ Fe lds_load_fe(const uint32_t *lds, int f)
 }
 #endif
 
+#if defined(__HIPCC__)
+// Two items per lane sharing one inversion (pt_pair_to_affine_bytes): a wave takes 128 consecutive items, lane l the
+// items base + l and base + 64 + l.  The first result waits in LDS (one column per lane) while the second is computed
+// by the same loop body, so the code is not duplicated.  Used when the batch still fills the chip at half the waves.
+struct PtXYZ {
+    uint32_t w[48][64];  // X, Y, Z limbs x lanes
+};
+__device__ __forceinline__ void park_xyz(PtXYZ &s, const Pt &p)
+{
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        s.w[i][threadIdx.x] = p.X.l[i];
+        s.w[16 + i][threadIdx.x] = p.Y.l[i];
+        s.w[32 + i][threadIdx.x] = p.Z.l[i];
+    }
+}
+__device__ __forceinline__ Pt unpark_xyz(const PtXYZ &s)
+{
+    Pt p;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        p.X.l[i] = s.w[i][threadIdx.x];
+        p.Y.l[i] = s.w[16 + i][threadIdx.x];
+        p.Z.l[i] = s.w[32 + i][threadIdx.x];
+        p.T.l[i] = 0;
+    }
+    return p;
+}
+#endif
+
 // Build the per-item table {0,1,..,WHALF}P (cached form) at tab[0 .. VB_TABLE_DWORDS).
 CAPY_HD inline void vb_build_table(uint32_t *tab, const Pt &P)
 {

@@ -156,9 +156,12 @@ CAPY_HD inline Fe fe_from_columns(uint64_t lo[8], uint64_t hi[8])
 // acc + x * y as ONE v_mad_u64_u32, in the order written.  The optimiser re-associates a column's sum of products and
 // addends freely and then needs a separate 64-bit addition wherever a value other than the running sum should have been
 // the first multiply-add's addend (r04: 33 v_lshl_add_u64 per fe_mul where 26 are needed); the asm pins the chain.
-// CAPY_ED448_ASM_MAD=0 keeps the plain C form (also what the host build runs).
+// CAPY_ED448_ASM_MAD=0 keeps the plain C form (also what the host build runs).  Pinned chains pay in ONE kernel, vb2_kernel
+// (+1.1 % at 2^18 items; ed448_vb2.hip defines the macro to 1); everywhere else they cost -- 2.7 % (one item per lane at
+// 65 536 items) to 2.1x (vb_ct_kernel: its table scan no longer overlaps the arithmetic) -- so the default is 0
+// (profiles/r04_ed448_pinned_chains.txt).
 #ifndef CAPY_ED448_ASM_MAD
-#define CAPY_ED448_ASM_MAD 1
+#define CAPY_ED448_ASM_MAD 0
 #endif
 CAPY_HD inline uint64_t mad64(uint32_t x, uint32_t y, uint64_t acc)
 {

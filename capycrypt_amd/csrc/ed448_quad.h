@@ -151,6 +151,87 @@ __device__ __forceinline__ Fe scalarmul(const uint8_t *k_be, const uint8_t *xy, 
     return acc;
 }
 
+// ---- constant-address form (secret scalars: KeyEncryptable's k V and s Z, /root/reference/src/ecc/encryptable.rs:37,78).
+// The table of an item is 8 rows (1 .. CtWin::HALF times P; the identity row is not stored: a digit of 0 matches no row and
+// the zeros it leaves become the cached identity) of 4 fields x 64 B, one field per lane: 2 KiB per item, 32 KiB per wave of
+// 16 items -- it lives in LDS (four waves per compute unit = one per SIMD: 128 of 160 KiB), laid out so that lane l owns
+// bytes 16 l .. 16 l + 15 of every 1 KiB line: every ds_read_b128 / ds_write_b128 of the wave is one conflict-free line, and
+// its address depends on the lane and the row counter only.  Every row is read for every window and the wanted one kept by
+// an arithmetic mask (ct_mask / ct_take, ed448_algo.h): 32 LDS reads + 128 v_bitop3_b32 per window, no HBM traffic at all
+// (the one-item-per-lane hardened kernel reads its per-item tables from HBM: ~60 GB per 2^18 multiplications).
+constexpr int QUAD_CT_ROWS = CtWin::HALF;                    // rows 1 .. HALF
+constexpr int QUAD_CT_LDS_DWORDS = QUAD_CT_ROWS * 4 * 256;   // rows x 16-byte pieces x (64 lanes x 4 dwords)
+
+__device__ __forceinline__ void ct_store_row(uint32_t *lds, int row, const Fe &a)
+{
+    const uint32_t lane = threadIdx.x & 63;
+#pragma unroll
+    for (int pc = 0; pc < 4; pc++) {
+        const uint4 v = {a.l[4 * pc], a.l[4 * pc + 1], a.l[4 * pc + 2], a.l[4 * pc + 3]};
+        *reinterpret_cast<uint4 *>(lds + ((row * 4 + pc) * 64 + lane) * 4) = v;
+    }
+}
+
+// this lane's field of sign(digit) * tab[|digit|], every row read
+__device__ __forceinline__ Fe ct_entry(const uint32_t *lds, int digit, uint32_t q)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const bool neg = digit < 0;
+    const uint32_t idx = (uint32_t)(neg ? -digit : digit);
+    Fe e = fe_zero();
+#pragma unroll
+    for (int row = 0; row < QUAD_CT_ROWS; row++) {
+        const uint32_t m = ct_mask((uint32_t)(row + 1) == idx);
+#pragma unroll
+        for (int pc = 0; pc < 4; pc++) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(lds + ((row * 4 + pc) * 64 + lane) * 4);
+            e.l[4 * pc] = ct_take(e.l[4 * pc], v.x, m);
+            e.l[4 * pc + 1] = ct_take(e.l[4 * pc + 1], v.y, m);
+            e.l[4 * pc + 2] = ct_take(e.l[4 * pc + 2], v.z, m);
+            e.l[4 * pc + 3] = ct_take(e.l[4 * pc + 3], v.w, m);
+        }
+    }
+    e.l[0] |= ct_mask(idx == 0) & ((q == 1 || q == 2) ? 1u : 0u);   // digit 0: the cached identity (0, 1, 1, 0)
+    const bool flips = (q == 0 || q == 3);
+    return fe_sel(neg && flips, e, fe_neg_nr(e));                    // a select of data, not of an address
+}
+
+// [k]P with constant-address lookups; lds = the wave's QUAD_CT_LDS_DWORDS.  Windows of CT_WBITS bits (as the other
+// hardened kernels: fewer rows to read per window outweigh the extra windows).
+__device__ __forceinline__ Fe scalarmul_ct(const uint8_t *k_be, const uint8_t *xy, uint32_t *lds, uint32_t q)
+{
+    const Fe px = fe_from_bytes(xy), py = fe_from_bytes(xy + 56);
+    Fe p_own = q == 0 ? px : py;
+    {
+        const Fe t = fe_mul(px, py), one = fe_one();
+        p_own = fe_sel(q == 2, p_own, one);
+        p_own = fe_sel(q == 3, p_own, t);
+    }
+    const Fe p_cached = fe_sel(q == 3, p_own, fe_mul_d(p_own));
+    Fe acc = fe_zero();
+    acc.l[0] = (q == 1 || q == 2) ? 1u : 0u;
+#pragma unroll 1
+    for (int j = 0; j < QUAD_CT_ROWS; j++) {
+        acc = add_cached(acc, p_cached, q);
+        ct_store_row(lds, j, fe_sel(q == 3, acc, fe_mul_d(acc)));
+    }
+    uint32_t k[14], w[15];
+    sc_from_be(k, k_be);
+    const uint32_t top = sc_recode_signed<CT_WBITS>(w, k);
+    sc_msb_align<CT_WBITS>(w);
+    acc = fe_zero();
+    acc.l[0] = (q == 1 || q == 2) ? 1u : 0u;
+    acc = add_cached(acc, ct_entry(lds, (int)top, q), q);
+#pragma unroll 1
+    for (int i = 0; i < CtWin::NWIN; i++) {
+        const Fe e = ct_entry(lds, sc_next_digit_msb<CT_WBITS>(w), q);
+#pragma unroll 1
+        for (int j = 0; j < CT_WBITS; j++) acc = dbl(acc, q);
+        acc = add_cached(acc, e, q);
+    }
+    return acc;
+}
+
 // acc += [a]G from the shared fixed-base table on E (rows of FB_TAB_ENTRIES affine cached entries (x, y, d x y), 12-bit
 // signed windows, row FbWin::NWIN = the recoding carry): 39 additions in the same quad form -- lane q reads field q of
 // the entry, the Z lane multiplies by one.  The entry of the next window is requested before the current addition.

@@ -261,6 +261,10 @@ int capy_ed448_set_wave_max(long max_items);
  * latency than one item per lane, less throughput).  Defaults 4096 / 32768 (negative restores them; max = 0: never).
  * Results are bit-identical either way. */
 int capy_ed448_set_quad_range(long min_items, long max_items);
+/* The same for the two-lanes-per-item kernels (csrc/ed448_duo.h: (Y, Z) and (X, T) of the accumulator in the two lanes of
+ * a pair; one wave of 32 items per SIMD at 32 768 items, where the four-lane form needs two).  Checked before the quad
+ * range.  Defaults 16384 / 32768 (negative restores them; max = 0: never).  Results are bit-identical either way. */
+int capy_ed448_set_duo_range(long min_items, long max_items);
 
 /* status[i] = CAPY_ITEM_OK iff point i has canonical coordinates (both < p) and lies on the curve.  The multiplication
  * and protocol entry points do NOT validate their point inputs (results for off-curve or non-canonical input are

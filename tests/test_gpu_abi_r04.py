@@ -324,12 +324,14 @@ def test_python_mirror_takes_call_options(capy, O):
         capy.ops.keypair_batch(pws, 384, options={"hardened": 1})
 
 
-def test_four_lanes_per_item_kernels_equal_the_other_families(capy, O):
-    """csrc/ed448_quad.h (r04): batches of 4096 < n <= 32768 public-scalar multiplications put X, Y, Z, T of the accumulator
-    into the four lanes of a quad.  Variable base and the verify-shaped double multiplication must give the bytes of the
-    lane-per-item / wave-per-item kernels (capy_ed448_set_quad_range(0, 0) switches the family off) at sizes with full
-    and ragged last waves, on edge scalars (0, 1, r - 1, r, 2^448 - 1), the identity, a point of order 2 and random points;
-    a sample is checked against the oracle, and the protocol call that uses it (verify) accepts what sign produced."""
+@pytest.mark.parametrize("family", ["quad", "duo"])
+def test_lanes_per_item_kernels_equal_the_other_families(capy, O, family):
+    """csrc/ed448_quad.h, csrc/ed448_duo.h (r04): batches of 4096 < n <= 16384 public-scalar multiplications put X, Y, Z, T of
+    the accumulator into the four lanes of a quad, batches of 16384 < n <= 32768 put (Y, Z) and (X, T) into the two lanes of
+    a pair.  Variable base and the verify-shaped double multiplication must give the bytes of the lane-per-item /
+    wave-per-item kernels (capy_ed448_set_{quad,duo}_range(0, 0) switch the families off) at sizes with full and ragged last
+    waves, on edge scalars (0, 1, r - 1, r, 2^448 - 1), the identity, a point of order 2 and random points; a sample is
+    checked against the oracle, and the protocol call that uses it (verify) accepts what sign produced."""
     import torch
 
     from capycrypt_amd import _lib
@@ -342,8 +344,16 @@ def test_four_lanes_per_item_kernels_equal_the_other_families(capy, O):
     order2 = (0).to_bytes(56, "little") + (p - 1).to_bytes(56, "little")
     edge_k = [0, 1, 2, R - 1, R, R + 1, (1 << 448) - 1, 1 << 447]
     fam = C.c_int(0)
+    # "on" forces the family under test for every n and switches the other one off; "off" switches both off
+    on = {"quad": ((0, 1 << 30), (0, 0)), "duo": ((0, 0), (0, 1 << 30))}[family]
+    tag = {"quad": 33, "duo": 65}[family]
+
+    def set_ranges(quad_range, duo_range):
+        _lib.check(lib.capy_ed448_set_quad_range(*quad_range))
+        _lib.check(lib.capy_ed448_set_duo_range(*duo_range))
+
     try:
-        for n in (4097, 9000, 16384, 32768):
+        for n in {"quad": (4097, 9000, 16384, 32768), "duo": (33, 4097, 16385, 32768, 40001)}[family]:
             sc = torch.empty(n * 56, dtype=torch.uint8, device="cuda")
             asc = torch.empty(n * 56, dtype=torch.uint8, device="cuda")
             tsc = torch.empty(n * 56, dtype=torch.uint8, device="cuda")
@@ -353,18 +363,18 @@ def test_four_lanes_per_item_kernels_equal_the_other_families(capy, O):
             sc[:eb.numel()] = eb
             sc[(n - len(edge_k)) * 56:] = eb
             pts = torch.empty(n * 112, dtype=torch.uint8, device="cuda")
-            _lib.check(lib.capy_ed448_set_quad_range(0, 0))
+            set_ranges((0, 0), (0, 0))
             _lib.check(lib.capy_ed448_basemul_batch_dev(n, tsc.data_ptr(), pts.data_ptr(), sp))
             special = torch.tensor(list(ident + order2), dtype=torch.uint8, device="cuda")
             pts[8 * 112:10 * 112] = special
             outs = {}
-            for name, rng_ in (("other", (0, 0)), ("quad", (-1, -1))):
-                _lib.check(lib.capy_ed448_set_quad_range(*rng_))
+            for name, rng_ in (("other", ((0, 0), (0, 0))), ("quad", on)):
+                set_ranges(*rng_)
                 vb = torch.zeros(n * 112, dtype=torch.uint8, device="cuda")
                 ds = torch.zeros(n * 112, dtype=torch.uint8, device="cuda")
                 _lib.check(lib.capy_ed448_scalarmul_batch_dev(n, sc.data_ptr(), pts.data_ptr(), vb.data_ptr(), sp))
                 lib.capy_debug_last_curve_kernel(C.byref(fam), None)
-                assert (fam.value == 33) == (name == "quad"), (n, name, fam.value)
+                assert (fam.value == tag) == (name == "quad"), (n, name, fam.value)
                 _lib.check(lib.capy_ed448_double_scalarmul_batch_dev(n, asc.data_ptr(), sc.data_ptr(), pts.data_ptr(), ds.data_ptr(), sp))
                 torch.cuda.synchronize()
                 outs[name] = (vb, ds)
@@ -373,8 +383,9 @@ def test_four_lanes_per_item_kernels_equal_the_other_families(capy, O):
             hs, hp, hv = bytes(sc.cpu().numpy()), bytes(pts.cpu().numpy()), bytes(outs["quad"][0].cpu().numpy())
             for i in list(range(0, 10)) + [n // 2, n - 3, n - 1]:
                 assert hv[112 * i:112 * i + 112] == O.ed448_scalarmul(hs[56 * i:56 * i + 56], hp[112 * i:112 * i + 112]), (n, i)
-        # verify (double multiplication inside the protocol call) on a batch in the quad range
-        n = 5000
+        # verify (double multiplication inside the protocol call) on a batch in the family's default range
+        set_ranges((-1, -1), (-1, -1))
+        n = {"quad": 5000, "duo": 16500}[family]
         pws = [rng.randbytes(16) for _ in range(n)]
         msgs = [rng.randbytes(40) for _ in range(n)]
         pub = capy.ops.keypair_batch(pws, 256)
@@ -385,4 +396,73 @@ def test_four_lanes_per_item_kernels_equal_the_other_families(capy, O):
         ok = capy.ops.schnorr_verify_batch(pub, msgs, sigs, 256)
         assert not ok[7] and sum(ok) == n - 1
     finally:
+        set_ranges((-1, -1), (-1, -1))
+
+
+def test_constant_address_quad_kernel_equals_the_other_hardened_kernels(capy, O):
+    """vb_quad_ct_kernel (csrc/ed448_quad.h, r04): secret-scalar variable-base multiplications of 4096 < n <= 32768 items with
+    four lanes per item and the window table in LDS, every row read per window.  Bytes must equal those of the
+    one-item-per-lane / one-item-per-wave hardened kernels (capy_ed448_set_quad_range(0, 0)) and of the indexed kernels, on
+    edge scalars, the identity and a point of order 2, at sizes with ragged last waves and beyond one round of waves; a
+    sample is checked against the oracle; and the protocol calls that use it (key_encrypt / key_decrypt) round-trip."""
+    import torch
+
+    from capycrypt_amd import _lib
+
+    lib = _lib.lib()
+    rng = random.Random(0xC7C7)
+    sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = (1 << 448) - (1 << 224) - 1
+    ident = (0).to_bytes(56, "little") + (1).to_bytes(56, "little")
+    order2 = (0).to_bytes(56, "little") + (p - 1).to_bytes(56, "little")
+    edge_k = [0, 1, 2, R - 1, R, R + 1, (1 << 448) - 1, 1 << 447, 8, 0x8888, (1 << 448) - 8]
+    fam = C.c_int(0)
+    try:
+        for n in (4097, 9001, 16384, 20000):
+            sc = torch.empty(n * 56, dtype=torch.uint8, device="cuda")
+            tsc = torch.empty(n * 56, dtype=torch.uint8, device="cuda")
+            for t, seed in ((sc, 1), (tsc, 3)):
+                _lib.check(lib.capy_fill_random_dev(t.data_ptr(), n * 56, 900 + seed + n, sp))
+            eb = torch.tensor(list(b"".join(k.to_bytes(56, "big") for k in edge_k)), dtype=torch.uint8, device="cuda")
+            sc[:eb.numel()] = eb
+            sc[(n - len(edge_k)) * 56:] = eb
+            pts = torch.empty(n * 112, dtype=torch.uint8, device="cuda")
+            _lib.check(lib.capy_ed448_basemul_batch_dev(n, tsc.data_ptr(), pts.data_ptr(), sp))
+            pts[12 * 112:14 * 112] = torch.tensor(list(ident + order2), dtype=torch.uint8, device="cuda")
+            outs = {}
+            for name, mode, qr in (("indexed", capy.ops.HARDEN_OFF, (0, 0)), ("lane_ct", capy.ops.HARDEN_ALL, (0, 0)),
+                                   ("quad_ct", capy.ops.HARDEN_ALL, (-1, -1))):
+                capy.ops.ed448_set_hardened(mode)
+                _lib.check(lib.capy_ed448_set_quad_range(*qr))
+                _lib.check(lib.capy_ed448_set_duo_range(*((0, 0) if qr == (0, 0) else (-1, -1))))
+                vb = torch.zeros(n * 112, dtype=torch.uint8, device="cuda")
+                _lib.check(lib.capy_ed448_scalarmul_batch_dev(n, sc.data_ptr(), pts.data_ptr(), vb.data_ptr(), sp))
+                lib.capy_debug_last_curve_kernel(C.byref(fam), None)
+                assert (fam.value == 34) == (name == "quad_ct"), (n, name, fam.value)
+                torch.cuda.synchronize()
+                outs[name] = vb
+            assert torch.equal(outs["indexed"], outs["quad_ct"]), n
+            assert torch.equal(outs["lane_ct"], outs["quad_ct"]), n
+            hs, hp, hv = bytes(sc.cpu().numpy()), bytes(pts.cpu().numpy()), bytes(outs["quad_ct"].cpu().numpy())
+            for i in list(range(0, 14)) + [n // 2, n - 3, n - 1]:
+                assert hv[112 * i:112 * i + 112] == O.ed448_scalarmul(hs[56 * i:56 * i + 56], hp[112 * i:112 * i + 112]), (n, i)
+        # the protocol calls whose secret-scalar multiplications take it in the default mode
+        capy.ops.ed448_set_hardened(capy.ops.HARDEN_PROTOCOL)
         _lib.check(lib.capy_ed448_set_quad_range(-1, -1))
+        _lib.check(lib.capy_ed448_set_duo_range(-1, -1))
+        n = 4500
+        pws = [rng.randbytes(12) for _ in range(n)]
+        msgs = [rng.randbytes(33) for _ in range(n)]
+        pub = capy.ops.keypair_batch(pws, 256)
+        ks = [rng.randbytes(56) for _ in range(n)]
+        cts, zs, tags = capy.ops.key_encrypt_batch(pub, ks, msgs, 256)
+        lib.capy_debug_last_curve_kernel(C.byref(fam), None)
+        assert fam.value == 34, fam.value
+        for i in (0, 1, n - 1):
+            assert (cts[i], zs[i], tags[i]) == O.key_encrypt(pub[i], ks[i], msgs[i], 256), i
+        back, ok = capy.ops.key_decrypt_batch(pws, zs, cts, tags, 256)
+        assert all(ok) and back == msgs
+    finally:
+        capy.ops.ed448_set_hardened(capy.ops.HARDEN_PROTOCOL)
+        _lib.check(lib.capy_ed448_set_quad_range(-1, -1))
+        _lib.check(lib.capy_ed448_set_duo_range(-1, -1))

@@ -188,6 +188,20 @@ def _step(ins, ptr, data, secret_dwords, kernarg_base, report):
         return
     if not R:
         return
+    if op in ("v_writelane_b32", "v_readlane_b32") and len(ops) == 3 and re.fullmatch(r"\d+", ops[2].strip()):
+        # SGPR spills: lane N of a VGPR holds one scalar (often a kernel-argument pointer).  Marks are kept per (register, lane)
+        lane = ops[2].strip()
+        if op == "v_writelane_b32":
+            p, d = tags(R[1])
+            key = "%s#%s" % (R[0][0], lane)
+            (ptr.add if p else ptr.discard)(key)
+            (data.add if d else data.discard)(key)
+            if d:
+                data.add(R[0][0])  # part of the register now carries the mark: any whole-register read sees it
+        else:
+            key = "%s#%s" % (R[1][0], lane)
+            setregs(R[0], key in ptr, key in data or R[1][0] in data)
+        return
     ndest = 2 if op.startswith(TWO_DEST) else 1
     dests = [r for rs in R[:ndest] for r in rs]
     srcs = [r for rs in R[ndest:] for r in rs]
@@ -198,6 +212,18 @@ def _step(ins, ptr, data, secret_dwords, kernarg_base, report):
         p, d = tags(srcs)
         setregs(dests, False, d)
         setregs(["exec"], False, d)
+        return
+    if op.startswith(("v_mad_u64_u32", "v_mad_i64_i32", "v_lshl_add_u64")) and len(R[0]) == 2 and len(R[-1]) == 2:
+        # 64-bit results dword by dword: the LOW dword of a * b + c and of (a << s) + c does not depend on the high dword of
+        # any 64-bit source (the compiler forms 32-bit address arithmetic this way, with junk in the unused high halves)
+        lo_srcs = [r for rs in R[ndest:] for r in (rs[:1] if len(rs) == 2 else rs)]
+        p_lo, d_lo = tags(lo_srcs)
+        p, d = tags(srcs)
+        keep = op.startswith(("v_mad_u64_u32", "v_lshl_add"))
+        setregs(R[0][:1], keep and p_lo, d_lo)
+        setregs(R[0][1:], keep and p, d)
+        if ndest == 2:
+            setregs(R[1], False, d)
         return
     if op.startswith(("v_cndmask", "v_addc", "v_subb", "v_div_fmas")) and len(R) <= ndest + 2:
         srcs.append("vcc")  # the e32 forms read vcc implicitly
