@@ -10,7 +10,35 @@
 
 namespace capy {
 
-
+// cshake(x, l, "", "", d) on device buffers (shake_functions.rs:59-61, see capy_cshake_batch): y_i = x_i || 04 || sfx || pad,
+// where sfx is the SHA3 suffix the dropped shake() call left behind (86 when the framed length is 135 mod 136, else 06)
+// and pad is its pad10*1 up to the SHA3-d rate r1 (nothing when already a multiple).  One wave per item: the bytes are
+// copied, lane 0 writes the trailer.  dst_off == nullptr: y_i at dst + i * dst_stride (uniform lengths).
+__host__ __device__ inline uint64_t cshake_empty_trailer(uint64_t len, uint64_t w, uint64_t r1, uint8_t *sfx)
+{
+    uint64_t L = w + len + 1;  // bytepad(encode_string("") || encode_string(""), w) is exactly one block of w bytes
+    *sfx = (136 - L % 136) == 1 ? 0x86 : 0x06;
+    L += 1;
+    return 2 + (L % r1 ? r1 - L % r1 : 0);
+}
+__global__ __launch_bounds__(64) void cshake_empty_trailer_kernel(uint8_t *dst, const uint64_t *dst_off, uint64_t dst_stride,
+                                                                  const uint8_t *src, const uint64_t *src_off, uint64_t uniform_len,
+                                                                  uint64_t src_stride, uint64_t n, uint32_t w, uint32_t r1)
+{
+    const uint64_t i = blockIdx.x;
+    if (i >= n) return;
+    const uint64_t s0 = src_off ? src_off[i] : i * src_stride, len = src_off ? src_off[i + 1] - s0 : uniform_len;
+    uint8_t *y = dst + (dst_off ? dst_off[i] : i * dst_stride);
+    for (uint64_t j = threadIdx.x; j < len; j += 64) y[j] = src[s0 + j];
+    if (threadIdx.x == 0) {
+        uint8_t sfx;
+        const uint64_t t = cshake_empty_trailer(len, w, r1, &sfx);
+        y[len] = 0x04;
+        y[len + 1] = sfx;
+        for (uint64_t j = 2; j < t; j++) y[len + j] = 0;
+        if (t > 2) y[len + t - 1] = 0x80;
+    }
+}
 
 }  // namespace capy
 
@@ -108,6 +136,47 @@ int capy_cshake_batch_dev(int d, size_t n, const uint8_t *xs, const uint64_t *of
     if (n && !outs) return fail(CAPY_ERR_ARG, "null argument");
     if (n) CAPY_REQUIRE(msgs_ok(xs, offsets, uniform_len), "xs");
     if (out_stride < l_bits / 8) return fail(CAPY_ERR_ARG, "out_stride shorter than the output");
+    if (fn_len == 0 && custom_len == 0 && n && valid_d(d)) {
+        // the N = S = "" corner: every message gets its trailer in a scratch copy, absorbed without a further suffix.
+        // Synchronous (ragged batches read their offsets back to size the copy, and the scratch copy must outlive the
+        // launch): crate-internal and unreachable through kmac_xof, so not a path worth a stream-ordered allocator
+        hipStream_t s = (hipStream_t)stream;
+        const uint64_t w = (1600 - (uint64_t)d) / 8, r1 = (1600 - 2 * (uint64_t)d) / 8;
+        DevBuf y, meta;  // meta: n + 1 starts of the copies, then their n lengths
+        uint64_t ylen = 0, ystride = 0;
+        uint8_t sfx;
+        MsgView v;
+        if (offsets) {
+            std::vector<uint64_t> off(n + 1), m(2 * n + 1, 0);
+            CAPY_HIP(hipMemcpyAsync(off.data(), offsets, (n + 1) * 8, hipMemcpyDeviceToHost, s));
+            CAPY_HIP(hipStreamSynchronize(s));
+            for (size_t i = 0; i < n; i++) {
+                if (off[i + 1] < off[i]) return fail(CAPY_ERR_ARG, "offsets must be non-decreasing");
+                const uint64_t len = off[i + 1] - off[i];
+                m[n + 1 + i] = len + cshake_empty_trailer(len, w, r1, &sfx);
+                m[i + 1] = m[i] + ((m[n + 1 + i] + 7) & ~7ull);  // 8-byte aligned starts
+            }
+            CAPY_HIP(meta.alloc((2 * n + 1) * 8));
+            CAPY_HIP(hipMemcpyAsync(meta.p, m.data(), (2 * n + 1) * 8, hipMemcpyHostToDevice, s));
+            CAPY_HIP(hipStreamSynchronize(s));  // m goes out of scope
+            CAPY_HIP(y.alloc(m[n] + 8));
+            v = view_dev(y.as<uint8_t>(), meta.as<uint64_t>(), 0, 0);
+            v.lens = meta.as<uint64_t>() + n + 1;
+            v.aligned8 = true;
+        } else {
+            ylen = uniform_len + cshake_empty_trailer(uniform_len, w, r1, &sfx);
+            ystride = (ylen + 7) & ~7ull;
+            CAPY_HIP(y.alloc(n * ystride + 8));
+            v = view_dev(y.as<uint8_t>(), nullptr, ylen, ystride);
+        }
+        hipLaunchKernelGGL(cshake_empty_trailer_kernel, dim3((unsigned)n), dim3(64), 0, s, y.as<uint8_t>(),
+                           offsets ? meta.as<uint64_t>() : nullptr, ystride, xs, offsets, uniform_len,
+                           msg_stride ? msg_stride : uniform_len, (uint64_t)n, (uint32_t)w, (uint32_t)r1);
+        CAPY_HIP(hipGetLastError());
+        const int rc = cshake_launch(d, n, v, l_bits, fn_name, 0, custom, 0, outs, out_stride, s, true);
+        CAPY_HIP(hipStreamSynchronize(s));  // the scratch copy is released on return
+        return rc;
+    }
     return cshake_launch(d, n, view_dev(xs, offsets, uniform_len, msg_stride), l_bits, fn_name, fn_len, custom,
                          custom_len, outs, out_stride, (hipStream_t)stream);
 }

@@ -671,7 +671,7 @@ int cshake_launch(int d, size_t n, const MsgView &m, size_t l_bits, const uint8_
     if (!valid_d(d)) return fail(CAPY_ERR_UNSUPPORTED_SECPARAM, "unsupported security parameter");
     if (fn_len == 0 && cs_len == 0 && !body_has_trailer)
         return fail(CAPY_ERR_UNSUPPORTED,
-                    "cshake with empty N and S (shake_functions.rs:59-61) is served by the host-buffer entry point only");
+                    "cshake with empty N and S (shake_functions.rs:59-61): the caller frames the trailer (capy_cshake_batch[_dev])");
     Framing f = cshake_framing(d);
     SpongeParams p;
     memset(&p, 0, sizeof p);

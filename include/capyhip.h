@@ -125,8 +125,9 @@ int capy_sha3_batch_dev(int d, size_t n, const uint8_t *msgs, const uint64_t *of
 
 /* cSHAKE: out_i = cshake(x_i, l_bits, N, S, d).  outs: n * l_bits/8 bytes.
  * Replaces cshake(), src/sha3/shake_functions.rs:49-64 (capacity = d), including its N = S = "" corner (:59-61: the
- * dropped shake() call whose buffer mutation is kept), which the host-buffer form reproduces bit for bit; the device
- * form answers that corner with CAPY_ERR_UNSUPPORTED (crate-internal, unreachable through kmac_xof). */
+ * dropped shake() call whose buffer mutation is kept), which both forms reproduce bit for bit (the device-buffer form
+ * through a scratch copy of the messages with their trailers, synchronously: crate-internal, unreachable through
+ * kmac_xof). */
 int capy_cshake_batch(int d, size_t n, const uint8_t *xs, const uint64_t *offsets, size_t l_bits,
                       const uint8_t *fn_name, size_t fn_len, const uint8_t *custom, size_t custom_len,
                       uint8_t *outs);

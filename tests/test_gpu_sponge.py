@@ -152,15 +152,43 @@ def test_cshake_empty_n_and_s_matches_the_reference_corner(capy, O, d):
         assert capy.ops.cshake_batch(msgs, l, b"", b"", d) == [O.cshake(m, l, b"", b"", d) for m in msgs]
 
 
-def test_cshake_empty_n_and_s_device_form_is_rejected(capy):
+@pytest.mark.parametrize("d", [224, 256, 384, 512])
+def test_cshake_empty_n_and_s_device_form_matches_the_reference_corner(capy, O, d):
+    """The same corner through capy_cshake_batch_dev (r03: answered CAPY_ERR_UNSUPPORTED): uniform batches (one length per
+    call, with a message stride) and a ragged batch through device offsets, lengths on the block boundaries of both rates."""
+    import ctypes as C
+
     import torch
 
     from capycrypt_amd import _lib
 
-    x = torch.zeros(64, dtype=torch.uint8, device="cuda")
-    out = torch.zeros(64, dtype=torch.uint8, device="cuda")
-    rc = _lib.lib().capy_cshake_batch_dev(256, 1, x.data_ptr(), None, 8, 8, 256, b"", 0, b"", 0, out.data_ptr(), 32, None)
-    assert rc == _lib.CAPY_ERR_UNSUPPORTED
+    lib = _lib.lib()
+    rng = random.Random(950 + d)
+    w, r1 = (1600 - d) // 8, (1600 - 2 * d) // 8
+    sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    lens = sorted(set([0, 1, 7, 8, 100, 135, 136, 1000] + [136 - (w + 1) % 136 + 135 - 136 * k for k in (0, -1)] + [r1 - 2, r1 - 1, r1,
+                                                                                                            2 * r1 - w % r1]))
+    lens = [n for n in lens if n >= 0]
+    ol = 64
+    for n_bytes in lens:  # uniform: 5 messages of this length, stride rounded up to 8 plus one slack word
+        stride = (n_bytes + 7) // 8 * 8 + 8
+        msgs = [rng.randbytes(n_bytes) for _ in range(5)]
+        buf = torch.tensor(list(b"".join(m + bytes(stride - n_bytes) for m in msgs)), dtype=torch.uint8, device="cuda")
+        out = torch.zeros(5 * ol, dtype=torch.uint8, device="cuda")
+        _lib.check(lib.capy_cshake_batch_dev(d, 5, buf.data_ptr(), None, n_bytes, stride, 8 * ol, b"", 0, b"", 0, out.data_ptr(), ol, sp))
+        got = bytes(out.cpu().numpy())
+        assert [got[ol * i:ol * (i + 1)] for i in range(5)] == [O.cshake(m, 8 * ol, b"", b"", d) for m in msgs], n_bytes
+    msgs = [rng.randbytes(n) for n in lens]
+    offs, data = [0], b""
+    for m in msgs:
+        data += m
+        offs.append(len(data))
+    buf = torch.tensor(list(data + bytes(8)), dtype=torch.uint8, device="cuda")
+    doff = torch.tensor(offs, dtype=torch.int64, device="cuda")
+    out = torch.zeros(len(msgs) * ol, dtype=torch.uint8, device="cuda")
+    _lib.check(lib.capy_cshake_batch_dev(d, len(msgs), buf.data_ptr(), doff.data_ptr(), 0, 0, 8 * ol, b"", 0, b"", 0, out.data_ptr(), ol, sp))
+    got = bytes(out.cpu().numpy())
+    assert [got[ol * i:ol * (i + 1)] for i in range(len(msgs))] == [O.cshake(m, 8 * ol, b"", b"", d) for m in msgs]
 
 
 def test_unsupported_security_parameter(capy):
