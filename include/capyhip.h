@@ -259,8 +259,9 @@ int capy_ed448_set_wave_max(long max_items);
 /* Tuning / A-B switch (process-wide): batches of min_items < n <= max_items public-scalar multiplications (the raw
  * scalarmul / double_scalarmul calls, verification) take the four-lanes-per-item kernels (csrc/ed448_quad.h: X, Y, Z, T of
  * the accumulator in the four lanes of a quad, the field multiplications of a formula level side by side; 2.3x lower
- * latency than one item per lane, less throughput).  Defaults 4096 / 32768 (negative restores them; max = 0: never).
- * Results are bit-identical either way. */
+ * latency than one item per lane, less throughput).  Defaults 4096 / 32768 (negative restores them; max = 0: never); the
+ * two-lane range below takes 16384 < n <= 32768 out of it.  An explicit max also bounds the constant-address quad kernel
+ * (vb_quad_ct_kernel: secret scalars, window table in LDS; default 4096 < n <= 32768).  Results are bit-identical either way. */
 int capy_ed448_set_quad_range(long min_items, long max_items);
 /* The same for the two-lanes-per-item kernels (csrc/ed448_duo.h: (Y, Z) and (X, T) of the accumulator in the two lanes of
  * a pair; one wave of 32 items per SIMD at 32 768 items, where the four-lane form needs two).  Checked before the quad
