@@ -146,10 +146,38 @@ def test_cshake_empty_n_and_s_matches_the_reference_corner(capy, O, d):
     (oracle_sponge.c, quirks = 1); lengths on both rates' block boundaries and the 135-mod-136 suffix switch."""
     rng = random.Random(900 + d)
     w, r1 = (1600 - d) // 8, (1600 - 2 * d) // 8
-    lens = sorted(set(LENS + [136 - (w + 1) % 136 + 135 - 136 * k for k in (0, -1)] + [r1 - 2, r1 - 1, r1, 2 * r1 - w % r1]))
+    lens = sorted(set(LENS + [136 - (w + 1) % 136 + 135 - 136 * k for k in (0, -1)] + [r1 - 2, r1 - 1, r1, 2 * r1 - w % r1]
+                      + _cshake_empty_aligned_lens(d)))
     msgs = [rng.randbytes(max(0, n)) for n in lens]
     for l in (8, 256, 1600):
         assert capy.ops.cshake_batch(msgs, l, b"", b"", d) == [O.cshake(m, l, b"", b"", d) for m in msgs]
+
+
+def _cshake_empty_aligned_lens(d):
+    """Message lengths for which the buffer the dropped shake() call leaves behind -- one block of w bytes, x, 04, the
+    SHA3 suffix, pad10*1 to the SHA3-d rate r1 -- is ALSO a whole number of blocks of w bytes: the absorb at capacity d then
+    ends on a block boundary with nothing appended.  (The wave-per-item digest kernel took such an item's digest from a stale
+    state until tools/fuzz_soak.py found it in r04.)"""
+    import math
+
+    w, r1 = (1600 - d) // 8, (1600 - 2 * d) // 8
+    m = w * r1 // math.gcd(w, r1)
+    lo, hi = m - w - 2 - (r1 - 1), m - w - 2
+    return [lo, lo + 1, (lo + hi) // 2, hi - 1, hi, hi + 1, 2 * m - w - 2 - 5]
+
+
+@pytest.mark.parametrize("d", [256, 384, 512])
+def test_cshake_empty_n_and_s_on_a_block_boundary_of_both_rates(capy, O, d):
+    """The aligned corner of the corner (see _cshake_empty_aligned_lens) on its own: uniform batches of one, two, three and
+    130 such messages (the wave-per-item kernel holds two items per wave; 130 leaves it) and a ragged one."""
+    rng = random.Random(990 + d)
+    lens = [n for n in _cshake_empty_aligned_lens(d)]
+    for n_items in (1, 2, 3, 130):
+        for ln in lens[:5]:
+            msgs = [rng.randbytes(ln) for _ in range(n_items)]
+            assert capy.ops.cshake_batch(msgs, 512, b"", b"", d) == [O.cshake(m, 512, b"", b"", d) for m in msgs], (n_items, ln)
+    msgs = [rng.randbytes(ln) for ln in lens * 3]
+    assert capy.ops.cshake_batch(msgs, 1088, b"", b"", d) == [O.cshake(m, 1088, b"", b"", d) for m in msgs]
 
 
 @pytest.mark.parametrize("d", [224, 256, 384, 512])
@@ -168,7 +196,7 @@ def test_cshake_empty_n_and_s_device_form_matches_the_reference_corner(capy, O, 
     sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     lens = sorted(set([0, 1, 7, 8, 100, 135, 136, 1000] + [136 - (w + 1) % 136 + 135 - 136 * k for k in (0, -1)] + [r1 - 2, r1 - 1, r1,
                                                                                                             2 * r1 - w % r1]))
-    lens = [n for n in lens if n >= 0]
+    lens = [n for n in lens + _cshake_empty_aligned_lens(d)[:4] if n >= 0]
     ol = 64
     for n_bytes in lens:  # uniform: 5 messages of this length, stride rounded up to 8 plus one slack word
         stride = (n_bytes + 7) // 8 * 8 + 8
