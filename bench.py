@@ -430,7 +430,7 @@ def main():
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 eel = float(t.item())
             ed = {"pairs_per_gpu": n, "scalar_mults_per_s": world * n * reps / eel,
-                  "kernel_ms": e0.elapsed_time(e1) / reps, "scaling": "weak (every rank its own 2^18 pairs)"}
+                  "kernel_ms": e0.elapsed_time(e1) / reps, "scaling": "weak (every rank its own %d pairs)" % a.ed448_pairs}
             # BASELINE config 4 as specified is a FIXED batch of 2^18 pairs over 1 -> 8 GPUs (2^18 / N per
             # GPU): the strong-scaled figure beside the weak one.  Rank r takes the contiguous slice r of one global,
             # rank-independent batch (no collective on the data path; the N outputs concatenate to the 1-GPU output).
