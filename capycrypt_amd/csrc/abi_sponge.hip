@@ -157,8 +157,7 @@ int capy_cshake_batch_dev(int d, size_t n, const uint8_t *xs, const uint64_t *of
                 m[i + 1] = m[i] + ((m[n + 1 + i] + 7) & ~7ull);  // 8-byte aligned starts
             }
             CAPY_HIP(meta.alloc((2 * n + 1) * 8));
-            CAPY_HIP(hipMemcpyAsync(meta.p, m.data(), (2 * n + 1) * 8, hipMemcpyHostToDevice, s));
-            CAPY_HIP(hipStreamSynchronize(s));  // m goes out of scope
+            CAPY_HIP(meta.put(m.data(), (2 * n + 1) * 8));  // (a small buffer may live in the pinned arena: plain memory)
             CAPY_HIP(y.alloc(m[n] + 8));
             v = view_dev(y.as<uint8_t>(), meta.as<uint64_t>(), 0, 0);
             v.lens = meta.as<uint64_t>() + n + 1;

@@ -17,6 +17,13 @@ from oracle import oracle as O  # noqa: E402
 
 lib = _lib.lib()
 _lib.check(lib.capy_set_device(0))
+# DEVICES="0,0,0": the in-library sharding (capy_set_devices) under the same soak -- on a one-GPU box every shard lands on the
+# same card, which exercises the shard cut, the per-worker pools and the output slices, not a speed-up
+_devs = [int(x) for x in os.environ.get("DEVICES", "").split(",") if x.strip() != ""]
+if _devs:
+    import ctypes as _C
+
+    _lib.check(lib.capy_set_devices((_C.c_int * len(_devs))(*_devs), len(_devs)))
 seed = int(os.environ.get("SEED", "1"))
 budget = float(os.environ.get("SECONDS", "240"))
 rng = random.Random(seed)
@@ -232,7 +239,8 @@ while time.time() - t0 < budget:
     if time.time() - last > 50:
         last = time.time()
         print("# %4.0f s: %s" % (last - t0, {k: v[0] for k, v in stats.items()}), flush=True)
-print("# fuzz_soak seed %d, %.0f s on %s" % (seed, time.time() - t0, lib.capy_version().decode()))
+print("# fuzz_soak seed %d, %.0f s on %s%s" % (seed, time.time() - t0, lib.capy_version().decode(),
+                                              ", capy_set_devices(%s)" % _devs if _devs else ""))
 for k in sorted(stats):
     print("%-26s calls %5d   failures %d" % (k, stats[k][0], stats[k][1]))
 print("# total calls %d, failures %d" % (sum(v[0] for v in stats.values()), len(failures)))
