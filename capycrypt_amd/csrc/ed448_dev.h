@@ -122,11 +122,52 @@ CAPY_HD inline Fe fe_sub4(const Fe &a, const Fe &b)
     return r;
 }
 
+// CAPY_ED448_SETPRIO (r04): raise the wave's priority around the 4-cycle instructions of fe_mul / fe_sqr (multiply-add chains,
+// 64-bit subtractions, carry chain) so that the other wave of the SIMD can issue its SIMPLE instructions (limb sums, masks, the
+// limb arithmetic between products) in the half windows they leave (profiles/r03_valu_issue_bisect.txt, finding 4).
+//   1: priority 1 from the first multiply-add to the last;  2: priority 1 up to the end of the carry chain, the 16 masks of the
+//   result deferred into one block at priority 0 (so that a wave at priority 0 holds simple instructions only).
+// Pays in vb2_kernel only (two waves per SIMD, pinned chains): profiles/r04_ed448_setprio.txt.
+#ifndef CAPY_ED448_SETPRIO
+#define CAPY_ED448_SETPRIO 0
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && CAPY_ED448_SETPRIO
+#define CAPY_ED448_PRIO(x) __builtin_amdgcn_s_setprio(x)
+#else
+#define CAPY_ED448_PRIO(x)
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && CAPY_ED448_SETPRIO == 2
+#define CAPY_ED448_PRIO_TAIL(x) __builtin_amdgcn_s_setprio(x)
+#define CAPY_ED448_PRIO_MID(x)
+#else
+#define CAPY_ED448_PRIO_TAIL(x)
+#define CAPY_ED448_PRIO_MID(x) CAPY_ED448_PRIO(x)
+#endif
+
 // 16 column sums (lo = columns 0..7, hi = 8..15), each < 2^63, to 28-bit limbs
 CAPY_HD inline Fe fe_from_columns(uint64_t lo[8], uint64_t hi[8])
 {
     Fe r;
     uint64_t c = 0;
+#if defined(__HIP_DEVICE_COMPILE__) && CAPY_ED448_SETPRIO == 2
+    // the carry chain at priority 1 with the low dwords kept unmasked, then all masks and the wrap in one block at priority 0
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        uint64_t v = lo[k] + c;
+        r.l[k] = (uint32_t)v;
+        c = v >> 28;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        uint64_t v = hi[k] + c;
+        r.l[8 + k] = (uint32_t)v;
+        c = v >> 28;
+    }
+    asm volatile("" ::: "memory");
+    CAPY_ED448_PRIO_TAIL(0);
+#pragma unroll
+    for (int k = 0; k < 16; k++) r.l[k] &= M28;
+#else
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         uint64_t v = lo[k] + c;
@@ -139,6 +180,7 @@ CAPY_HD inline Fe fe_from_columns(uint64_t lo[8], uint64_t hi[8])
         r.l[8 + k] = (uint32_t)v & M28;
         c = v >> 28;
     }
+#endif
     // c * 2^448 = c * (2^224 + 1), c < 2^36
     uint64_t v = r.l[0] + c;
     r.l[0] = (uint32_t)v & M28;
@@ -249,6 +291,7 @@ CAPY_HD CAPY_NOINLINE inline Fe fe_mul(const Fe a, const Fe b)
     uint64_t aa[15], lo[8], hi[8], cch[7];
 #pragma unroll
     for (int k = 0; k < 15; k++) aa[k] = 0;
+    CAPY_ED448_PRIO(1);
 #pragma unroll
     for (int i = 0; i < 8; i++)
 #pragma unroll
@@ -279,6 +322,7 @@ CAPY_HD CAPY_NOINLINE inline Fe fe_mul(const Fe a, const Fe b)
                 hi[k - 8] = mad64(a.l[8 + i], b.l[8 + j], hi[k - 8]);
             }
         }
+    CAPY_ED448_PRIO_MID(0);
 #pragma unroll
     for (int k = 0; k < 8; k++) hi[k] -= aa[k];
 #pragma unroll
@@ -349,6 +393,7 @@ CAPY_HD CAPY_NOINLINE inline Fe fe_sqr(const Fe a)
     uint64_t aa[15];
 #pragma unroll
     for (int k = 0; k < 15; k++) aa[k] = 0;
+    CAPY_ED448_PRIO(1);
 #pragma unroll
     for (int i = 0; i < 8; i++)
 #pragma unroll
@@ -377,9 +422,15 @@ CAPY_HD CAPY_NOINLINE inline Fe fe_sqr(const Fe a)
                 ohi[k - 8] = mad64(a.l[8 + i], a.l[8 + j], ohi[k - 8]);
             }
         }
+    CAPY_ED448_PRIO_MID(0);
     // columns in carry order; the diagonal squares of column k sit at index k / 2 (even k only)
     Fe r;
     uint64_t c = 0;
+#if defined(__HIP_DEVICE_COMPILE__) && CAPY_ED448_SETPRIO == 2
+    constexpr uint32_t MASK_NOW = 0xffffffffu;  // masks deferred into one block behind the carry chain (see fe_from_columns)
+#else
+    constexpr uint32_t MASK_NOW = M28;
+#endif
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         uint64_t d = c;
@@ -390,7 +441,7 @@ CAPY_HD CAPY_NOINLINE inline Fe fe_sqr(const Fe a)
         d += aa[k];
         if (k < 7) d -= aa[k + 8];
         const uint64_t v = (olo[k] << 1) + d;
-        r.l[k] = (uint32_t)v & M28;
+        r.l[k] = (uint32_t)v & MASK_NOW;
         c = v >> 28;
     }
 #pragma unroll
@@ -405,9 +456,15 @@ CAPY_HD CAPY_NOINLINE inline Fe fe_sqr(const Fe a)
         }
         d -= aa[k];
         const uint64_t v = (ohi[k] << 1) + d;
-        r.l[8 + k] = (uint32_t)v & M28;
+        r.l[8 + k] = (uint32_t)v & MASK_NOW;
         c = v >> 28;
     }
+#if defined(__HIP_DEVICE_COMPILE__) && CAPY_ED448_SETPRIO == 2
+    asm volatile("" ::: "memory");
+    CAPY_ED448_PRIO_TAIL(0);
+#pragma unroll
+    for (int k = 0; k < 16; k++) r.l[k] &= M28;
+#endif
     // c * 2^448 = c * (2^224 + 1), c < 2^36
     uint64_t v = r.l[0] + c;
     r.l[0] = (uint32_t)v & M28;

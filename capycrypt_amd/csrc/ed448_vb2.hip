@@ -7,6 +7,12 @@
 #ifndef CAPY_ED448_ASM_MAD
 #define CAPY_ED448_ASM_MAD 1
 #endif
+// ... and the one kernel that gains from raised priority around its 4-cycle instructions (two waves per SIMD; needs the
+// pinned chains; ed448_dev.h: CAPY_ED448_SETPRIO): 9.63 -> 9.27 ms with form 1, -5 % with form 2 (profiles/r04_ed448_setprio.txt);
+// the one-wave-per-SIMD kernels of ed448.hip lose 1-3 % with it.
+#ifndef CAPY_ED448_SETPRIO
+#define CAPY_ED448_SETPRIO 2
+#endif
 #include "common.h"
 #include "ed448_algo.h"
 
