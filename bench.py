@@ -606,12 +606,14 @@ def main():
                 ach = waves * e["valu_insts_per_wave"] / (ed["kernel_ms"] * 1e-3)
                 clk = e.get("effective_clock_GHz", 2.4)
                 ceil_ = 1024 * clk * 1e9 / 4.0
-                ed["roofline"] = {"bound": "valu (32x32+64 multiply-adds; r04: their ENERGY binds, not their issue slots -- 4.6 % "
-                                           "fewer instructions with 8 % more multiply-adds ran no faster, profiles/r04_ed448_fe_trim.txt)",
+                ed["roofline"] = {"bound": "valu issue (79 % of the stream are 4-cycle instructions: 32x32+64 multiply-adds, 64-bit "
+                                           "adds / subtractions / shifts; since r04 the other wave of the SIMD fills part of the half "
+                                           "windows they leave with its simple instructions: profiles/r04_ed448_setprio.txt)",
                                   "kernel": kn.split("(")[0],
                                   "valu_insts_per_unit": insts_unit, "achieved": ach / 1e9, "unit": "G wave-instructions/s",
                                   "peak": ceil_ / 1e9, "frac": ach / ceil_, "clock_GHz": clk,
-                                  "peak_note": "1024 SIMDs x clock / 4 cycles per instruction (single-wave issue rate)",
+                                  "peak_note": "1024 SIMDs x clock / 4 cycles per instruction (the issue rate of a stream of 4-cycle "
+                                               "instructions; 21 % of this one are simple instructions that can pair, so 1.0 is not a bound)",
                                   "source": "profiles/%s" % pm_file}
         if not a.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(a.cpu_seconds)
