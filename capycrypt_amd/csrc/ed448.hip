@@ -42,24 +42,48 @@ __attribute__((amdgpu_num_vgpr(CAPY_ED448_NUMVGPR)))
 #ifndef CAPY_ED448_PREFETCH_DSM
 #define CAPY_ED448_PREFETCH_DSM 1
 #endif
-__global__ __launch_bounds__(64, CAPY_ED448_WAVES) void vb_kernel(uint64_t n, const uint8_t *scalars_be, uint64_t scalar_stride,
-                                                const uint8_t *points_xy, uint64_t point_stride, uint8_t *out_xy,
-                                                uint32_t *table_ws)
+// One item per lane.  Each of vb_kernel / vb_ct_kernel / dsm_kernel exists twice: the plain form (two waves per SIMD fit) for
+// batches beyond one wave per SIMD, and a *_1w form compiled for exactly one wave per SIMD (see CAPY_ONE_WAVE_PER_SIMD below)
+// for batches of up to 64 items per SIMD, whose launch time is one wave's chain and must not double because the dispatcher
+// put two waves on one SIMD.
+__device__ __forceinline__ void vb_body(uint64_t n, const uint8_t *scalars_be, uint64_t scalar_stride, const uint8_t *points_xy,
+                                        uint64_t point_stride, uint8_t *out_xy, uint32_t *table_ws, uint32_t *pf)
 {
     const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
     if (i >= n) return;
-#if CAPY_ED448_PREFETCH_VB
-    __shared__ uint32_t pf[VB_PF_DWORDS];
-#else
-    uint32_t *const pf = nullptr;
-#endif
     const Pt P = pt_from_affine_bytes(points_xy + i * point_stride);
     const Pt r = vb_scalarmul(scalars_be + i * scalar_stride, P, table_ws + i * VB_TABLE_DWORDS, pf);
     pt_to_affine_bytes(out_xy + i * 112, r);
 }
+#if CAPY_ED448_PREFETCH_VB
+#define CAPY_VB_PF __shared__ uint32_t pf[VB_PF_DWORDS];
+#else
+#define CAPY_VB_PF uint32_t *const pf = nullptr;
+#endif
+__global__ __launch_bounds__(64, CAPY_ED448_WAVES) void vb_kernel(uint64_t n, const uint8_t *scalars_be, uint64_t scalar_stride,
+                                                const uint8_t *points_xy, uint64_t point_stride, uint8_t *out_xy,
+                                                uint32_t *table_ws)
+{
+    CAPY_VB_PF
+    vb_body(n, scalars_be, scalar_stride, points_xy, point_stride, out_xy, table_ws, pf);
+}
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void vb_kernel_1w(
+    uint64_t n, const uint8_t *scalars_be, uint64_t scalar_stride, const uint8_t *points_xy, uint64_t point_stride, uint8_t *out_xy,
+    uint32_t *table_ws)
+{
+    CAPY_VB_PF
+    vb_body(n, scalars_be, scalar_stride, points_xy, point_stride, out_xy, table_ws, pf);
+}
+
+// The kernels below are chosen for batches that put at most ONE wave on a SIMD, where the time of the launch is the chain of
+// one wave -- if the dispatcher puts two of them on one SIMD (it does when the launch follows a kernel whose waves end
+// staggered: 32 768 items in the two-lane form took 3.3 instead of 1.8 ms behind a 196 608-item launch,
+// profiles/r04_ed448_remainder.txt) the launch takes twice as long.  amdgpu_waves_per_eu(1, 1) rounds the register
+// allocation up so that a second wave of the SAME kernel does not fit on the SIMD.
+#define CAPY_ONE_WAVE_PER_SIMD __attribute__((amdgpu_waves_per_eu(1, 1)))
 
 // four lanes per item (ed448_quad.h): batches between the one-item-per-wave and the one-item-per-lane kernels
-__global__ __launch_bounds__(64, 2) void vb_quad_kernel(uint64_t n, const uint8_t *scalars_be, uint64_t scalar_stride,
+__global__ __launch_bounds__(64) CAPY_ONE_WAVE_PER_SIMD void vb_quad_kernel(uint64_t n, const uint8_t *scalars_be, uint64_t scalar_stride,
                                                         const uint8_t *points_xy, uint64_t point_stride, uint8_t *out_xy,
                                                         uint32_t *table_ws)
 {
@@ -76,7 +100,7 @@ __global__ __launch_bounds__(64, 2) void vb_quad_kernel(uint64_t n, const uint8_
 }
 
 // [a]G + [b]P with four lanes per item (the shape of verify, /root/reference/src/ecc/signable.rs:77)
-__global__ __launch_bounds__(64, 2) void dsm_quad_kernel(uint64_t n, const uint8_t *a_be, const uint8_t *b_be, const uint8_t *points_xy,
+__global__ __launch_bounds__(64) CAPY_ONE_WAVE_PER_SIMD void dsm_quad_kernel(uint64_t n, const uint8_t *a_be, const uint8_t *b_be, const uint8_t *points_xy,
                                                          uint8_t *out_xy, uint32_t *table_ws, const uint32_t *gtab)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -108,7 +132,7 @@ __global__ __launch_bounds__(64, 1) void vb_quad_ct_kernel(uint64_t n, const uin
 }
 
 // two lanes per item (ed448_duo.h): 16 k .. 32 k items, one wave of 32 items per SIMD at 32 768
-__global__ __launch_bounds__(64, 1) void vb_duo_kernel(uint64_t n, const uint8_t *scalars_be, uint64_t scalar_stride,
+__global__ __launch_bounds__(64) CAPY_ONE_WAVE_PER_SIMD void vb_duo_kernel(uint64_t n, const uint8_t *scalars_be, uint64_t scalar_stride,
                                                        const uint8_t *points_xy, uint64_t point_stride, uint8_t *out_xy,
                                                        uint32_t *table_ws)
 {
@@ -121,7 +145,7 @@ __global__ __launch_bounds__(64, 1) void vb_duo_kernel(uint64_t n, const uint8_t
 #endif
 }
 
-__global__ __launch_bounds__(64, 1) void dsm_duo_kernel(uint64_t n, const uint8_t *a_be, const uint8_t *b_be, const uint8_t *points_xy,
+__global__ __launch_bounds__(64) CAPY_ONE_WAVE_PER_SIMD void dsm_duo_kernel(uint64_t n, const uint8_t *a_be, const uint8_t *b_be, const uint8_t *points_xy,
                                                         uint8_t *out_xy, uint32_t *table_ws, const uint32_t *gtab)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -135,9 +159,8 @@ __global__ __launch_bounds__(64, 1) void dsm_duo_kernel(uint64_t n, const uint8_
 }
 
 // hardened form: constant-address table lookups (ed448_algo.h: vb_add_digit_ct); also serves [k]G with point_stride 0
-__global__ __launch_bounds__(64, CAPY_ED448_WAVES) void vb_ct_kernel(uint64_t n, const uint8_t *scalars_be, uint64_t scalar_stride,
-                                                   const uint8_t *points_xy, uint64_t point_stride, uint8_t *out_xy,
-                                                   uint32_t *table_ws)
+__device__ __forceinline__ void vb_ct_body(uint64_t n, const uint8_t *scalars_be, uint64_t scalar_stride, const uint8_t *points_xy,
+                                           uint64_t point_stride, uint8_t *out_xy, uint32_t *table_ws)
 {
     const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
     if (i >= n) return;
@@ -146,6 +169,18 @@ __global__ __launch_bounds__(64, CAPY_ED448_WAVES) void vb_ct_kernel(uint64_t n,
     const CtTable t = {table_ws + (uint64_t)blockIdx.x * 64 * VB_TABLE_DWORDS, threadIdx.x, 64};
     const Pt r = vb_scalarmul_ct(scalars_be + i * scalar_stride, P, t);
     pt_to_affine_bytes(out_xy + i * 112, r);
+}
+__global__ __launch_bounds__(64, CAPY_ED448_WAVES) void vb_ct_kernel(uint64_t n, const uint8_t *scalars_be, uint64_t scalar_stride,
+                                                   const uint8_t *points_xy, uint64_t point_stride, uint8_t *out_xy,
+                                                   uint32_t *table_ws)
+{
+    vb_ct_body(n, scalars_be, scalar_stride, points_xy, point_stride, out_xy, table_ws);
+}
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void vb_ct_kernel_1w(
+    uint64_t n, const uint8_t *scalars_be, uint64_t scalar_stride, const uint8_t *points_xy, uint64_t point_stride, uint8_t *out_xy,
+    uint32_t *table_ws)
+{
+    vb_ct_body(n, scalars_be, scalar_stride, points_xy, point_stride, out_xy, table_ws);
 }
 
 __global__ __launch_bounds__(64, CAPY_ED448_WAVES) void fb_ct_kernel(uint64_t n, const uint8_t *scalars_be, uint8_t *out_xy,
@@ -291,20 +326,33 @@ __global__ __launch_bounds__(64, CAPY_ED448_WAVES) void fb2_kernel(uint64_t n, c
     }
 }
 
+__device__ __forceinline__ void dsm_body(uint64_t n, const uint8_t *a_be, const uint8_t *b_be, const uint8_t *points_xy, uint8_t *out_xy,
+                                         uint32_t *table_ws, const uint32_t *gtab, uint32_t *pf)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    const Pt P = pt_from_affine_bytes(points_xy + i * 112);
+    const Pt r = double_scalarmul(a_be + i * 56, b_be + i * 56, P, table_ws + i * VB_TABLE_DWORDS, gtab, pf);
+    pt_to_affine_bytes(out_xy + i * 112, r);
+}
+#if CAPY_ED448_PREFETCH_DSM
+#define CAPY_DSM_PF __shared__ uint32_t pf[VB_PF_DWORDS];  /* serves the variable-base part, then the fixed-base part */
+#else
+#define CAPY_DSM_PF uint32_t *const pf = nullptr;
+#endif
 __global__ __launch_bounds__(64, CAPY_ED448_WAVES) void dsm_kernel(uint64_t n, const uint8_t *a_be, const uint8_t *b_be,
                                                  const uint8_t *points_xy, uint8_t *out_xy, uint32_t *table_ws,
                                                  const uint32_t *gtab)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
-    if (i >= n) return;
-#if CAPY_ED448_PREFETCH_DSM
-    __shared__ uint32_t pf[VB_PF_DWORDS];  // serves the variable-base part, then the fixed-base part
-#else
-    uint32_t *const pf = nullptr;
-#endif
-    const Pt P = pt_from_affine_bytes(points_xy + i * 112);
-    const Pt r = double_scalarmul(a_be + i * 56, b_be + i * 56, P, table_ws + i * VB_TABLE_DWORDS, gtab, pf);
-    pt_to_affine_bytes(out_xy + i * 112, r);
+    CAPY_DSM_PF
+    dsm_body(n, a_be, b_be, points_xy, out_xy, table_ws, gtab, pf);
+}
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void dsm_kernel_1w(
+    uint64_t n, const uint8_t *a_be, const uint8_t *b_be, const uint8_t *points_xy, uint8_t *out_xy, uint32_t *table_ws,
+    const uint32_t *gtab)
+{
+    CAPY_DSM_PF
+    dsm_body(n, a_be, b_be, points_xy, out_xy, table_ws, gtab, pf);
 }
 
 __global__ __launch_bounds__(64) void add_kernel(uint64_t n, const uint8_t *p_xy, const uint8_t *q_xy, uint8_t *out_xy)
@@ -492,11 +540,36 @@ static size_t quad_ct_max_items()
 static bool duo_range(size_t n) { return n > duo_min_items() && n <= duo_max_items(); }
 static bool quad_range(size_t n) { return !duo_range(n) && n > quad_min_items() && n <= quad_max_items(); }
 
+// Wave quantisation of the one-item-per-lane kernels: a batch of q x 65 536 + x items puts a further wave on x / 64 SIMDs, and
+// the launch takes a whole further chain (2.3-3.3 ms) however small x is -- 81 920 items took 5.03 ms where 65 536 take 2.88
+// (profiles/r04_ed448_remainder.txt).  A remainder of up to 32 768 items is therefore peeled off into a launch of its own,
+// which takes the kernel family of ITS size (one item per wave, four or two lanes per item: 0.4-1.8 ms), on the same stream.
+// CAPY_DEBUG=ed448_peel=0 switches it off.
+// batches of at most one wave per SIMD in the one-item-per-lane form take the *_1w kernels
+static size_t one_wave_items() { return 65536; }
+static size_t peel_remainder(size_t n)
+{
+    static const bool on = debug_knob("ed448_peel", 1) != 0;
+    const size_t quantum = 65536;  // 1024 SIMDs x 64 lanes
+    if (!on || n <= quantum) return 0;
+    const size_t x = n % quantum;
+    return x <= 32768 ? x : 0;
+}
+
 // secret: the scalars are key material (see harden())
 static int vb_launch(size_t n, const uint8_t *scalars, uint64_t scalar_stride, const uint8_t *points,
                      uint64_t point_stride, uint8_t *out, hipStream_t s, bool secret)
 {
     if (!n) return CAPY_OK;
+    if (const size_t x = peel_remainder(n)) {
+        // the remainder FIRST: its waves all start on an empty chip and run equally long, so the big launch behind it starts
+        // on an empty chip too.  Behind the big launch (whose waves end staggered) the remainder's waves doubled up on the
+        // SIMDs that happened to be free: 32 768 items took 3.7 ms there instead of 1.8
+        const int rc = vb_launch(x, scalars + (n - x) * scalar_stride, scalar_stride, points + (n - x) * point_stride, point_stride,
+                                 out + (n - x) * 112, s, secret);
+        if (rc) return rc;
+        return vb_launch(n - x, scalars, scalar_stride, points, point_stride, out, s, secret);
+    }
     const bool ct = harden(secret);
     const bool quad_ct = ct && n > quad_min_items() && n <= quad_ct_max_items();
     const bool wave_family = n <= wave_max_items() && !quad_ct && (ct || !(duo_range(n) || quad_range(n)));
@@ -546,13 +619,21 @@ static int vb_launch(size_t n, const uint8_t *scalars, uint64_t scalar_stride, c
         // 2^18 items against 12.9 ms here (profiles/r03_ed448_hardened.txt) -- at two waves per SIMD the 17-row scans
         // of the wave-interleaved table have nothing to hide behind
 
-        hipLaunchKernelGGL(vb_ct_kernel, grid64(n), dim3(64), 0, s, (uint64_t)n, scalars, scalar_stride, points, point_stride,
-                           out, tab);
+        if (n <= one_wave_items())
+            hipLaunchKernelGGL(vb_ct_kernel_1w, grid64(n), dim3(64), 0, s, (uint64_t)n, scalars, scalar_stride, points, point_stride,
+                               out, tab);
+        else
+            hipLaunchKernelGGL(vb_ct_kernel, grid64(n), dim3(64), 0, s, (uint64_t)n, scalars, scalar_stride, points, point_stride,
+                               out, tab);
     } else if (n >= pair_min_items()) {
         return vb2_launch(n, scalars, scalar_stride, points, point_stride, out, tab, s);
     } else {
-        hipLaunchKernelGGL(vb_kernel, grid64(n), dim3(64), 0, s, (uint64_t)n, scalars, scalar_stride, points, point_stride,
-                           out, tab);
+        if (n <= one_wave_items())
+            hipLaunchKernelGGL(vb_kernel_1w, grid64(n), dim3(64), 0, s, (uint64_t)n, scalars, scalar_stride, points, point_stride,
+                               out, tab);
+        else
+            hipLaunchKernelGGL(vb_kernel, grid64(n), dim3(64), 0, s, (uint64_t)n, scalars, scalar_stride, points, point_stride,
+                               out, tab);
     }
     CAPY_HIP(hipGetLastError());
     return CAPY_OK;
@@ -772,6 +853,11 @@ static int fb_launch(size_t n, const uint8_t *scalars, uint8_t *out, hipStream_t
 static int dsm_launch(size_t n, const uint8_t *a, const uint8_t *b, const uint8_t *points, uint8_t *out, hipStream_t s)
 {
     if (!n) return CAPY_OK;
+    if (const size_t x = peel_remainder(n)) {  // see peel_remainder() and vb_launch(): the remainder first
+        const int rc = dsm_launch(x, a + (n - x) * 56, b + (n - x) * 56, points + (n - x) * 112, out + (n - x) * 112, s);
+        if (rc) return rc;
+        return dsm_launch(n - x, a, b, points, out, s);
+    }
     const uint32_t *gt = nullptr;
     int rc = ensure_gtab(&gt);
     if (rc) return rc;
@@ -795,7 +881,10 @@ static int dsm_launch(size_t n, const uint8_t *a, const uint8_t *b, const uint8_
         return CAPY_OK;
     }
     CAPY_WS(tab, uint32_t *, s, WS_TABLE, n * VB_TABLE_DWORDS * 4);
-    hipLaunchKernelGGL(dsm_kernel, grid64(n), dim3(64), 0, s, (uint64_t)n, a, b, points, out, tab, gt);
+    if (n <= one_wave_items())
+        hipLaunchKernelGGL(dsm_kernel_1w, grid64(n), dim3(64), 0, s, (uint64_t)n, a, b, points, out, tab, gt);
+    else
+        hipLaunchKernelGGL(dsm_kernel, grid64(n), dim3(64), 0, s, (uint64_t)n, a, b, points, out, tab, gt);
     CAPY_HIP(hipGetLastError());
     return CAPY_OK;
 }

@@ -466,3 +466,47 @@ def test_constant_address_quad_kernel_equals_the_other_hardened_kernels(capy, O)
         capy.ops.ed448_set_hardened(capy.ops.HARDEN_PROTOCOL)
         _lib.check(lib.capy_ed448_set_quad_range(-1, -1))
         _lib.check(lib.capy_ed448_set_duo_range(-1, -1))
+
+
+def test_batches_between_the_wave_quanta_are_split_and_stay_byte_identical(capy, O):
+    """csrc/ed448.hip: peel_remainder (r04).  A batch of q x 65 536 + x items (0 < x <= 32 768) in the one-item-per-lane regime
+    is launched as its remainder (in the kernel family of ITS size) followed by the whole quanta.  The outputs must be those of
+    item-by-item evaluation: the indexed and the constant-address paths (which split into different kernel pairs) agree byte
+    for byte, the items on both sides of the cut and at both ends match the oracle, and verify (the double multiplication,
+    split the same way) accepts what sign produced for such a batch."""
+    import torch
+
+    from capycrypt_amd import _lib
+
+    lib = _lib.lib()
+    rng = random.Random(0x9EE1)
+    sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    try:
+        for n, x in ((65536 + 37, 37), (65536 + 5000, 5000), (65536 + 20000, 20000), (131072 + 32768, 32768)):
+            sc = torch.empty(n * 56, dtype=torch.uint8, device="cuda")
+            asc = torch.empty(n * 56, dtype=torch.uint8, device="cuda")
+            tsc = torch.empty(n * 56, dtype=torch.uint8, device="cuda")
+            for t, seed in ((sc, 1), (asc, 2), (tsc, 3)):
+                _lib.check(lib.capy_fill_random_dev(t.data_ptr(), n * 56, 700 + seed + n, sp))
+            pts = torch.empty(n * 112, dtype=torch.uint8, device="cuda")
+            _lib.check(lib.capy_ed448_basemul_batch_dev(n, tsc.data_ptr(), pts.data_ptr(), sp))
+            outs = {}
+            for mode in (capy.ops.HARDEN_OFF, capy.ops.HARDEN_ALL):
+                capy.ops.ed448_set_hardened(mode)
+                vb = torch.zeros(n * 112, dtype=torch.uint8, device="cuda")
+                _lib.check(lib.capy_ed448_scalarmul_batch_dev(n, sc.data_ptr(), pts.data_ptr(), vb.data_ptr(), sp))
+                torch.cuda.synchronize()
+                outs[mode] = vb
+            assert torch.equal(outs[capy.ops.HARDEN_OFF], outs[capy.ops.HARDEN_ALL]), n
+            ds = torch.zeros(n * 112, dtype=torch.uint8, device="cuda")
+            capy.ops.ed448_set_hardened(capy.ops.HARDEN_OFF)
+            _lib.check(lib.capy_ed448_double_scalarmul_batch_dev(n, asc.data_ptr(), sc.data_ptr(), pts.data_ptr(), ds.data_ptr(), sp))
+            hs, ha, hp = bytes(sc.cpu().numpy()), bytes(asc.cpu().numpy()), bytes(pts.cpu().numpy())
+            hv, hd = bytes(outs[capy.ops.HARDEN_OFF].cpu().numpy()), bytes(ds.cpu().numpy())
+            for i in (0, 1, n - x - 2, n - x - 1, n - x, n - x + 1, n - 2, n - 1, rng.randrange(n)):
+                k, a, pt = hs[56 * i:56 * i + 56], ha[56 * i:56 * i + 56], hp[112 * i:112 * i + 112]
+                want = O.ed448_scalarmul(k, pt)
+                assert hv[112 * i:112 * i + 112] == want, (n, i)
+                assert hd[112 * i:112 * i + 112] == O.ed448_add(O.ed448_basemul(a), want), (n, i)
+    finally:
+        capy.ops.ed448_set_hardened(capy.ops.HARDEN_PROTOCOL)
