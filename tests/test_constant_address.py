@@ -158,10 +158,12 @@ def test_counters_do_not_depend_on_the_scalars_in_hardened_mode():
     _, l2i = results["indexed"]
     # the instrument sees the leak: with indexed lookups of a SHARED table the request count follows the scalars (one row
     # for the whole wave against 64 different rows: 4.7x measured); with per-item tables (variable base) every lane reads
-    # its own table either way, the count moves by 3 % and the L2 hit count by 30 %
+    # its own table either way, the request count hardly moves and the L2 HIT count moves by 30 %
     for op in ("fixed_base", "keypair"):
         s, vals = _spread(l2i, op, "TCC_REQ_sum")
         assert s >= 0.5, ("indexed", op, vals)
     s_req, v_req = _spread(l2i, "variable_base", "TCC_REQ_sum")
     s_hit, v_hit = _spread(l2i, "variable_base", "TCC_HIT_sum")
-    assert s_req >= 0.01 and s_hit >= 0.10, ("indexed", "variable_base", v_req, v_hit)
+    # (the request COUNT need not move: every lane reads one entry per window whatever the digit -- with the *_1w kernel of r04,
+    # which hardly spills, it is the same to 0.2 %; which lines those requests hit is what follows the digits)
+    assert s_hit >= 0.10, ("indexed", "variable_base", v_req, v_hit)
