@@ -14,6 +14,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// at most MAXW waves of the kernel per SIMD: the register allocation in the kernel descriptor is rounded up accordingly
+#define CAPY_WAVES_PER_SIMD(MAXW) __attribute__((amdgpu_waves_per_eu(1, (MAXW))))
+
 namespace capy {
 
 __device__ __constant__ const uint32_t KECCAK_RC32[48] = {

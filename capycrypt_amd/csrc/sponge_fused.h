@@ -60,7 +60,7 @@ __device__ __forceinline__ uint32_t quad_swap_pairs(uint32_t v)
 // PAIRED (r03): the launch puts two or three waves on a SIMD (16 384 < n <= 49 152): the hot loop runs the blocked round
 // with raised priority around its DPP / rotation blocks (sponge_kernels_k2.h: keccak_round_k2_blocked).
 template <int RW, bool STAGED = false, bool PAIRED = false>
-__global__ __launch_bounds__(64) void sponge_fused_crypt_kernel(const FusedParams fp)
+__global__ __launch_bounds__(64) CAPY_WAVES_PER_SIMD(PAIRED ? 8 : 1) void sponge_fused_crypt_kernel(const FusedParams fp)
 {
     constexpr uint32_t RB = RW * 8;
     constexpr int NIT = 16;                       // items per wave

@@ -78,8 +78,11 @@ __device__ __forceinline__ uint64_t state_word(const KState &a, int w) { return 
 // WAVES = waves per SIMD the register budget is sized for (2: latency-tuned, 256 VGPRs; 3: issue-tuned, 168 VGPRs).
 // A 3-wave copy of the issue-tuned instance for ragged batches was tried and dropped: the latency-tuned instance is
 // faster there (see launch_sponge in sponge.hip).
-template <int RW, bool FULLCHIP, int MODE, int WAVES = (FULLCHIP ? CAPY_FULLCHIP_WAVES : 2), bool PAIRED = false>
-__global__ __launch_bounds__(64, WAVES) void sponge_kernel(const SpongeParams p)
+// WAVES = 1 (the latency-tuned instance, taken for at most one wave per SIMD): compiled so that a second wave of the SAME kernel
+// does not fit on the SIMD (CAPY_WAVES_PER_SIMD below) -- behind a launch whose waves end staggered the dispatcher otherwise
+// doubles waves up on the SIMDs that happen to be free and the launch takes up to twice as long (profiles/r04_placement.txt).
+template <int RW, bool FULLCHIP, int MODE, int WAVES = (FULLCHIP ? CAPY_FULLCHIP_WAVES : 1), bool PAIRED = false>
+__global__ __launch_bounds__(64, WAVES) CAPY_WAVES_PER_SIMD(WAVES == 1 ? 1 : 8) void sponge_kernel(const SpongeParams p)
 {
     constexpr uint32_t RB = RW * 8;
     __shared__ uint64_t s_stage[64 * RW];

@@ -170,8 +170,9 @@ __device__ __forceinline__ void keccakf1600_k2_pipelined(KHalf &s, uint32_t hmas
 // BODY 1: the rolled two-round form above (A/B instance, selected by debug bit 3 of capy_set_sponge_lanes)
 // BODY 2: the blocked round with raised priority (keccak_round_k2_blocked), for two waves per SIMD (A/B instance for
 //         SHA3-256 digests, forced two-lane launches of more than 32 sponges per SIMD: profiles/r03_chipfull.txt)
+// BODY 0 / 1 serve at most 32 sponges per SIMD = one wave per SIMD: see CAPY_WAVES_PER_SIMD (keccak_dev.h)
 template <int RW, int MODE, int BODY = 0>
-__global__ __launch_bounds__(64) void sponge_kernel_k2(const SpongeParams p)
+__global__ __launch_bounds__(64) CAPY_WAVES_PER_SIMD(BODY == 2 ? 8 : 1) void sponge_kernel_k2(const SpongeParams p)
 {
     constexpr uint32_t RB = RW * 8;
     constexpr int NSP = 32;                        // sponges per wave

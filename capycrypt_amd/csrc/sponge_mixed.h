@@ -224,7 +224,7 @@ __device__ __forceinline__ void mixed_body_k2(const MixedParams &q, uint32_t wav
 }
 
 template <int RW>
-__global__ __launch_bounds__(64) void sponge_mixed_kernel(const MixedParams q)
+__global__ __launch_bounds__(64) CAPY_WAVES_PER_SIMD(1) void sponge_mixed_kernel(const MixedParams q)
 {
     if (blockIdx.x < q.k2_waves)
         mixed_body_k2<RW, false>(q, blockIdx.x, nullptr);

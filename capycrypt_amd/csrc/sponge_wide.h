@@ -161,7 +161,7 @@ __device__ __forceinline__ void wide_permute(uint32_t &lo, uint32_t &hi, const W
 }
 
 template <int RW>
-__global__ __launch_bounds__(64) void sponge_wide_crypt_kernel(const FusedParams fp)
+__global__ __launch_bounds__(64) CAPY_WAVES_PER_SIMD(1) void sponge_wide_crypt_kernel(const FusedParams fp)
 {
     constexpr uint32_t RB = RW * 8;
     const uint32_t lane = threadIdx.x, role = lane >> 5, i = lane & 31;  // role 0 = tag sponge, 1 = keystream sponge
@@ -344,7 +344,7 @@ namespace capy {
 // The two items of a wave may differ in length: the wave runs max(blocks) steps and a half whose item is finished
 // keeps its state across the remaining wave-wide permutations.
 template <int RW>
-__global__ __launch_bounds__(64) void sponge_wide_digest_kernel(const SpongeParams p)
+__global__ __launch_bounds__(64) CAPY_WAVES_PER_SIMD(1) void sponge_wide_digest_kernel(const SpongeParams p)
 {
     constexpr uint32_t RB = RW * 8;
     const uint32_t lane = threadIdx.x, half = lane >> 5, i = lane & 31;
