@@ -5,6 +5,7 @@
 #include <atomic>
 #include <mutex>
 #include "common.h"
+#include "occupancy.h"
 #include "ed448_algo.h"
 #include "ed448_wave.h"
 #include "ed448_fb7.h"
@@ -43,7 +44,7 @@ __attribute__((amdgpu_num_vgpr(CAPY_ED448_NUMVGPR)))
 #define CAPY_ED448_PREFETCH_DSM 1
 #endif
 // One item per lane.  Each of vb_kernel / vb_ct_kernel / dsm_kernel exists twice: the plain form (two waves per SIMD fit) for
-// batches beyond one wave per SIMD, and a *_1w form compiled for exactly one wave per SIMD (see CAPY_ONE_WAVE_PER_SIMD below)
+// batches beyond one wave per SIMD, and a *_1w form compiled for exactly one wave per SIMD (CAPY_WAVES_PER_SIMD, occupancy.h)
 // for batches of up to 64 items per SIMD, whose launch time is one wave's chain and must not double because the dispatcher
 // put two waves on one SIMD.
 __device__ __forceinline__ void vb_body(uint64_t n, const uint8_t *scalars_be, uint64_t scalar_stride, const uint8_t *points_xy,
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(64, CAPY_ED448_WAVES) void vb_kernel(uint64_t n, co
     CAPY_VB_PF
     vb_body(n, scalars_be, scalar_stride, points_xy, point_stride, out_xy, table_ws, pf);
 }
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void vb_kernel_1w(
+__global__ __launch_bounds__(64) CAPY_WAVES_PER_SIMD(1) void vb_kernel_1w(
     uint64_t n, const uint8_t *scalars_be, uint64_t scalar_stride, const uint8_t *points_xy, uint64_t point_stride, uint8_t *out_xy,
     uint32_t *table_ws)
 {
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 // staggered: 32 768 items in the two-lane form took 3.3 instead of 1.8 ms behind a 196 608-item launch,
 // profiles/r04_ed448_remainder.txt) the launch takes twice as long.  amdgpu_waves_per_eu(1, 1) rounds the register
 // allocation up so that a second wave of the SAME kernel does not fit on the SIMD.
-#define CAPY_ONE_WAVE_PER_SIMD __attribute__((amdgpu_waves_per_eu(1, 1)))
+#define CAPY_ONE_WAVE_PER_SIMD CAPY_WAVES_PER_SIMD(1)
 
 // four lanes per item (ed448_quad.h): batches between the one-item-per-wave and the one-item-per-lane kernels
 __global__ __launch_bounds__(64) CAPY_ONE_WAVE_PER_SIMD void vb_quad_kernel(uint64_t n, const uint8_t *scalars_be, uint64_t scalar_stride,
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(64, CAPY_ED448_WAVES) void vb_ct_kernel(uint64_t n,
 {
     vb_ct_body(n, scalars_be, scalar_stride, points_xy, point_stride, out_xy, table_ws);
 }
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void vb_ct_kernel_1w(
+__global__ __launch_bounds__(64) CAPY_WAVES_PER_SIMD(1) void vb_ct_kernel_1w(
     uint64_t n, const uint8_t *scalars_be, uint64_t scalar_stride, const uint8_t *points_xy, uint64_t point_stride, uint8_t *out_xy,
     uint32_t *table_ws)
 {
@@ -347,7 +348,7 @@ __global__ __launch_bounds__(64, CAPY_ED448_WAVES) void dsm_kernel(uint64_t n, c
     CAPY_DSM_PF
     dsm_body(n, a_be, b_be, points_xy, out_xy, table_ws, gtab, pf);
 }
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void dsm_kernel_1w(
+__global__ __launch_bounds__(64) CAPY_WAVES_PER_SIMD(1) void dsm_kernel_1w(
     uint64_t n, const uint8_t *a_be, const uint8_t *b_be, const uint8_t *points_xy, uint8_t *out_xy, uint32_t *table_ws,
     const uint32_t *gtab)
 {

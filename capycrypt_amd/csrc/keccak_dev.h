@@ -13,9 +13,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-
-// at most MAXW waves of the kernel per SIMD: the register allocation in the kernel descriptor is rounded up accordingly
-#define CAPY_WAVES_PER_SIMD(MAXW) __attribute__((amdgpu_waves_per_eu(1, (MAXW))))
+#include "occupancy.h"
 
 namespace capy {
 
