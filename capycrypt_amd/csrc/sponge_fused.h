@@ -43,7 +43,15 @@ struct FusedParams {
     uint32_t staged;        // A/B (debug bit 6): the round-1 form of this kernel, blocks staged through LDS
     uint32_t paired;        // launcher's choice: more than one wave per SIMD -> the blocked round with priority
     uint64_t n;
+    // time-sliced launches (r04; uniform batches between one and ~1.45 waves per SIMD, see the launcher): wave w of launch
+    // `sl_launch` works on wave-group (sl_launch * gridDim.x + w) mod sl_groups for at most sl_blocks full message blocks,
+    // resuming from / saving to sl_state ([group][25][64] half-words) with its progress in sl_done[group]
+    // (SLICE_FRESH: not started, SLICE_FINISHED: tag written).  sl_groups == 0: the whole job in one launch.
+    uint32_t sl_groups, sl_launch, sl_blocks, sl_grid;  // sl_grid: waves per launch
+    uint32_t *sl_done;
+    uint32_t *sl_state;
 };
+constexpr uint32_t SLICE_FRESH = 0xffffffffu, SLICE_FINISHED = 0xfffffffeu;
 
 // partner sponge's word: lanes (4q + 2, 4q + 3) <-> (4q, 4q + 1)
 __device__ __forceinline__ uint32_t quad_swap_pairs(uint32_t v)
@@ -72,7 +80,16 @@ __global__ __launch_bounds__(64) CAPY_WAVES_PER_SIMD(PAIRED ? 8 : 1) void sponge
     const uint32_t lane = threadIdx.x;
     const uint32_t h = lane & 1, role = (lane >> 1) & 1, q = lane >> 2;  // role 0 = tag sponge, 1 = keystream sponge
     const uint32_t hmask = 0u - h;
-    const uint64_t slot = (uint64_t)blockIdx.x * NIT + q;
+    const uint32_t grp = fp.sl_groups ? (uint32_t)(((uint64_t)fp.sl_launch * gridDim.x + blockIdx.x) % fp.sl_groups) : blockIdx.x;
+    const uint64_t slot = (uint64_t)grp * NIT + q;
+    uint32_t sl_t0 = 0;  // first full block of this launch (wave-uniform)
+    bool sl_resume = false;
+    if (fp.sl_groups) {
+        const uint32_t done = fp.sl_done[grp];
+        if (done == SLICE_FINISHED) return;  // an extra turn of a group that has its tag already
+        sl_resume = done != SLICE_FRESH;
+        sl_t0 = sl_resume ? done : 0;
+    }
     const bool active = slot < fp.n;
     const uint64_t item = active ? (fp.order ? (uint64_t)fp.order[slot] : slot) : fp.n;
 
@@ -139,16 +156,24 @@ __global__ __launch_bounds__(64) CAPY_WAVES_PER_SIMD(PAIRED ? 8 : 1) void sponge
     };
 
     // ---- heads (both roles), then the keystream sponge's only other block (00 01 04 || pad)
-    for (uint32_t b = 0; b < hb; b++)
-        if (active) absorb_slow((uint64_t)b * RB);
-    if (active && role == 1) absorb_slow((uint64_t)hb * RB);
+    if (sl_resume) {
+        const uint32_t *st = fp.sl_state + (size_t)grp * 25 * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < 25; i++) a.a[i] = st[i * 64];
+    } else {
+        for (uint32_t b = 0; b < hb; b++)
+            if (active) absorb_slow((uint64_t)b * RB);
+        if (active && role == 1) absorb_slow((uint64_t)hb * RB);
+    }
     // from here on the keystream sponge's state IS keystream block 0
 
     // ---- full blocks, one pass
     uint32_t *stage32 = reinterpret_cast<uint32_t *>(s_stage);
     if constexpr (!STAGED) {
-        const uint32_t max_full = wave_max_u32(nfull);
-        if (max_full) {
+        const uint32_t all_full = wave_max_u32(nfull);
+        // a time slice ends after sl_blocks blocks (uniform lengths: every lane of the batch has the same nfull)
+        const uint32_t max_full = (fp.sl_groups && all_full - sl_t0 > fp.sl_blocks) ? sl_t0 + fp.sl_blocks : all_full;
+        if (max_full > sl_t0) {
             const uint8_t *last_word = batch_last_word(fp.msgs, fp.offsets, fp.n, fp.msg_stride, fp.uniform_len);
             uint8_t *mine = (active ? const_cast<uint8_t *>(c.msg) : fp.msgs) + 4 * h;
             uint32_t pf[RW];
@@ -160,8 +185,8 @@ __global__ __launch_bounds__(64) CAPY_WAVES_PER_SIMD(PAIRED ? 8 : 1) void sponge
                     pf[w] = *reinterpret_cast<const __attribute__((address_space(1))) uint32_t *>(
                         reinterpret_cast<uintptr_t>(live ? src + 8 * w : src));
             };
-            own_load(0);
-            for (uint32_t t = 0; t < max_full; t++) {
+            own_load(sl_t0);
+            for (uint32_t t = sl_t0; t < max_full; t++) {
                 const bool live = t < nfull;
                 uint32_t wv[RW];
                 if (fp.decrypt) {  // wave-uniform; the DPP move runs in every lane
@@ -192,6 +217,13 @@ __global__ __launch_bounds__(64) CAPY_WAVES_PER_SIMD(PAIRED ? 8 : 1) void sponge
                         keccakf1600_k2_unrolled(a, hmask);
                 }
             }
+        }
+        if (fp.sl_groups && max_full < all_full) {  // wave-uniform: more full blocks remain for a later launch
+            uint32_t *st = fp.sl_state + (size_t)grp * 25 * 64 + lane;
+#pragma unroll
+            for (int i = 0; i < 25; i++) st[i * 64] = a.a[i];
+            if (lane == 0) fp.sl_done[grp] = max_full;
+            return;
         }
     } else {
     if (lane < NIT) {
@@ -331,6 +363,7 @@ __global__ __launch_bounds__(64) CAPY_WAVES_PER_SIMD(PAIRED ? 8 : 1) void sponge
         }
     }
 
+    if (fp.sl_groups && lane == 0) fp.sl_done[grp] = SLICE_FINISHED;
     // ---- tag
     if (role == 0 && active) {
         uint8_t *o = fp.tags + item * fp.tag_stride;

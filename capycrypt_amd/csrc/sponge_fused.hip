@@ -17,7 +17,7 @@ hipError_t launch_sponge_fused(int rw, const FusedParams &fp, hipStream_t s)
         }
         return hipGetLastError();
     }
-    const dim3 grid((unsigned)((fp.n + 15) / 16)), block(64);
+    const dim3 grid(fp.sl_groups ? fp.sl_grid : (unsigned)((fp.n + 15) / 16)), block(64);
     if (fp.staged) {
         switch (rw) {
         case 17: hipLaunchKernelGGL((sponge_fused_crypt_kernel<17, true>), grid, block, 0, s, fp); break;

@@ -510,3 +510,64 @@ def test_batches_between_the_wave_quanta_are_split_and_stay_byte_identical(capy,
                 assert hd[112 * i:112 * i + 112] == O.ed448_add(O.ed448_basemul(a), want), (n, i)
     finally:
         capy.ops.ed448_set_hardened(capy.ops.HARDEN_PROTOCOL)
+
+
+def test_time_sliced_fused_encrypt_matches_the_two_pass_form(capy, O):
+    """csrc/sponge_launch.hip (r04): sha3_encrypt / sha3_decrypt of 16 384 < n <= 22 528 uniform long messages run the fused
+    four-lane kernel in TIME SLICES (one wave per SIMD per launch, the groups of 16 items taking turns, states carried in
+    scratch) instead of putting a second wave on some SIMDs.  Ciphertexts and tags must be those of the two-pass form
+    (capy_set_sponge_lanes(1 | 1 << 16): no fused kernel) byte for byte, items across the batch match the oracle, and decrypt
+    restores the plaintext -- with one forged tag failing alone and keeping its ciphertext.  Lengths with and without a tail,
+    a batch size that is not a multiple of 16, the smallest and the largest sliced batch."""
+    import torch
+
+    from capycrypt_amd import _lib
+
+    lib = _lib.lib()
+    rng = random.Random(0x51CE)
+    sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    try:
+        for d, n, ln in ((512, 16400, 136 * 600 + 77), (256, 20003, 168 * 520), (512, 22528, 136 * 1030 + 8)):
+            stride = (ln + 7) // 8 * 8 + 8
+            pl = 32
+            def rand(nbytes, seed):
+                t = torch.empty((nbytes + 7) // 8 * 8, dtype=torch.uint8, device="cuda")
+                _lib.check(lib.capy_fill_random_dev(t.data_ptr(), t.numel(), seed, sp))
+                return t
+            pws, zs, plain = rand(n * pl, 1 + n), rand(n * 512, 2 + n), rand(n * stride, 3 + n)
+            res = {}
+            for name, lanes in (("sliced", 0), ("two-pass", 1 | (1 << 16))):
+                _lib.check(lib.capy_set_sponge_lanes(lanes))
+                m = plain.clone()
+                tags = torch.zeros(n * 64, dtype=torch.uint8, device="cuda")
+                _lib.check(lib.capy_sha3_encrypt_batch_dev(d, n, pws.data_ptr(), pl, None, n * pl, zs.data_ptr(), m.data_ptr(), None, ln, stride,
+                                                          tags.data_ptr(), sp))
+                torch.cuda.synchronize()
+                res[name] = (m, tags)
+            _lib.check(lib.capy_set_sponge_lanes(0))
+            assert torch.equal(res["sliced"][0], res["two-pass"][0]), (d, n, ln)
+            assert torch.equal(res["sliced"][1], res["two-pass"][1]), (d, n, ln)
+            m, tags = res["sliced"]
+            for i in (0, 15, 16, 16383, 16384, n - 1, rng.randrange(n)):
+                want = O.sha3_encrypt(bytes(pws[i * pl:(i + 1) * pl].cpu().numpy()), bytes(zs[i * 512:(i + 1) * 512].cpu().numpy()),
+                                      bytes(plain[i * stride:i * stride + ln].cpu().numpy()), d)
+                got = (bytes(m[i * stride:i * stride + ln].cpu().numpy()), bytes(tags[64 * i:64 * i + 64].cpu().numpy()))
+                assert got == want, (d, n, ln, i)
+            # bytes between the messages are not touched
+            gap = torch.arange(n, device="cuda").unsqueeze(1) * stride + torch.arange(ln, stride, device="cuda").unsqueeze(0)
+            assert torch.equal(m[gap.flatten()], plain[gap.flatten()]), (d, n, ln)
+            # and back: item 7's tag forged
+            status = torch.full((n,), 9, dtype=torch.int32, device="cuda")
+            tags[64 * 7] ^= 1
+            ct7 = m[7 * stride:7 * stride + ln].clone()
+            _lib.check(lib.capy_sha3_decrypt_batch_dev(d, n, pws.data_ptr(), pl, None, n * pl, zs.data_ptr(), m.data_ptr(), None, ln, stride,
+                                                      tags.data_ptr(), status.data_ptr(), sp))
+            torch.cuda.synchronize()
+            assert int(status[7]) == 1 and int((status != 0).sum()) == 1
+            assert torch.equal(m[7 * stride:7 * stride + ln], ct7)
+            keep = torch.ones(n, dtype=torch.bool, device="cuda")
+            keep[7] = False
+            idx = (torch.arange(n, device="cuda")[keep].unsqueeze(1) * stride + torch.arange(ln, device="cuda").unsqueeze(0)).flatten()
+            assert torch.equal(m[idx], plain[idx]), (d, n, ln)
+    finally:
+        _lib.check(lib.capy_set_sponge_lanes(0))
