@@ -67,8 +67,11 @@ __device__ __forceinline__ uint32_t quad_swap_pairs(uint32_t v)
 // STAGED = true: the round-1 form (wave-cooperative 8-byte transfers through LDS, four barriers per block), kept for A/B.
 // PAIRED (r03): the launch puts two or three waves on a SIMD (16 384 < n <= 49 152): the hot loop runs the blocked round
 // with raised priority around its DPP / rotation blocks (sponge_kernels_k2.h: keccak_round_k2_blocked).
-template <int RW, bool STAGED = false, bool PAIRED = false>
-__global__ __launch_bounds__(64) CAPY_WAVES_PER_SIMD(PAIRED ? 8 : 1) void sponge_fused_crypt_kernel(const FusedParams fp)
+// PAIRED: 0 = one wave per SIMD (and compiled for exactly one); 1 = two or more (the blocked round with priority), as many as
+// fit; 2 / 3 = the same round, compiled for at most two / three waves per SIMD: the time-sliced launches that hold exactly that
+// many (see the launcher)
+template <int RW, bool STAGED = false, int PAIRED = 0>
+__global__ __launch_bounds__(64) CAPY_WAVES_PER_SIMD(PAIRED == 0 ? 1 : (PAIRED == 1 ? 8 : PAIRED)) void sponge_fused_crypt_kernel(const FusedParams fp)
 {
     constexpr uint32_t RB = RW * 8;
     constexpr int NIT = 16;                       // items per wave

@@ -27,15 +27,20 @@ hipError_t launch_sponge_fused(int rw, const FusedParams &fp, hipStream_t s)
         }
         return hipGetLastError();
     }
-    if (fp.paired) {  // more than one wave per SIMD
-        switch (rw) {
-        case 17: hipLaunchKernelGGL((sponge_fused_crypt_kernel<17, false, true>), grid, block, 0, s, fp); break;
-        case 19: hipLaunchKernelGGL((sponge_fused_crypt_kernel<19, false, true>), grid, block, 0, s, fp); break;
-        case 21: hipLaunchKernelGGL((sponge_fused_crypt_kernel<21, false, true>), grid, block, 0, s, fp); break;
-        default: return hipErrorInvalidValue;
-        }
-        return hipGetLastError();
+#define CAPY_FUSED_PAIRED(P)                                                                                             \
+    if (fp.paired == P) {                                                                                                \
+        switch (rw) {                                                                                                    \
+        case 17: hipLaunchKernelGGL((sponge_fused_crypt_kernel<17, false, P>), grid, block, 0, s, fp); break;            \
+        case 19: hipLaunchKernelGGL((sponge_fused_crypt_kernel<19, false, P>), grid, block, 0, s, fp); break;            \
+        case 21: hipLaunchKernelGGL((sponge_fused_crypt_kernel<21, false, P>), grid, block, 0, s, fp); break;            \
+        default: return hipErrorInvalidValue;                                                                            \
+        }                                                                                                                \
+        return hipGetLastError();                                                                                        \
     }
+    CAPY_FUSED_PAIRED(1)  // more than one wave per SIMD
+    CAPY_FUSED_PAIRED(2)  // time-sliced launches of exactly two / three waves per SIMD
+    CAPY_FUSED_PAIRED(3)
+#undef CAPY_FUSED_PAIRED
     switch (rw) {
     case 17: hipLaunchKernelGGL(sponge_fused_crypt_kernel<17>, grid, block, 0, s, fp); break;
     case 19: hipLaunchKernelGGL(sponge_fused_crypt_kernel<19>, grid, block, 0, s, fp); break;

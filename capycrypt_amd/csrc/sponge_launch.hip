@@ -921,7 +921,8 @@ int symmetric_crypt_dev(bool encrypt, int d, size_t n, const uint8_t *keka, size
             fp.wide = ((dbg & 32) && n <= 4096) || (!(dbg & 16) && n <= wide_max_items()) ? 1 : 0;
         }
         fp.tags = encrypt ? tags : tag2;
-        // Between one and ~1.4 waves per SIMD (16 384 < n <= 22 528 uniform long messages): TIME SLICES instead of a second wave.
+        // Just above a whole number of waves per SIMD (16 384 < n <= 22 528, 32 768 < n <= 43 008, 49 152 < n <= 61 440 uniform long
+        // messages): TIME SLICES instead of a further wave on some SIMDs.
         // One launch of the whole batch puts a second wave on (n - 16 384) / 16 SIMDs, those run the paired round at 1 / 1.52 of
         // a lone wave's rate and the launch takes the two-waves time (0.30 s for 5 MiB messages) however few they are.  Here
         // every launch holds exactly one wave per SIMD: launch k works on the wave-groups (k C + w) mod G for `bp` full blocks,
@@ -933,17 +934,22 @@ int symmetric_crypt_dev(bool encrypt, int d, size_t n, const uint8_t *keka, size
             const uint64_t nfull = m.offsets ? 0 : m.uniform_len / ((uint64_t)ff.rw * 8);
             const size_t groups = (n + 15) / 16;
             static const bool slices_on = debug_knob("fused_slices", 1) != 0;
-            if (slices_on && !fp.staged && !fp.wide && !m.offsets && !m.order && groups > simds && groups * 16 <= simds * 22 &&
-                nfull >= 512 && nfull < 0xfffffff0u) {
+            // level k = waves per SIMD and launch: k = 1 for 16 384 < n <= 22 528, k = 2 for 32 768 < n <= 43 008, k = 3 for
+            // 49 152 < n <= 61 440 (beyond the limit of a level the single launch with k + 1 waves on some SIMDs is as fast)
+            uint32_t level = 0;
+            static const size_t level_limit[4] = {0, 22, 42, 60};  // items per SIMD up to which level k pays
+            for (uint32_t k = 1; k <= 3; k++)
+                if (groups > k * simds && groups * 16 <= simds * level_limit[k]) level = k;
+            if (slices_on && !fp.staged && !fp.wide && !m.offsets && !m.order && level && nfull >= 512 && nfull < 0xfffffff0u) {
                 const uint32_t turns = (uint32_t)std::min<uint64_t>(64, nfull / 64);  // >= 8 turns per group
                 const uint32_t bp = (uint32_t)((nfull + turns - 1) / turns);
                 const uint32_t need0 = (uint32_t)((nfull + bp - 1) / bp);
                 const size_t done_bytes = (groups * 4 + 255) & ~(size_t)255, state_bytes = groups * 25 * 64 * 4;
                 CAPY_WS(slws, uint8_t *, s, WS_STATE, done_bytes + state_bytes);
                 CAPY_HIP(hipMemsetAsync(slws, 0xff, done_bytes, s));  // SLICE_FRESH
-                fp.paired = 0;
+                fp.paired = level == 1 ? 0 : level;  // the instance compiled for exactly `level` waves per SIMD
                 fp.sl_groups = (uint32_t)groups;
-                fp.sl_grid = (uint32_t)simds;
+                fp.sl_grid = (uint32_t)(level * simds);
                 fp.sl_blocks = bp;
                 fp.sl_done = reinterpret_cast<uint32_t *>(slws);
                 fp.sl_state = reinterpret_cast<uint32_t *>(slws + done_bytes);
@@ -952,8 +958,8 @@ int symmetric_crypt_dev(bool encrypt, int d, size_t n, const uint8_t *keka, size
                 for (uint32_t k = 0; open_groups; k++) {
                     fp.sl_launch = k;
                     CAPY_HIP(launch_sponge_fused(ff.rw, fp, s));
-                    for (size_t w = 0; w < simds; w++) {
-                        uint32_t &left = need[((size_t)k * simds + w) % groups];
+                    for (size_t w = 0; w < fp.sl_grid; w++) {
+                        uint32_t &left = need[((size_t)k * fp.sl_grid + w) % groups];
                         if (left && --left == 0) open_groups--;
                     }
                 }

@@ -527,7 +527,9 @@ def test_time_sliced_fused_encrypt_matches_the_two_pass_form(capy, O):
     rng = random.Random(0x51CE)
     sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     try:
-        for d, n, ln in ((512, 16400, 136 * 600 + 77), (256, 20003, 168 * 520), (512, 22528, 136 * 1030 + 8)):
+        # one, two and three waves per SIMD and launch (16 384 < n <= 22 528, 32 768 < n <= 43 008, 49 152 < n <= 61 440)
+        for d, n, ln in ((512, 16400, 136 * 600 + 77), (256, 20003, 168 * 520), (512, 22528, 136 * 1030 + 8), (512, 33000, 136 * 520 + 16),
+                         (384, 50001, 152 * 515)):
             stride = (ln + 7) // 8 * 8 + 8
             pl = 32
             def rand(nbytes, seed):

@@ -90,8 +90,8 @@ for nmsg in (128, 512, 2048, 16384, 32768):
     perms = MIB5 // 136 + 3
     two_lane_bound = perms * 24 * 120 * 4.04 / 2.38e9
     wide_floor = perms * 24 * (3 * 64 + 22 * 4) / 2.38e9
-    kernel = ("sponge_wide_crypt_kernel<17>" if nmsg <= 512 else "sponge_fused_crypt_kernel<17, false, false>" if nmsg <= 16384
-              else "sponge_fused_crypt_kernel<17, false, true> (two waves per SIMD, blocked round with priority)")
+    kernel = ("sponge_wide_crypt_kernel<17>" if nmsg <= 512 else "sponge_fused_crypt_kernel<17, false, 0>" if nmsg <= 16384
+              else "sponge_fused_crypt_kernel<17, false, 1> (two waves per SIMD, blocked round with priority)")
     # two waves per SIMD on the blocked two-lane round: 2.74 cycles per instruction (profiles/r03_valu_issue_bisect.txt, mix21)
     paired_bound = perms * 24 * 120 * 2 * 2.74 / 2.38e9
     bound = wide_floor if nmsg <= 512 else two_lane_bound if nmsg <= 16384 else paired_bound

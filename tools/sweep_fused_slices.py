@@ -18,7 +18,7 @@ sp = C.c_void_p(st.cuda_stream)
 ln = int(os.environ.get("LEN", str(5 << 20)))
 stride = ln + 128
 print("# %s, %d-byte messages: n | encrypt s | decrypt s | GiB/s (encrypt) | round trip" % (os.environ.get("CAPY_DEBUG", "default"), ln))
-for n in (15360, 16384, 16400, 17408, 18432, 20480, 22528, 23552, 24576, 28672, 32768):
+for n in [int(x) for x in os.environ.get("NS", "15360,16384,16400,17408,18432,20480,22528,23552,24576,28672,32768,33024,36864,40960,43008,45056,49152,49408,53248,57344,61440,65536").split(",")]:
     if n * stride > 200 * (1 << 30):
         continue
     msgs = torch.empty(n * stride, dtype=torch.uint8, device=dev)
