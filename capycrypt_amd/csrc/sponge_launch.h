@@ -27,5 +27,5 @@ hipError_t launch_sponge_fused(int rw, const FusedParams &fp, hipStream_t s);
 hipError_t launch_sponge_wide_digest(int rw, const SpongeParams &p, hipStream_t s);
 // chip-full digest / XOF launches with wave-uniform framing (sponge_uniform.h); rw in {9, 13, 17, 18, 19, 21};
 // waves = 1..3: occupancy cap in waves per SIMD (A/B), else none
-hipError_t launch_sponge_uniform(int rw, const SpongeParams &p, int waves, hipStream_t s);
+hipError_t launch_sponge_uniform(int rw, const SpongeParams &p, int waves, hipStream_t s, unsigned sliced_grid = 0);
 }  // namespace capy

@@ -425,6 +425,60 @@ static bool wide_digest_ok(int rw, const SpongeParams &p, int forced, unsigned d
                         (forced == 0 && !(dbg & 16) && p.n <= 2 * wide_max_items()));
 }
 
+// Uniform digest batches JUST ABOVE a whole number k of waves per SIMD (k = 2, 3, 4): one launch puts a further wave on a few
+// SIMDs and takes a whole further chain -- SHA3-256 over 256 KiB messages: 1339 GB/s at 131 072 items, 1035 at 133 120; 1399 at
+// 196 608, 1160 at 200 704; 1476 at 262 144, 1223 at 266 240 (profiles/r04_uniform_slices.txt).  Instead: a sequence of launches of
+// the uniform-framing kernel's SLICED instance that each hold exactly k waves per SIMD; launch j works on the groups of 64
+// items (j k S + w) mod G for nfull / 64 full blocks (at least 8 turns per group), states through WS_STATE, heads in a group's
+// first turn, trailer and squeeze in its last.  Returns 1 if it handled the launch, 0 if not eligible, < 0 on error.
+// CAPY_DEBUG=uniform_slices=0 switches it off.
+static int try_launch_uniform_sliced(int rw, const SpongeParams &p, int forced, unsigned dbg, size_t simds, hipStream_t s)
+{
+    static const bool on = debug_knob("uniform_slices", 1) != 0;
+    if (!on || !p.absorb_body || !uniform_kernel_ok(rw, p, forced, dbg, simds)) return 0;
+    const uint64_t nfull = p.uniform_len / ((uint64_t)rw * 8);
+    if (nfull < 512 || nfull >= 0xfffffff0u) return 0;
+    const size_t groups = (p.n + 63) / 64;
+    // Level k = waves per SIMD and launch.  Measured (256 KiB messages): the sliced launches run at a flat 1362 / 1458 / 1474 GB/s
+    // at k = 2 / 3 / 4 -- as fast as the single launch at the NEXT whole number of waves per SIMD (1373 / 1445 / 1451), so a level
+    // serves almost up to the next quantum; beyond four waves per SIMD (the occupancy of the kernel) level 4 serves every batch
+    // that is not within a fifth of a quantum below a whole number of them (where the single launch is at its best: 1536-1560).
+    uint32_t level = 0;
+    if (groups > 2 * simds && groups * 100 <= 2 * simds * 148) level = 2;
+    else if (groups >= 3 * simds && groups * 100 <= 3 * simds * 133) level = 3;  // (the whole numbers themselves included:
+    else if (groups >= 4 * simds) {                                               //  1369 -> 1458, 1440 -> 1490 GB/s)
+        const size_t q = (groups + simds - 1) / simds;
+        if (groups * 5 <= (5 * q - 1) * simds) level = 4;
+    }
+    if (!level) return 0;
+    const uint32_t turns = (uint32_t)std::min<uint64_t>(64, nfull / 64);
+    const uint32_t bp = (uint32_t)((nfull + turns - 1) / turns);
+    const uint32_t need0 = (uint32_t)((nfull + bp - 1) / bp);
+    const size_t done_bytes = (groups * 4 + 255) & ~(size_t)255, state_bytes = groups * 50 * 64 * 4;
+    CAPY_WS(ws, uint8_t *, s, WS_STATE, done_bytes + state_bytes);
+    CAPY_HIP(hipMemsetAsync(ws, 0xff, done_bytes, s));
+    SpongeParams q = p;
+    q.sl_groups = (uint32_t)groups;
+    q.sl_blocks = bp;
+    q.sl_done = reinterpret_cast<uint32_t *>(ws);
+    q.sl_state = reinterpret_cast<uint32_t *>(ws + done_bytes);
+    const unsigned grid = (unsigned)(level * simds);
+    std::vector<uint32_t> need(groups, need0);
+    size_t open_groups = groups;
+    for (uint32_t j = 0; open_groups; j++) {
+        q.sl_launch = j;
+        hipError_t e = launch_sponge_uniform(rw, q, level <= 3 ? (int)level : 0, s, grid);
+        if (e == hipErrorInvalidValue) return fail(CAPY_ERR_ARG, "internal: no kernel instance for this rate");
+        CAPY_HIP(e);
+        for (size_t w = 0; w < grid; w++) {
+            uint32_t &left = need[((size_t)j * grid + w) % groups];
+            if (left && --left == 0) open_groups--;
+        }
+    }
+    if (p.head_len) workspace_scrub(s, WS_STATE, done_bytes + state_bytes);  // keyed sponge states
+    return 1;
+}
+
 static int sponge_plan(int rw, const SpongeParams &p, int *phases)
 {
     const int forced = g_lanes_per_sponge.load();
@@ -522,6 +576,12 @@ static int launch_sponge(int rw, const SpongeParams &p, hipStream_t s)
             CAPY_HIP(e);
             return launch_sponge(rw, tail, s);
         }
+    }
+    // Just above k waves per SIMD (k = 2, 3, 4): time slices of exactly k waves per SIMD instead of a further wave on a few
+    {
+        const int m = try_launch_uniform_sliced(rw, p2, forced, q.debug_flags, simds, s);
+        if (m < 0) return m;
+        if (m > 0) return CAPY_OK;
     }
     // Chip-full launches with wave-uniform framing (equal key, message and output lengths, 8-byte aligned): every framing
     // decision is scalar code in sponge_uniform.h.  Debug bit 7: never (A/B and tests).

@@ -63,6 +63,13 @@ struct SpongeParams {
     // to head_state[25][resume_pad] and stop (the body then goes through sponge_mixed_kernel)
     uint64_t *head_state;
     uint64_t n;
+    // time-sliced launches of the uniform-framing kernel (sponge_uniform.h, r04): wave w of launch sl_launch works on the group
+    // of 64 items (sl_launch * gridDim.x + w) mod sl_groups for at most sl_blocks full body blocks, resuming from / saving to
+    // sl_state ([group][50][64] half-words) with its progress in sl_done[group] (0xffffffff: not started, 0xfffffffe:
+    // finished).  sl_groups == 0: the whole job in one launch.
+    uint32_t sl_groups, sl_launch, sl_blocks;
+    uint32_t *sl_done;
+    uint32_t *sl_state;
 };
 
 struct ItemCtx {

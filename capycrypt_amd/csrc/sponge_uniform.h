@@ -44,14 +44,26 @@ __device__ __forceinline__ uint64_t uniform_tail_word(const uint8_t *msg, uint64
 }
 
 // 98..106 VGPRs, no scratch: four waves per SIMD fit; the launcher can cap the occupancy with dynamic LDS (A/B)
-template <int RW>
+// SLICED (r04): the instance of the time-sliced launches (SpongeParams::sl_*; the launcher caps the occupancy at the level's
+// waves per SIMD): a launch absorbs at most sl_blocks full body blocks per group of 64 items, heads in the group's first turn,
+// trailer and squeeze in its last, the state in sl_state in between.  The plain instance compiles none of it.
+template <int RW, bool SLICED = false>
 __global__ __launch_bounds__(64, 4) void sponge_uniform_kernel(const SpongeParams p)
 {
     constexpr uint32_t RB = RW * 8;
     __shared__ uint64_t s_rows[64 * RW];  // [item][word]: row stride RW words (bank-conflict-free for per-lane b64 access)
 
     const uint32_t lane = threadIdx.x;
-    const uint64_t item0 = (uint64_t)blockIdx.x * 64;
+    uint32_t grp = blockIdx.x, sl_t0 = 0;
+    bool sl_resume = false;
+    if constexpr (SLICED) {
+        grp = (uint32_t)(((uint64_t)p.sl_launch * gridDim.x + blockIdx.x) % p.sl_groups);
+        const uint32_t done = p.sl_done[grp];
+        if (done == 0xfffffffeu) return;  // an extra turn of a finished group
+        sl_resume = done != 0xffffffffu;
+        sl_t0 = sl_resume ? done : 0;
+    }
+    const uint64_t item0 = (uint64_t)grp * 64;
     const bool active = item0 + lane < p.n;
     const uint64_t item = active ? item0 + lane : p.n - 1;  // lanes past the batch redo the last item and store nothing
 
@@ -78,7 +90,14 @@ __global__ __launch_bounds__(64, 4) void sponge_uniform_kernel(const SpongeParam
     // ---- head blocks: stream byte s = hdr_len + k holds key byte k.  With K[x] the x-th aligned 8-byte word of the key
     // (zero outside [0, key_len), key_len a multiple of 8), stream word j = K[j + i0] >> 8 sh | K[j + i0 + 1] << (64 - 8 sh)
     // for the launch-wide i0 = floor(-hdr_len / 8), sh = -hdr_len mod 8; the hdr bytes are ORed into words 0 and 1.
-    if (hb) {
+    if (SLICED && sl_resume) {
+        const uint32_t *st = p.sl_state + (size_t)grp * 50 * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < 25; i++) {
+            a.lo[i] = st[(2 * i) * 64];
+            a.hi[i] = st[(2 * i + 1) * 64];
+        }
+    } else if (hb) {
         const uint8_t *key = p.keys + item * p.key_stride;
         const int32_t i0 = -(int32_t)((p.hdr_len + 7) / 8);
         const uint32_t sh = (8 - (p.hdr_len & 7)) & 7;
@@ -105,11 +124,29 @@ __global__ __launch_bounds__(64, 4) void sponge_uniform_kernel(const SpongeParam
     // ---- body: full blocks straight from the message (per-lane 8-byte loads: the lines a wave touches are shared by its
     // next blocks and stay in the vector cache / L2), then the trailer blocks
     const uint8_t *msg = p.msgs + (p.absorb_body ? item * p.msg_stride : 0);
-    for (uint32_t t = 0; t < nfull; t++) {
+    uint32_t t_end = nfull;
+    if constexpr (SLICED) {
+        msg += (uint64_t)sl_t0 * RB;
+        if (nfull - sl_t0 > p.sl_blocks) t_end = sl_t0 + p.sl_blocks;
+    }
+    for (uint32_t t = sl_t0; t < t_end; t++) {
 #pragma unroll
         for (int w = 0; w < RW; w++) xor_word(a, w, load_global_u64(msg + 8 * w));
         msg += RB;
         keccakf1600_paired<CAPY_PAIRED_PRIO>(a);
+    }
+    if constexpr (SLICED) {
+        if (t_end < nfull) {  // scalar: more full blocks remain for a later launch
+            uint32_t *st = p.sl_state + (size_t)grp * 50 * 64 + lane;
+#pragma unroll
+            for (int i = 0; i < 25; i++) {
+                st[(2 * i) * 64] = a.lo[i];
+                st[(2 * i + 1) * 64] = a.hi[i];
+            }
+            if (lane == 0) p.sl_done[grp] = t_end;
+            return;
+        }
+        if (lane == 0) p.sl_done[grp] = 0xfffffffeu;
     }
     for (uint32_t b = nfull; b < nb; b++) {
         const uint64_t base = (uint64_t)(b - nfull) * RB, left = len - (uint64_t)nfull * RB;

@@ -573,3 +573,53 @@ def test_time_sliced_fused_encrypt_matches_the_two_pass_form(capy, O):
             assert torch.equal(m[idx], plain[idx]), (d, n, ln)
     finally:
         _lib.check(lib.capy_set_sponge_lanes(0))
+
+
+def test_time_sliced_uniform_digests_match_the_one_lane_kernel(capy, O):
+    """csrc/sponge_launch.hip: try_launch_uniform_sliced (r04).  Uniform digest batches just above two, three and four waves per
+    SIMD (131 072 / 196 608 / 262 144 items on this chip) run as a sequence of launches of exactly that many waves per SIMD,
+    groups of 64 items taking turns.  SHA3-256, SHA3-512 and keyed KMACXOF (per-item head blocks, a long output) must give the
+    bytes of the forced one-lane kernel (capy_set_sponge_lanes(1)), and items across the batch -- first and last group, both
+    sides of a launch boundary -- those of the oracle.  Batch sizes that are not multiples of 64, lengths with and without a
+    tail."""
+    import torch
+
+    from capycrypt_amd import _lib
+
+    lib = _lib.lib()
+    rng = random.Random(0x51CF)
+    sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def rand(nbytes, seed):
+        t = torch.empty((nbytes + 7) // 8 * 8, dtype=torch.uint8, device="cuda")
+        _lib.check(lib.capy_fill_random_dev(t.data_ptr(), t.numel(), seed, sp))
+        return t
+
+    try:
+        for d, n, ln, keyed in ((256, 133121, 136 * 520 + 40, False), (512, 200704, 72 * 600, False), (512, 266245, 136 * 515 + 8, True)):
+            stride = (ln + 7) // 8 * 8 + 8
+            msgs = rand(n * stride, 11 + n)
+            keys = rand(n * 64, 12 + n)
+            ol = 200 if keyed else d // 8
+            os_ = (ol + 15) // 16 * 16
+            outs = {}
+            for name, lanes in (("sliced", 0), ("one-lane", 1)):
+                _lib.check(lib.capy_set_sponge_lanes(lanes))
+                o = torch.zeros(n * os_ + 16, dtype=torch.uint8, device="cuda")
+                if keyed:
+                    _lib.check(lib.capy_kmac_xof_batch_dev(d, n, keys.data_ptr(), 64, 64, None, msgs.data_ptr(), None, ln, stride, 8 * ol, b"T", 1,
+                                                          o.data_ptr(), os_, sp))
+                else:
+                    _lib.check(lib.capy_sha3_batch_dev(d, n, msgs.data_ptr(), None, ln, stride, o.data_ptr(), sp))
+                torch.cuda.synchronize()
+                outs[name] = o
+            _lib.check(lib.capy_set_sponge_lanes(0))
+            assert torch.equal(outs["sliced"], outs["one-lane"]), (d, n, ln, keyed)
+            row = os_ if keyed else d // 8
+            for i in (0, 63, 64, 65535, 65536, 131071, 131072, n - 65, n - 1, rng.randrange(n)):
+                x = bytes(msgs[i * stride:i * stride + ln].cpu().numpy())
+                got = bytes(outs["sliced"][i * row:i * row + ol].cpu().numpy())
+                want = O.kmac_xof(bytes(keys[i * 64:(i + 1) * 64].cpu().numpy()), x, 8 * ol, b"T", d) if keyed else O.sha3(x, d)
+                assert got == want, (d, n, ln, keyed, i)
+    finally:
+        _lib.check(lib.capy_set_sponge_lanes(0))
