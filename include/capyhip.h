@@ -360,7 +360,8 @@ int capy_set_sponge_lanes(int lanes);
  * 2 sponge_kernel_k2<RW,0>, 3 sponge_mixed_kernel<RW> launched *phases times, 4 sponge_kernel<RW,true,0>,
  * 5 a full-chip head on sponge_kernel<RW,false,0> plus a remainder on kind 2 or 3 (*phases = launches in all),
  * 6 sponge_wide_digest_kernel<RW> (two items per wave: batches of up to two items per SIMD, any message length),
- * 7 sponge_uniform_kernel<RW> (more than 128 items per SIMD, wave-uniform framing: csrc/sponge_uniform.h),
+ * 7 sponge_uniform_kernel<RW> (more than 128 items per SIMD, wave-uniform framing: csrc/sponge_uniform.h; long messages just
+ *   above a whole number of waves per SIMD run as a sequence of time-sliced launches of it, still reported as 7),
  * 8 sponge_rot_kernel<RW> launched *phases times (between 64 and 128 items per SIMD, long messages: csrc/sponge_rot.h). */
 int capy_sha3_launch_plan(int d, size_t n, uint64_t uniform_len, uint64_t msg_stride, int *kind, int *phases);
 /* Fill a device buffer with the harness PRNG (SplitMix64 counter mode, seed + 8-byte word index). */
