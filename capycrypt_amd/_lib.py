@@ -46,6 +46,7 @@ SIGNATURES = {
     "capy_release_workspace": (C.c_int, []),
     "capy_debug_secret_scratch_nonzero": (C.c_int, [vp, vp]),
     "capy_debug_last_curve_kernel": (C.c_int, [vp, vp]),
+    "capy_debug_last_sponge_kernel": (C.c_int, [vp, vp]),
     "capy_sha3_batch": (C.c_int, [C.c_int, sz, vp, vp, vp]),
     "capy_sha3_batch_dev": (C.c_int, [C.c_int, sz, vp, vp, u64, u64, vp, vp]),
     "capy_cshake_batch": (C.c_int, [C.c_int, sz, vp, vp, sz, vp, sz, vp, sz, vp]),

@@ -50,6 +50,12 @@ struct FusedParams {
     uint32_t sl_groups, sl_launch, sl_blocks, sl_grid;  // sl_grid: waves per launch
     uint32_t *sl_done;
     uint32_t *sl_state;
+    // the one-lane-per-sponge form (sponge_fused1.h, r05: two lanes per item, chip-filling batches): launcher's choice of the
+    // instance (0: not this form; 1 lone wave per SIMD, 2 two waves, 4 three or four), A/B switch for per-lane stores
+    // instead of whole lines, occupancy cap in waves per SIMD (0: none), and the rotating-occupancy schedule's phase
+    // (sponge_fused1.h: fused1_rot_kernel; rot_G == 0: not that schedule)
+    uint32_t one_lane, direct_stores, cap_waves;
+    uint32_t rot_phase, rot_Cp, rot_G, rot_nb1, rot_nb2;
 };
 constexpr uint32_t SLICE_FRESH = 0xffffffffu, SLICE_FINISHED = 0xfffffffeu;
 

@@ -908,6 +908,52 @@ __global__ __launch_bounds__(64) void keccak_probe_kernel(uint64_t n_states, uin
         atomicXor((unsigned long long *)checksum, ((uint64_t)y << 32) | x);
 }
 
+// first batch size that takes the one-lane-per-sponge fused kernel: more than 32 items per SIMD
+static size_t fused1_min_items()
+{
+    static const long forced = (long)debug_knob("fused1_min", -1);
+    return forced >= 0 ? (size_t)forced : 32 * (size_t)device_simds() + 1;
+}
+
+// what the last symmetric_crypt_dev / launch_sponge call of this thread ran (capy_debug_last_sponge_kernel): kind =
+//   digest launches  1 one-lane latency-tuned, 2 two-lane, 3 rotating one-/two-lane schedule, 4 one-lane issue-tuned, 5 wave-quantisation
+//                    split, 6 wave-per-item, 7 uniform-framing kernel, 8 rotating-occupancy schedule, 9 uniform-framing kernel in time slices
+//   encrypt/decrypt  20 four lanes per item, 21 one wave per item, 22 four lanes per item in time slices, 23 one lane per sponge,
+//                    24 one lane per sponge in time slices, 25 one lane per sponge on the rotating-occupancy schedule, 26 two passes
+// launches = kernel launches of the data pass (phases / slices)
+static thread_local int t_last_kind = 0, t_last_launches = 0;
+static void note_kernel(int kind, int launches)
+{
+    t_last_kind = kind;
+    t_last_launches = launches;
+}
+
+// The one-lane-per-sponge fused pass (sponge_fused1.h) over a batch that fills the chip; fp is complete but for the schedule.
+static int fused1_launch(int rw, FusedParams &fp, const MsgView &m, hipStream_t s)
+{
+    const size_t simds = device_simds();
+    const size_t groups = (fp.n + 31) / 32;  // waves
+    static const bool direct = debug_knob("fused1_direct", 0) != 0;
+    fp.direct_stores = direct ? 1 : 0;
+    // up to two waves per SIMD: the unrolled blocked round with the next block prefetched; beyond: the rolled round at three
+    // or four waves per SIMD
+    static const int forced_form = (int)debug_knob("fused1_form", 0);
+    fp.one_lane = groups <= 2 * simds ? 2 : 4;
+    if (forced_form == 1 || forced_form == 2 || forced_form == 4) fp.one_lane = (uint32_t)forced_form;
+    fp.cap_waves = 0;
+    if (fp.one_lane == 4) {
+        const size_t w = (groups + simds - 1) / simds;
+        static const int forced_cap = (int)debug_knob("fused1_waves", 0);
+        fp.cap_waves = forced_cap ? (uint32_t)forced_cap : (w <= 3 ? (uint32_t)w : 0u);
+    }
+    fp.sl_groups = 0;
+    hipError_t e = launch_sponge_fused1(rw, fp, s);
+    if (e == hipErrorInvalidValue) return fail(CAPY_ERR_ARG, "internal: no one-lane fused kernel instance for this rate");
+    CAPY_HIP(e);
+    note_kernel(23, 1);
+    return CAPY_OK;
+}
+
 // The symmetric half shared by sha3_encrypt/decrypt (src/sha3/encryptable.rs:39-42, 71-82), key_encrypt/decrypt
 // (src/ecc/encryptable.rs:43-46, 82-93) and kem_encrypt/decrypt (src/kem/encryptable.rs:55-57, 96-103):
 //     tag = kmac_xof(ka, m, 8*tag_len, ka_custom) ;  m ^= kmac_xof(ke, "", |m|, ke_custom)
@@ -935,8 +981,12 @@ int symmetric_crypt_dev(bool encrypt, int d, size_t n, const uint8_t *keka, size
         if (!tag2) return fail(CAPY_ERR_HIP, "workspace allocation failed");
     }
     const Framing ff = cshake_framing(d);
-    const bool fused_ok = g_fused_enabled.load() && ff.stride == (uint32_t)ff.rw * 8 && n <= FUSED_MAX_ITEMS &&
-                          m.aligned8 && m.msgs != nullptr && tag_len <= 64 && (tag_len & 3) == 0;
+    const bool fused_shape = g_fused_enabled.load() && ff.stride == (uint32_t)ff.rw * 8 && m.aligned8 && m.msgs != nullptr &&
+                             tag_len <= 64 && (tag_len & 3) == 0;
+    // From 32 items per SIMD on there is one sponge for every lane of the chip: one lane per sponge (sponge_fused1.h), at every
+    // larger batch size; below, four lanes per item (sponge_fused.h).  CAPY_DEBUG=fused1_min=N moves the boundary (A/B, tests).
+    const bool one_lane = fused_shape && n >= fused1_min_items() && (key_len & 7) == 0 && (((uintptr_t)keka | keka_stride) & 7) == 0;
+    const bool fused_ok = fused_shape && (one_lane || n <= FUSED_MAX_ITEMS);
     if (fused_ok) {
         FusedParams fp;
         memset(&fp, 0, sizeof fp);
@@ -981,6 +1031,13 @@ int symmetric_crypt_dev(bool encrypt, int d, size_t n, const uint8_t *keka, size
             fp.wide = ((dbg & 32) && n <= 4096) || (!(dbg & 16) && n <= wide_max_items()) ? 1 : 0;
         }
         fp.tags = encrypt ? tags : tag2;
+        if (one_lane) {
+            const int rc1 = fused1_launch(ff.rw, fp, m, s);
+            if (rc1) return rc1;
+            if (encrypt) return CAPY_OK;
+            tag_compare_launch(tags, tag_len, tag2, tag_len, (uint32_t)tag_len, status, n, s);
+            return keystream(status);
+        }
         // Just above a whole number of waves per SIMD (16 384 < n <= 22 528, 32 768 < n <= 43 008, 49 152 < n <= 61 440 uniform long
         // messages): TIME SLICES instead of a further wave on some SIMDs.
         // One launch of the whole batch puts a second wave on (n - 16 384) / 16 SIMDs, those run the paired round at 1 / 1.52 of
@@ -1024,9 +1081,11 @@ int symmetric_crypt_dev(bool encrypt, int d, size_t n, const uint8_t *keka, size
                     }
                 }
                 workspace_scrub(s, WS_STATE, done_bytes + state_bytes);  // keyed sponge states
+                note_kernel(22, (int)fp.sl_launch + 1);
                 fp.sl_groups = 0;
             } else {
                 CAPY_HIP(launch_sponge_fused(ff.rw, fp, s));
+                note_kernel(fp.wide ? 21 : 20, 1);
             }
         }
         if (encrypt) return CAPY_OK;
@@ -1037,13 +1096,16 @@ int symmetric_crypt_dev(bool encrypt, int d, size_t n, const uint8_t *keka, size
     if (encrypt) {
         rc = tag(tags);
         if (rc == CAPY_OK) rc = keystream(nullptr);
+        note_kernel(26, 2);
         return rc;
     }
     rc = keystream(nullptr);
     if (rc == CAPY_OK) rc = tag(tag2);
     if (rc) return rc;
     tag_compare_launch(tags, tag_len, tag2, tag_len, (uint32_t)tag_len, status, n, s);
-    return keystream(status);
+    rc = keystream(status);
+    note_kernel(26, 2);
+    return rc;
 }
 
 // sha3_encrypt / sha3_decrypt on device buffers (src/sha3/encryptable.rs:29-83)
@@ -1102,6 +1164,13 @@ int capy_set_sponge_lanes(int lanes)
     lanes &= 0xff;
     if (lanes < 0 || lanes > 3) return fail(CAPY_ERR_ARG, "lanes must be 0 (auto), 1, 2 or 3 (mixed where eligible)");
     g_lanes_per_sponge.store(lanes);
+    return CAPY_OK;
+}
+
+int capy_debug_last_sponge_kernel(int *kind, int *launches)
+{
+    if (kind) *kind = t_last_kind;
+    if (launches) *launches = t_last_launches;
     return CAPY_OK;
 }
 

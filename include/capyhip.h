@@ -113,6 +113,14 @@ int capy_debug_secret_scratch_nonzero(void *stream, uint64_t *nonzero_bytes);
 /* Test hook: which kernel family the calling thread's last variable-base / fixed-base launch took: 1 indexed lookups,
  * 2 constant-address lookups, + 16 for the one-item-per-wave kernels of small batches; 0 = none yet. */
 int capy_debug_last_curve_kernel(int *variable_base, int *fixed_base);
+/* Test hook: which sponge kernel / schedule the calling thread's last digest or encrypt / decrypt launch took, and in how many
+ * launches of the data pass (phases, time slices).  kind: 1 one lane per sponge (latency-tuned), 2 two lanes per sponge,
+ * 3 rotating one-/two-lane schedule, 4 one lane per sponge (issue-tuned), 5 wave-quantisation split, 6 one wave per item,
+ * 7 uniform-framing kernel, 8 rotating-occupancy schedule, 9 uniform-framing kernel in time slices; sha3_encrypt / decrypt and
+ * the other symmetric halves: 20 four lanes per item, 21 one wave per item, 22 four lanes per item in time slices, 23 one lane
+ * per sponge (two lanes per item), 24 the same in time slices, 25 the same on the rotating-occupancy schedule, 26 two passes;
+ * 0 = none yet.  Lets the tests assert that the path they mean to cover is the one that ran. */
+int capy_debug_last_sponge_kernel(int *kind, int *launches);
 
 /* ------------------------------------------------------------------ sponge (src/sha3) */
 
