@@ -23,6 +23,8 @@
 //
 // FORM: 1 = a lone wave per SIMD (plain unrolled round, next block prefetched; the lone role of the rotating schedule)
 //       2 = two waves per SIMD (blocked round with raised priority, unrolled, next block prefetched; <= 256 VGPRs)
+//       3 = the doubled-up role of the rotating-occupancy schedule (two waves per SIMD: the blocked round ROLLED -- two compute
+//           units share an instruction cache, and both roles unrolled evict each other, sponge_rot.h --, next block prefetched)
 //       4 = three or four waves per SIMD (the same round rolled, blocks loaded at the top of the step; <= 128 VGPRs)
 #pragma once
 #include "sponge_fused.h"
@@ -30,6 +32,9 @@
 
 namespace capy {
 
+#ifndef CAPY_F1_ROT_DOUBLED
+#define CAPY_F1_ROT_DOUBLED 3  // 2: the doubled-up role unrolled as well (A/B)
+#endif
 #ifndef CAPY_F1_LB
 #define CAPY_F1_LB 4
 #endif
@@ -59,7 +64,7 @@ __device__ __forceinline__ void fused1_hot(KState &a)
         keccakf1600_unrolled(a);
     else if constexpr (FORM == 2)
         keccakf1600_paired_unrolled<CAPY_PAIRED_PRIO>(a);
-    else
+    else  // 3, 4
         keccakf1600_paired<CAPY_PAIRED_PRIO>(a);
 }
 template <int FORM>
@@ -284,6 +289,10 @@ __device__ __forceinline__ uint32_t fused1_body(const FusedParams &fp, uint32_t 
                         if (fp.direct_stores) {
 #pragma unroll
                             for (int w = 0; w < RW; w++) store_global_u64(blk + 8 * w, pf[w] ^ state_word(a, w));
+                            const uint64_t e2 = (((uint64_t)r.y << 32) | r.x) + RB;
+                            r.x = (uint32_t)e2;
+                            r.y = (uint32_t)(e2 >> 32);
+                            home[q] = r;
                         } else {
                             // per-item rotation of the ring by 16 q: the 8 items of a store group hit different banks
                             uint32_t rp = (r.x + 16 * q) & 255;
@@ -410,6 +419,40 @@ __device__ __forceinline__ uint32_t fused1_body(const FusedParams &fp, uint32_t 
         }
     }
     return 0xffffffffu;
+}
+
+// The rotating-OCCUPANCY schedule of sponge_rot.h for this kernel: batches between one and two waves per SIMD (32 S < n < 64 S
+// items).  One launch of the whole batch takes the two-waves time however few SIMDs hold a second wave; time slices of one
+// wave per SIMD run every wave at the lone-wave rate, which for this kernel is 0.75 of the two-waves throughput.  Here the
+// wave-groups are bundled in fours (= one compute unit at one wave per SIMD, 128 items); in each of P phase launches Cp compute
+// units hold TWO bundles -- two waves per SIMD, rot_nb2 blocks each -- and the others one bundle, rot_nb1 = ratio x rot_nb2
+// blocks; roles rotate (bundle g has role (g + phase 2 Cp) mod G), every bundle is doubled up in the same number of phases, all
+// waves of a phase finish together.  A workgroup is 512 lanes and the kernel is compiled for exactly two waves per SIMD, so a
+// compute unit holds exactly one workgroup; in the lone role waves 4..7 leave at once.  Progress per wave-group in sl_done,
+// states in sl_state, as for the time slices; what the phases leave (a few blocks, tail, tag) is done by one sliced launch of
+// sponge_fused1_kernel.
+template <int RW, bool DECRYPT>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void sponge_fused1_rot_kernel(const FusedParams fp)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_lds[8 * FUSED1_LDS_WAVE];
+    const uint32_t b = blockIdx.x, wave = threadIdx.x >> 6;
+    const bool doubled = b < fp.rot_Cp;  // workgroup-uniform
+    if (!doubled && wave >= 4) return;
+    const uint32_t rho = doubled ? 2 * b + (wave >> 2) : fp.rot_Cp + b;
+    const uint32_t shift = (uint32_t)(((uint64_t)fp.rot_phase * 2 * fp.rot_Cp) % fp.rot_G);
+    const uint32_t g = rho >= shift ? rho - shift : rho + fp.rot_G - shift;
+    const uint32_t grp = g * 4 + (wave & 3);
+    if ((uint64_t)grp * FUSED1_ITEMS >= fp.n) return;  // wave-uniform: an empty bundle / the idle part of the last one
+    const uint32_t done = fp.sl_done[grp];
+    if (done == SLICE_FINISHED) return;
+    const bool fresh = done == SLICE_FRESH;
+    fused1_lds_u8 *lds = (fused1_lds_u8 *)s_lds + wave * FUSED1_LDS_WAVE;
+    uint32_t next;
+    if (doubled)
+        next = fused1_body<RW, CAPY_F1_ROT_DOUBLED, DECRYPT>(fp, grp, fresh ? 0 : done, fp.rot_nb2, fresh, lds);
+    else
+        next = fused1_body<RW, 1, DECRYPT>(fp, grp, fresh ? 0 : done, fp.rot_nb1, fresh, lds);
+    if ((threadIdx.x & 63) == 0) fp.sl_done[grp] = next == 0xffffffffu ? SLICE_FINISHED : next;
 }
 
 // One launch: wave w works on wave-group w (sl_groups == 0), or -- time slices, as in sponge_fused.h -- on wave-group

@@ -38,4 +38,24 @@ hipError_t launch_sponge_fused1(int rw, const FusedParams &fp, hipStream_t s)
     return hipErrorInvalidValue;
 }
 
+// one phase of the rotating-occupancy schedule: `cus` workgroups of 512 lanes
+hipError_t launch_sponge_fused1_rot(int rw, const FusedParams &fp, unsigned cus, hipStream_t s)
+{
+    const dim3 grid(cus), block(512);
+#define CAPY_F1ROT(D)                                                                                  \
+    switch (rw) {                                                                                      \
+    case 17: hipLaunchKernelGGL((sponge_fused1_rot_kernel<17, D>), grid, block, 0, s, fp); break;      \
+    case 19: hipLaunchKernelGGL((sponge_fused1_rot_kernel<19, D>), grid, block, 0, s, fp); break;      \
+    case 21: hipLaunchKernelGGL((sponge_fused1_rot_kernel<21, D>), grid, block, 0, s, fp); break;      \
+    default: return hipErrorInvalidValue;                                                              \
+    }                                                                                                  \
+    return hipGetLastError();
+    if (fp.decrypt) {
+        CAPY_F1ROT(true)
+    } else {
+        CAPY_F1ROT(false)
+    }
+#undef CAPY_F1ROT
+}
+
 }  // namespace capy

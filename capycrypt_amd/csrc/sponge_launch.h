@@ -24,6 +24,7 @@ struct FusedParams;
 hipError_t launch_sponge_fused(int rw, const FusedParams &fp, hipStream_t s);
 // the same with ONE lane per sponge, two lanes per item, for chip-filling batches (sponge_fused1.h); fp.one_lane = the instance
 hipError_t launch_sponge_fused1(int rw, const FusedParams &fp, hipStream_t s);
+hipError_t launch_sponge_fused1_rot(int rw, const FusedParams &fp, unsigned cus, hipStream_t s);
 // digests of very small batches of long messages: two items per wave, a sponge spread over 25 lanes (sponge_wide.h);
 // rw in {9, 13, 17, 18, 19, 21}, digest mode only, no raw prefix bytes
 hipError_t launch_sponge_wide_digest(int rw, const SpongeParams &p, hipStream_t s);

@@ -147,6 +147,20 @@ static std::atomic<int> g_lanes_per_sponge{0};
 static std::atomic<unsigned> g_debug_flags{0};
 unsigned sponge_debug_flags() { return g_debug_flags.load(); }
 static std::atomic<bool> g_fused_enabled{true};
+// what the last symmetric_crypt_dev / launch_sponge call of this thread ran (capy_debug_last_sponge_kernel): kind =
+//   digest launches  1 one-lane latency-tuned, 2 two-lane, 3 rotating one-/two-lane schedule, 4 one-lane issue-tuned, 5 wave-quantisation
+//                    split, 6 wave-per-item, 7 uniform-framing kernel, 8 rotating-occupancy schedule, 9 uniform-framing kernel in time slices
+//   encrypt/decrypt  20 four lanes per item, 21 one wave per item, 22 four lanes per item in time slices, 23 one lane per sponge,
+//                    24 one lane per sponge in time slices, 25 one lane per sponge on the rotating-occupancy schedule, 26 two passes
+// launches = kernel launches of the data pass (phases / slices)
+static thread_local int t_last_kind = 0, t_last_launches = 0;
+static void note_kernel(int kind, int launches)
+{
+    t_last_kind = kind;
+    t_last_launches = launches;
+}
+
+
 // 16 items per wave x one wave per SIMD with the plain round; beyond that the blocked round at raised priority pairs the
 // waves of a SIMD (r03, profiles/r03_chipfull.txt: 32 768 x 5 MiB 353 -> 451 GiB/s, 49 152 x 4 MiB 405 -> 472, 98 304 x
 // 1 MiB 432 -> 515 against the two-pass form; at 131 072 x 1 MiB the two passes win again, 541 vs 527).
@@ -240,7 +254,9 @@ static int try_launch_mixed(int rw, const SpongeParams &p, bool forced, hipStrea
     MixedPlan m;
     if (!mixed_plan(rw, p, forced, m)) return 0;
     const uint64_t n = p.n, n_pad = (n + 63) / 64 * 64;
+    WsScrubGuard scrub(s);  // keyed sponge states when the launch has per-item head blocks: zeroed on every return
     CAPY_WS(state, uint64_t *, s, WS_STATE, 25 * n_pad * sizeof(uint64_t));
+    if (p.head_len) scrub.add(WS_STATE, 25 * n_pad * sizeof(uint64_t));
     MixedParams q;
     memset(&q, 0, sizeof q);
     q.msgs = p.msgs;
@@ -282,6 +298,7 @@ static int try_launch_mixed(int rw, const SpongeParams &p, bool forced, hipStrea
     r.resume_pad = n_pad;
     r.resume_blocks = hb + (uint32_t)m.nf;
     CAPY_HIP(launch_sponge_k1_lat(rw, 0, r, s));
+    note_kernel(3, (int)m.P + 1 + (hb ? 1 : 0));
     return 1;
 }
 
@@ -346,7 +363,9 @@ static int try_launch_rot(int rw, const SpongeParams &p, hipStream_t s)
     RotPlan m;
     if (!rot_plan(rw, p, m)) return 0;
     const uint64_t n = p.n, n_pad = (n + 63) / 64 * 64;
+    WsScrubGuard scrub(s);  // with per-item head blocks these are KEYED sponge states (e.g. by the Schnorr secret): zeroed on every return
     CAPY_WS(state, uint64_t *, s, WS_STATE, 25 * n_pad * sizeof(uint64_t));
+    if (p.head_len) scrub.add(WS_STATE, 25 * n_pad * sizeof(uint64_t));
     RotParams q;
     memset(&q, 0, sizeof q);
     q.msgs = p.msgs;
@@ -383,6 +402,7 @@ static int try_launch_rot(int rw, const SpongeParams &p, hipStream_t s)
     r.resume_pad = n_pad;
     r.resume_blocks = hb + m.a * m.nb2 + (m.P - m.a) * m.nb1;
     CAPY_HIP(launch_sponge_k1_lat_paired(rw, 0, r, s));
+    note_kernel(8, (int)m.P + 1 + (hb ? 1 : 0));
     return 1;
 }
 
@@ -455,7 +475,9 @@ static int try_launch_uniform_sliced(int rw, const SpongeParams &p, int forced, 
     const uint32_t bp = (uint32_t)((nfull + turns - 1) / turns);
     const uint32_t need0 = (uint32_t)((nfull + bp - 1) / bp);
     const size_t done_bytes = (groups * 4 + 255) & ~(size_t)255, state_bytes = groups * 50 * 64 * 4;
+    WsScrubGuard scrub(s);  // keyed sponge states (KMAC heads): zeroed however this returns
     CAPY_WS(ws, uint8_t *, s, WS_STATE, done_bytes + state_bytes);
+    if (p.head_len) scrub.add(WS_STATE, done_bytes + state_bytes);
     CAPY_HIP(hipMemsetAsync(ws, 0xff, done_bytes, s));
     SpongeParams q = p;
     q.sl_groups = (uint32_t)groups;
@@ -475,7 +497,7 @@ static int try_launch_uniform_sliced(int rw, const SpongeParams &p, int forced, 
             if (left && --left == 0) open_groups--;
         }
     }
-    if (p.head_len) workspace_scrub(s, WS_STATE, done_bytes + state_bytes);  // keyed sponge states
+    note_kernel(9, (int)q.sl_launch + 1);
     return 1;
 }
 
@@ -589,20 +611,22 @@ static int launch_sponge(int rw, const SpongeParams &p, hipStream_t s)
         e = launch_sponge_uniform(rw, p2, uniform_waves(), s);
         if (e == hipErrorInvalidValue) return fail(CAPY_ERR_ARG, "internal: no kernel instance for this rate");
         CAPY_HIP(e);
+        note_kernel(7, 1);
         return CAPY_OK;
     }
     // Very small digest batches of long messages: one sponge per 25 lanes (sponge_wide.h), 1.3x the two-lane kernel per
     // permutation while every wave has most of a SIMD pair's LDS bandwidth to itself (n / 2 waves <= SIMDs / 2).
     // Debug bit 4 / 5: never / always.
+    int kind = 1;
     if (wide_digest_ok(rw, p2, forced, q.debug_flags))
-        e = launch_sponge_wide_digest(rw, p2, s);
+        kind = 6, e = launch_sponge_wide_digest(rw, p2, s);
     else if (forced == 2 || ((forced == 0 || forced == 3) && p.n <= 32 * simds))
-        e = launch_sponge_k2(rw, (int)p.out_mode, p2, s);
+        kind = 2, e = launch_sponge_k2(rw, (int)p.out_mode, p2, s);
     // ragged batches stay on the latency-tuned instance at every size: its ragged path keeps the source pointers in
     // registers and prefetches a block ahead, which the 128-VGPR issue-tuned instance cannot afford (2^18 ragged
     // messages of 0..64 KiB: 16.0 vs 13.6 ms; equal lengths given through offsets: 9.7 vs 8.1 ms)
     else if (p.n > 128 * simds && !(q.debug_flags & 2) && !p2.offsets && !p2.order)  // debug bit 1: A/B switch
-        e = launch_sponge_k1_full(rw, (int)p.out_mode, p2, s);
+        kind = 4, e = launch_sponge_k1_full(rw, (int)p.out_mode, p2, s);
     // more than one wave on some SIMD: the paired form of the latency-tuned instance (debug bit 8: A/B switch)
     else if (p.n > 64 * simds && !(q.debug_flags & 256))
         e = launch_sponge_k1_lat_paired(rw, (int)p.out_mode, p2, s);
@@ -610,6 +634,7 @@ static int launch_sponge(int rw, const SpongeParams &p, hipStream_t s)
         e = launch_sponge_k1_lat(rw, (int)p.out_mode, p2, s);
     if (e == hipErrorInvalidValue) return fail(CAPY_ERR_ARG, "internal: no kernel instance for this rate / mode");
     CAPY_HIP(e);
+    note_kernel(kind, 1);
     return CAPY_OK;
 }
 
@@ -908,24 +933,51 @@ __global__ __launch_bounds__(64) void keccak_probe_kernel(uint64_t n_states, uin
         atomicXor((unsigned long long *)checksum, ((uint64_t)y << 32) | x);
 }
 
-// first batch size that takes the one-lane-per-sponge fused kernel: more than 32 items per SIMD
+// first batch size that takes the one-lane-per-sponge fused kernel.  From 32 items per SIMD on there is a sponge for every lane
+// of the chip, but just above that size the one-lane form runs mostly lone waves (477 GiB/s against 497-501 for the four-lane
+// form in time slices of two waves per SIMD); measured crossover 35 items per SIMD (profiles/r05_fused_one_lane.txt)
 static size_t fused1_min_items()
 {
     static const long forced = (long)debug_knob("fused1_min", -1);
-    return forced >= 0 ? (size_t)forced : 32 * (size_t)device_simds() + 1;
+    return forced >= 0 ? (size_t)forced : 35 * (size_t)device_simds() + 1;
 }
 
-// what the last symmetric_crypt_dev / launch_sponge call of this thread ran (capy_debug_last_sponge_kernel): kind =
-//   digest launches  1 one-lane latency-tuned, 2 two-lane, 3 rotating one-/two-lane schedule, 4 one-lane issue-tuned, 5 wave-quantisation
-//                    split, 6 wave-per-item, 7 uniform-framing kernel, 8 rotating-occupancy schedule, 9 uniform-framing kernel in time slices
-//   encrypt/decrypt  20 four lanes per item, 21 one wave per item, 22 four lanes per item in time slices, 23 one lane per sponge,
-//                    24 one lane per sponge in time slices, 25 one lane per sponge on the rotating-occupancy schedule, 26 two passes
-// launches = kernel launches of the data pass (phases / slices)
-static thread_local int t_last_kind = 0, t_last_launches = 0;
-static void note_kernel(int kind, int launches)
+// The plan of the rotating-occupancy schedule for the one-lane fused kernel: bundles of 128 items (four waves), C compute units,
+// Cp of them doubled up per phase, P phases, every bundle doubled up in `a` of them (the arithmetic of rot_plan above);
+// nb1 / nb2 = the speed of a lone wave (unrolled plain round) over that of a wave that shares its SIMD (rolled blocked round);
+// swept 1.25 .. 1.6 over 36 864 .. 61 440 x 1 MiB: best at 1.45 (profiles/r05_fused_one_lane.txt); CAPY_DEBUG=fused1_ratio=R for A/B.
+static bool fused1_rot_plan(uint64_t n, uint64_t nf, size_t simds, RotPlan &m)
 {
-    t_last_kind = kind;
-    t_last_launches = launches;
+    static const double ratio = [] {
+        const double v = debug_knob("fused1_ratio", 0.0);
+        return (v >= 1.0 && v <= 2.5) ? v : 1.45;
+    }();
+    if (n <= 32 * simds || n >= 64 * simds) return false;
+    m.nf = nf;
+    m.C = (uint32_t)(simds / 4);
+    const uint64_t bundles = (n + 127) / 128;
+    if (bundles <= m.C) return false;
+    const uint32_t cp0 = (uint32_t)(bundles - m.C);
+    double best = 2.0;
+    m.P = 0;
+    for (uint32_t a = 1; a <= 24; a++)
+        for (uint32_t P = a + 1; P <= 24; P++) {
+            if ((a * m.C) % (2 * P - a)) continue;
+            const uint32_t cp = a * m.C / (2 * P - a);
+            if (cp < cp0 || cp > m.C) continue;
+            const double f = (double)a / P;
+            if (f < best - 1e-12 || (f < best + 1e-12 && P < m.P)) {
+                best = f;
+                m.P = P;
+                m.a = a;
+                m.Cp = cp;
+            }
+        }
+    if (!m.P) return false;
+    m.G = m.C + m.Cp;
+    m.nb2 = (uint32_t)((double)nf / ((double)m.a + ratio * (double)(m.P - m.a)));
+    m.nb1 = (uint32_t)((nf - (uint64_t)m.a * m.nb2) / (m.P - m.a));
+    return m.nb2 != 0 && m.nb1 != 0;
 }
 
 // The one-lane-per-sponge fused pass (sponge_fused1.h) over a batch that fills the chip; fp is complete but for the schedule.
@@ -945,6 +997,92 @@ static int fused1_launch(int rw, FusedParams &fp, const MsgView &m, hipStream_t 
         const size_t w = (groups + simds - 1) / simds;
         static const int forced_cap = (int)debug_knob("fused1_waves", 0);
         fp.cap_waves = forced_cap ? (uint32_t)forced_cap : (w <= 3 ? (uint32_t)w : 0u);
+    }
+    const uint64_t nfull = m.offsets ? 0 : m.uniform_len / ((uint64_t)rw * 8);
+    const bool long_uniform = !forced_form && !m.offsets && !m.order && nfull >= 512 && nfull < 0xfffffff0u;
+    // Between one and two waves per SIMD: the rotating-occupancy schedule (sponge_fused1.h: sponge_fused1_rot_kernel).
+    // CAPY_DEBUG=fused1_rot=0 switches it off.
+    static const bool rot_on = debug_knob("fused1_rot", 1) != 0;
+    RotPlan rp;
+    if (rot_on && long_uniform && fused1_rot_plan(fp.n, nfull, simds, rp)) {
+        const size_t done_bytes = (groups * 4 + 255) & ~(size_t)255, state_bytes = groups * 50 * 64 * 4;
+        WsScrubGuard scrub(s);  // keyed sponge states: zeroed however this returns
+        CAPY_WS(slws, uint8_t *, s, WS_STATE, done_bytes + state_bytes);
+        scrub.add(WS_STATE, done_bytes + state_bytes);
+        CAPY_HIP(hipMemsetAsync(slws, 0xff, done_bytes, s));  // SLICE_FRESH
+        fp.sl_done = reinterpret_cast<uint32_t *>(slws);
+        fp.sl_state = reinterpret_cast<uint32_t *>(slws + done_bytes);
+        fp.rot_Cp = rp.Cp;
+        fp.rot_G = rp.G;
+        fp.rot_nb1 = rp.nb1;
+        fp.rot_nb2 = rp.nb2;
+        for (uint32_t ph = 0; ph < rp.P; ph++) {
+            fp.rot_phase = ph;
+            hipError_t e = launch_sponge_fused1_rot(rw, fp, rp.C, s);
+            if (e == hipErrorInvalidValue) return fail(CAPY_ERR_ARG, "internal: no one-lane fused kernel instance for this rate");
+            CAPY_HIP(e);
+        }
+        // what the phases left of the full blocks (fewer than P - a), tail and tag: one launch over all wave-groups
+        fp.rot_G = 0;
+        fp.one_lane = 2;
+        fp.cap_waves = 0;
+        fp.sl_groups = (uint32_t)groups;
+        fp.sl_grid = (uint32_t)groups;
+        fp.sl_launch = 0;
+        fp.sl_blocks = 0xffffffffu;
+        CAPY_HIP(launch_sponge_fused1(rw, fp, s));
+        fp.sl_groups = 0;
+        note_kernel(25, (int)rp.P + 1);
+        return CAPY_OK;
+    }
+    // TIME SLICES for uniform batches of long messages whose wave count is not a whole number per SIMD (as for the four-lane
+    // kernel and the uniform-framing digest kernel): one launch of the whole batch puts a further wave on some SIMDs and takes
+    // that many waves' time however few they are.  Instead every launch holds exactly `level` waves per SIMD, launch k works on
+    // the wave-groups (k level S + w) mod G for `bp` full blocks, the states cross launches through WS_STATE (12.8 KB per group
+    // of 32 items), heads in a group's first turn, tail and tag in its last.  CAPY_DEBUG=fused1_slices=0 switches it off.
+    static const bool slices_on = debug_knob("fused1_slices", 1) != 0;
+    // level = waves per SIMD and launch.  Measured (1 MiB messages, profiles/r05_fused_one_lane.txt): slices of two waves per
+    // SIMD on the unrolled instance run at a flat 645-650 GiB/s for every batch size, the rolled instance at three waves per SIMD
+    // reaches 620-645 and at four 665-670 -- so beyond two waves per SIMD every batch takes level 2 unless it is within a fifth
+    // of a quantum below a whole number q >= 4 of waves per SIMD, where one launch of the four-waves instance is at its best.
+    // Level 1 (lone waves, 477 GiB/s) only when the rotating schedule above is switched off.
+    uint32_t level = 0;
+    if (groups > simds && groups * 100 <= simds * 149) level = 1;
+    else if (groups > 2 * simds) {
+        const size_t q = (groups + simds - 1) / simds;
+        if (!(q >= 4 && groups * 5 > (5 * q - 1) * simds)) level = 2;
+    }
+    if (slices_on && level && long_uniform) {
+        static const uint64_t max_turns = (uint64_t)debug_knob("fused1_turns", 64);
+        const uint32_t turns = (uint32_t)std::min<uint64_t>(max_turns ? max_turns : 64, nfull / 64);  // >= 8 turns per group
+        const uint32_t bp = (uint32_t)((nfull + turns - 1) / turns);
+        const uint32_t need0 = (uint32_t)((nfull + bp - 1) / bp);
+        const size_t done_bytes = (groups * 4 + 255) & ~(size_t)255, state_bytes = groups * 50 * 64 * 4;
+        WsScrubGuard scrub(s);  // keyed sponge states: zeroed however this returns
+        CAPY_WS(slws, uint8_t *, s, WS_STATE, done_bytes + state_bytes);
+        scrub.add(WS_STATE, done_bytes + state_bytes);
+        CAPY_HIP(hipMemsetAsync(slws, 0xff, done_bytes, s));  // SLICE_FRESH
+        fp.one_lane = level == 1 ? 1 : 2;
+        fp.cap_waves = 0;
+        fp.sl_groups = (uint32_t)groups;
+        fp.sl_grid = (uint32_t)(level * simds);
+        fp.sl_blocks = bp;
+        fp.sl_done = reinterpret_cast<uint32_t *>(slws);
+        fp.sl_state = reinterpret_cast<uint32_t *>(slws + done_bytes);
+        std::vector<uint32_t> need(groups, need0);
+        size_t open_groups = groups;
+        uint32_t k = 0;
+        for (; open_groups; k++) {
+            fp.sl_launch = k;
+            CAPY_HIP(launch_sponge_fused1(rw, fp, s));
+            for (size_t w = 0; w < fp.sl_grid; w++) {
+                uint32_t &left = need[((size_t)k * fp.sl_grid + w) % groups];
+                if (left && --left == 0) open_groups--;
+            }
+        }
+        fp.sl_groups = 0;
+        note_kernel(24, (int)k);
+        return CAPY_OK;
     }
     fp.sl_groups = 0;
     hipError_t e = launch_sponge_fused1(rw, fp, s);
@@ -968,8 +1106,11 @@ int symmetric_crypt_dev(bool encrypt, int d, size_t n, const uint8_t *keka, size
     if (!valid_d(d)) return fail(CAPY_ERR_UNSUPPORTED_SECPARAM, "unsupported security parameter");
     if (n == 0) return CAPY_OK;
     auto keystream = [&](const int32_t *mask) {
-        return kmac_launch(d, n, fixed_keys(keka, key_len, keka_stride), m, false, (const uint8_t *)ke_custom,
-                           strlen(ke_custom), 1, nullptr, 0, 0, mask, s);
+        const int kind = t_last_kind, launches = t_last_launches;  // the masked restore pass of decrypt is not what the hook reports
+        const int rc = kmac_launch(d, n, fixed_keys(keka, key_len, keka_stride), m, false, (const uint8_t *)ke_custom,
+                                   strlen(ke_custom), 1, nullptr, 0, 0, mask, s);
+        if (mask) note_kernel(kind, launches);
+        return rc;
     };
     auto tag = [&](uint8_t *out) {
         return kmac_launch(d, n, fixed_keys(keka + key_len, key_len, keka_stride), m, true, (const uint8_t *)ka_custom,
@@ -983,8 +1124,8 @@ int symmetric_crypt_dev(bool encrypt, int d, size_t n, const uint8_t *keka, size
     const Framing ff = cshake_framing(d);
     const bool fused_shape = g_fused_enabled.load() && ff.stride == (uint32_t)ff.rw * 8 && m.aligned8 && m.msgs != nullptr &&
                              tag_len <= 64 && (tag_len & 3) == 0;
-    // From 32 items per SIMD on there is one sponge for every lane of the chip: one lane per sponge (sponge_fused1.h), at every
-    // larger batch size; below, four lanes per item (sponge_fused.h).  CAPY_DEBUG=fused1_min=N moves the boundary (A/B, tests).
+    // From 35 items per SIMD on: one lane per sponge (sponge_fused1.h), at every larger batch size; below, four lanes per item
+    // (sponge_fused.h).  CAPY_DEBUG=fused1_min=N moves the boundary (A/B, tests).
     const bool one_lane = fused_shape && n >= fused1_min_items() && (key_len & 7) == 0 && (((uintptr_t)keka | keka_stride) & 7) == 0;
     const bool fused_ok = fused_shape && (one_lane || n <= FUSED_MAX_ITEMS);
     if (fused_ok) {
@@ -1051,18 +1192,21 @@ int symmetric_crypt_dev(bool encrypt, int d, size_t n, const uint8_t *keka, size
             const uint64_t nfull = m.offsets ? 0 : m.uniform_len / ((uint64_t)ff.rw * 8);
             const size_t groups = (n + 15) / 16;
             static const bool slices_on = debug_knob("fused_slices", 1) != 0;
-            // level k = waves per SIMD and launch: k = 1 for 16 384 < n <= 22 528, k = 2 for 32 768 < n <= 43 008, k = 3 for
-            // 49 152 < n <= 61 440 (beyond the limit of a level the single launch with k + 1 waves on some SIMDs is as fast)
+            // level k = waves per SIMD and launch: k = 1 for 16 384 < n <= 22 528, k = 2 for 32 768 < n <= 43 008 (beyond the limit
+            // of a level the single launch with k + 1 waves on some SIMDs is as fast; from 35 840 items on the one-lane-per-sponge
+            // kernel takes the batch, so r04's third level, 49 152 < n <= 61 440, is gone)
             uint32_t level = 0;
-            static const size_t level_limit[4] = {0, 22, 42, 60};  // items per SIMD up to which level k pays
-            for (uint32_t k = 1; k <= 3; k++)
+            static const size_t level_limit[3] = {0, 22, 42};  // items per SIMD up to which level k pays
+            for (uint32_t k = 1; k <= 2; k++)
                 if (groups > k * simds && groups * 16 <= simds * level_limit[k]) level = k;
             if (slices_on && !fp.staged && !fp.wide && !m.offsets && !m.order && level && nfull >= 512 && nfull < 0xfffffff0u) {
                 const uint32_t turns = (uint32_t)std::min<uint64_t>(64, nfull / 64);  // >= 8 turns per group
                 const uint32_t bp = (uint32_t)((nfull + turns - 1) / turns);
                 const uint32_t need0 = (uint32_t)((nfull + bp - 1) / bp);
                 const size_t done_bytes = (groups * 4 + 255) & ~(size_t)255, state_bytes = groups * 25 * 64 * 4;
+                WsScrubGuard slscrub(s);  // keyed sponge states: zeroed however this block is left
                 CAPY_WS(slws, uint8_t *, s, WS_STATE, done_bytes + state_bytes);
+                slscrub.add(WS_STATE, done_bytes + state_bytes);
                 CAPY_HIP(hipMemsetAsync(slws, 0xff, done_bytes, s));  // SLICE_FRESH
                 fp.paired = level == 1 ? 0 : level;  // the instance compiled for exactly `level` waves per SIMD
                 fp.sl_groups = (uint32_t)groups;
@@ -1080,7 +1224,6 @@ int symmetric_crypt_dev(bool encrypt, int d, size_t n, const uint8_t *keka, size
                         if (left && --left == 0) open_groups--;
                     }
                 }
-                workspace_scrub(s, WS_STATE, done_bytes + state_bytes);  // keyed sponge states
                 note_kernel(22, (int)fp.sl_launch + 1);
                 fp.sl_groups = 0;
             } else {
