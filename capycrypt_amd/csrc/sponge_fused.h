@@ -54,7 +54,7 @@ struct FusedParams {
     // instance (0: not this form; 1 lone wave per SIMD, 2 two waves, 4 three or four), A/B switch for per-lane stores
     // instead of whole lines, occupancy cap in waves per SIMD (0: none), and the rotating-occupancy schedule's phase
     // (sponge_fused1.h: fused1_rot_kernel; rot_G == 0: not that schedule)
-    uint32_t one_lane, direct_stores, cap_waves;
+    uint32_t one_lane, direct_stores, cap_waves, store_policy;
     uint32_t rot_phase, rot_Cp, rot_G, rot_nb1, rot_nb2;
 };
 constexpr uint32_t SLICE_FRESH = 0xffffffffu, SLICE_FINISHED = 0xfffffffeu;

@@ -98,7 +98,8 @@ __device__ __forceinline__ uint64_t fused1_trailer_word(uint32_t rel, uint32_t l
 // item writes what it still holds (the last, partial line of its range).  Lane l serves the 16-byte chunk l % 8 of item
 // 8 k + l / 8 for k = 0 .. 3, straight from that item's record.  Returns false (wave-uniform) when no item had anything.
 template <bool FINAL, bool ROLLED>
-__device__ __forceinline__ bool fused1_flush_pass(uint32_t role, uint32_t q, uint32_t lane, fused1_lds_u8 *ring, fused1_lds_u32x4 *home)
+__device__ __forceinline__ bool fused1_flush_pass(uint32_t role, uint32_t q, uint32_t lane, fused1_lds_u8 *ring, fused1_lds_u32x4 *home,
+                                                  uint32_t policy)
 {
     fused1_u32x4 mine = home[q];
     const bool has = FINAL ? mine.z > mine.w : mine.z >= 128;
@@ -113,7 +114,15 @@ __device__ __forceinline__ bool fused1_flush_pass(uint32_t role, uint32_t q, uin
             const uint64_t gl = (((uint64_t)r.y << 32) | r.x) - r.z;
             const uint32_t ro = (((uint32_t)gl & 255) + 16 * j + c16) & 255;
             const fused1_u32x4 v = *reinterpret_cast<const fused1_lds_u32x4 *>(ring + j * FUSED1_RING + ro);
-            *reinterpret_cast<__attribute__((address_space(1))) fused1_u32x4 *>(gl + c16) = v;
+            // policy (wave-uniform; A/B, CAPY_DEBUG=fused1_store): 0 plain stores -- the written lines stay in the XCD's L2 --,
+            // 1 sc1 (written through and dropped from L2), 2 nt
+            const uint64_t dst = gl + c16;
+            if (policy == 1)
+                asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
+            else if (policy == 2)
+                asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(dst), "v"(v) : "memory");
+            else
+                *reinterpret_cast<__attribute__((address_space(1))) fused1_u32x4 *>(dst) = v;
         }
     };
     if constexpr (ROLLED) {  // the 128-register instance: one item at a time; the other waves of the SIMD cover the LDS round trips
@@ -318,7 +327,7 @@ __device__ __forceinline__ uint32_t fused1_body(const FusedParams &fp, uint32_t 
                 if constexpr (W1 < RW) {
                     fused1_wave_sync();
                     if (!fp.direct_stores) {  // wave-uniform
-                        while (fused1_flush_pass<false, FORM == 4>(role, q, lane, ring, home)) {
+                        while (fused1_flush_pass<false, FORM == 4>(role, q, lane, ring, home, fp.store_policy)) {
                         }
                         if (live && role == 1) {
                             r = home[q];
@@ -342,13 +351,13 @@ __device__ __forceinline__ uint32_t fused1_body(const FusedParams &fp, uint32_t 
                 }
                 fused1_wave_sync();
                 if (!fp.direct_stores) {  // wave-uniform
-                    while (fused1_flush_pass<false, FORM == 4>(role, q, lane, ring, home)) {
+                    while (fused1_flush_pass<false, FORM == 4>(role, q, lane, ring, home, fp.store_policy)) {
                     }
                 }
                 if (live) fused1_hot<FORM>(a);
             }
             if (!fp.direct_stores) {
-                while (fused1_flush_pass<true, true>(role, q, lane, ring, home)) {
+                while (fused1_flush_pass<true, true>(role, q, lane, ring, home, fp.store_policy)) {
                 }
             }
         }

@@ -987,6 +987,12 @@ static int fused1_launch(int rw, FusedParams &fp, const MsgView &m, hipStream_t 
     const size_t groups = (fp.n + 31) / 32;  // waves
     static const bool direct = debug_knob("fused1_direct", 0) != 0;
     fp.direct_stores = direct ? 1 : 0;
+    // line stores with sc1: written through and dropped from the XCD's L2.  Plain stores keep the written lines there, where
+    // they crowd out the message lines that the next block step needs again (a 136-byte block shares a line with its successor):
+    // HBM reads 1.26x the message bytes at four waves per SIMD and 1.09x at two against 1.015x / 1.003x with sc1, at the same
+    // speed (profiles/r05_fused_one_lane.txt); CAPY_DEBUG=fused1_store=0 plain, 2 nt (1.19x / 1.02x)
+    static const uint32_t store_policy = (uint32_t)debug_knob("fused1_store", 1);
+    fp.store_policy = store_policy;
     // up to two waves per SIMD: the unrolled blocked round with the next block prefetched; beyond: the rolled round at three
     // or four waves per SIMD
     static const int forced_form = (int)debug_knob("fused1_form", 0);
