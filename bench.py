@@ -79,6 +79,7 @@ def parse():
                     help="5 MiB messages per GPU per step (reduced automatically to what fits in HBM)")
     ap.add_argument("--lanes", type=int, default=0, help="sponge lanes per item: 0 auto, 1 or 2 (tuning/debug)")
     ap.add_argument("--ed448-pairs", type=int, default=1 << 18, help="(scalar, point) pairs per GPU (0 = skip)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the secondary legs for BASELINE configs 2, 3 and 5")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--crossover", action="store_true",
@@ -211,6 +212,211 @@ def cpu_baseline_ed448(seconds, sample):
     return n / (time.perf_counter() - t0)
 
 
+# ------------------------------------------------------------------ BASELINE.json configs 2, 3 and 5 (secondary legs of the line)
+# One function per config, shared with tools/bench_configs.py.  Each returns (result dict, sample); `sample` holds a few timed
+# inputs / outputs that cpu_baseline's leg later checks against the oracle (the only place this file touches oracle/), and every
+# function checks a size-independent property of ALL its outputs itself (round trip, verification, a second kernel family).
+class Ctx:
+    """what a config leg needs: the library, torch's device / stream, and the N > 1 plumbing (barrier, max over ranks)"""
+
+    def __init__(self, lib, _lib, torch, dev, stream, world=1, rank=0, barrier=None, reduce_max=None):
+        self.lib, self._lib, self.torch, self.dev, self.stream = lib, _lib, torch, dev, stream
+        self.sp = C.c_void_p(stream.cuda_stream)
+        self.world, self.rank = world, rank
+        self.barrier = barrier or (lambda: torch.cuda.synchronize())
+        self.reduce_max = reduce_max or (lambda x: x)
+
+    def rand(self, nbytes, seed):
+        t = self.torch.empty((nbytes + 7) // 8 * 8, dtype=self.torch.uint8, device=self.dev)
+        self._lib.check(self.lib.capy_fill_random_dev(t.data_ptr(), t.numel(), seed + self.rank, self.sp))
+        return t
+
+    def timed(self, fn, reps):
+        """seconds per call: `reps` back-to-back calls between two barriers, the max over the ranks"""
+        fn()
+        self.barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        self.barrier()
+        return self.reduce_max(time.perf_counter() - t0) / reps
+
+    def last_sponge_kernel(self):
+        k, l = C.c_int(0), C.c_int(0)
+        self.lib.capy_debug_last_sponge_kernel(C.byref(k), C.byref(l))
+        return {"kind": k.value, "launches": l.value}
+
+
+def config2(cx, n=1 << 20, reps=30):
+    """BASELINE config 2: n units of kmac_xof(k_i, "", 8192 bits, "SKE", D512) -- the squeeze path of sha3_encrypt
+    (/root/reference/src/sha3/encryptable.rs:41) -- per rank; 64-byte keys, 1 KiB out per unit."""
+    lib, _lib, torch = cx.lib, cx._lib, cx.torch
+    keys = cx.rand(n * 64, 0xCA9C0002)
+    out = torch.empty(n * 1024, dtype=torch.uint8, device=cx.dev)
+
+    def run(lanes=0):
+        _lib.check(lib.capy_set_sponge_lanes(lanes))
+        _lib.check(lib.capy_kmac_xof_batch_dev(512, n, keys.data_ptr(), 64, 64, None, None, None, 0, 0, 8192, b"SKE", 3, out.data_ptr(), 1024, cx.sp))
+
+    # a 0.8 ms launch: a few repetitions only see the clock settle; 30 reach the steady state
+    s = cx.timed(run, reps)
+    ref = out.clone()
+    kern = cx.last_sponge_kernel()
+    # every output byte against a second kernel family (the generic one-lane kernel: debug bit 7 = never the uniform-framing one)
+    try:
+        run(1 << 15)
+        cx.torch.cuda.synchronize()
+    finally:
+        _lib.check(lib.capy_set_sponge_lanes(0))
+    same = bool(torch.equal(out, ref))
+    sample = [(bytes(keys[64 * i:64 * i + 64].cpu().numpy()), bytes(ref[1024 * i:1024 * i + 1024].cpu().numpy())) for i in (0, n // 2, n - 1)]
+    res = {"what": "%d x KMACXOF256 1 KiB squeeze (64-B keys) per GPU" % n, "seconds": s, "units_per_s": cx.world * n / s,
+           "out_GBps": cx.world * n * 1024 / s / 1e9,
+           # 9 permutations run on the device per unit: 2 absorb (key block, suffix block) + 7 between the 8 squeeze blocks; the
+           # reference runs 11 (the shared prefix block, folded into the initial state here, and a wasted last one)
+           "device_permutations_per_s": cx.world * n * 9 / s, "kernel": kern,
+           "all_outputs_equal_second_kernel_family": same}
+    assert same, "config 2: kernel families disagree"
+    return res, sample
+
+
+def config3(cx, specified_total=1024, saturating=((65536, 1 << 20), (131072, 1 << 20), (32768, MSG_BYTES), (49152, MSG_BYTES))):
+    """BASELINE config 3: sha3_encrypt D512 (/root/reference/src/sha3/encryptable.rs:29-45) over 5 MiB messages -- as specified
+    (1024 messages split over 8 GPUs = 128 per GPU; here specified_total / world per rank, and the whole 1024 on one rank beside
+    it) and in its saturating form.  Every batch is decrypted again: all tags verify, all plaintext bytes return."""
+    lib, _lib, torch = cx.lib, cx._lib, cx.torch
+    res = {"what": "sha3_encrypt / sha3_decrypt D512, device-resident; GiB/s = message bytes / 2^30 / seconds, whole job"}
+    sample = None
+
+    def one(nmsg, ln, stride, reps):
+        nonlocal sample
+        msgs = cx.rand(nmsg * stride, 0xCA9C0003)
+        pws, zs = cx.rand(nmsg * 64, 0xCA9C0031), cx.rand(nmsg * 512, 0xCA9C0032)
+        tags = torch.empty(nmsg * 64, dtype=torch.uint8, device=cx.dev)
+        status = torch.full((nmsg,), 7, dtype=torch.int32, device=cx.dev)
+        keep = msgs[:ln].clone()
+
+        def enc():
+            _lib.check(lib.capy_sha3_encrypt_batch_dev(512, nmsg, pws.data_ptr(), 64, None, 0, zs.data_ptr(), msgs.data_ptr(), None, ln, stride,
+                                                      tags.data_ptr(), cx.sp))
+
+        def dec():
+            _lib.check(lib.capy_sha3_decrypt_batch_dev(512, nmsg, pws.data_ptr(), 64, None, 0, zs.data_ptr(), msgs.data_ptr(), None, ln, stride,
+                                                      tags.data_ptr(), status.data_ptr(), cx.sp))
+
+        te = td = 1e9
+        for _ in range(reps):  # encrypt and decrypt alternate, so that every encrypt sees plaintext
+            cx.barrier()
+            t0 = time.perf_counter()
+            enc()
+            cx.barrier()
+            te = min(te, cx.reduce_max(time.perf_counter() - t0))
+            if sample is None:
+                sample = (bytes(pws[:64].cpu().numpy()), bytes(zs[:512].cpu().numpy()), bytes(keep.cpu().numpy()), bytes(msgs[:ln].cpu().numpy()),
+                          bytes(tags[:64].cpu().numpy()))
+            t0 = time.perf_counter()
+            dec()
+            cx.barrier()
+            td = min(td, cx.reduce_max(time.perf_counter() - t0))
+        kern = cx.last_sponge_kernel()
+        ok = bool((status == 0).all().item()) and bool(torch.equal(msgs[:ln], keep))
+        assert ok, "config 3: round trip failed at %d x %d" % (nmsg, ln)
+        del msgs
+        torch.cuda.empty_cache()
+        return te, td, kern
+
+    per_rank = max(1, specified_total // cx.world)
+    te, td, kern = one(per_rank, MSG_BYTES, MSG_BYTES + 128, 2)
+    res["as_specified"] = {"messages_total": per_rank * cx.world, "messages_per_gpu": per_rank, "enc_seconds": te, "dec_seconds": td,
+                           "enc_GiBps": per_rank * cx.world * MSG_BYTES / te / 2**30, "kernel": kern,
+                           "note": "a chain-latency workload: every sponge is 38 553 serial permutations whatever the batch"}
+    if cx.world == 1 and per_rank != 128:
+        te8, td8, kern8 = one(128, MSG_BYTES, MSG_BYTES + 128, 2)
+        res["one_eighth_on_one_gpu"] = {"messages": 128, "enc_seconds": te8, "dec_seconds": td8, "kernel": kern8,
+                                        "note": "what each of eight GPUs would run: config 3 as specified does not scale -- one GPU takes the "
+                                                "whole config in %.2f x the time eight GPUs need for their eighth" % (te / te8)}
+    sat = []
+    free, _ = torch.cuda.mem_get_info()
+    for nmsg, ln in saturating:
+        if nmsg * (ln + 128) > free - (8 << 30):
+            continue
+        te, td, kern = one(nmsg, ln, ln + 128, 2)
+        sat.append({"messages_per_gpu": nmsg, "msg_bytes": ln, "enc_seconds": te, "dec_seconds": td,
+                    "enc_GiBps": cx.world * nmsg * ln / te / 2**30, "dec_GiBps": cx.world * nmsg * ln / td / 2**30,
+                    "algorithmic_GBps": 2 * cx.world * nmsg * ln / te / 1e9, "frac_of_hbm_peak": 2 * nmsg * ln / te / 1e9 / HBM_PEAK_GBS,
+                    # two permutations per 136-byte block (tag sponge + keystream sponge)
+                    "device_permutations_per_s": cx.world * nmsg * (ln // 136 + 3) * 2 / te, "kernel": kern})
+    res["saturating"] = sat
+    return res, sample
+
+
+def config5(cx, n=1 << 16, msg_len=1024):
+    """BASELINE config 5: Schnorr keypair / sign / verify (/root/reference/src/ecc/keypair.rs:41-51, signable.rs:40-87) over n
+    messages of 1 KiB through the HOST-buffer C ABI (PCIe inclusive), D512, default (hardened) mode.  Every signature verifies;
+    after one message byte is flipped exactly that item fails."""
+    import random
+
+    lib, _lib = cx.lib, cx._lib
+    rng = random.Random(0xCA9C0005 + cx.rank)
+    msgs_h = C.create_string_buffer(rng.randbytes(n * msg_len), n * msg_len)
+    pws_h = C.create_string_buffer(rng.randbytes(n * 64), n * 64)
+    offs_h = (C.c_uint64 * (n + 1))(*[i * msg_len for i in range(n + 1)])
+    pubs_h, h_h, z_h, st_h = (C.c_uint8 * (n * 112))(), (C.c_uint8 * (n * 56))(), (C.c_uint8 * (n * 56))(), (C.c_int32 * n)()
+
+    def steady(fn):
+        """seconds of the first call (scratch pools, side stream, fixed-base tables, host pages not yet pinned) and of the best of
+        three further ones, max over the ranks"""
+        t0 = time.perf_counter()
+        _lib.check(fn())
+        first = time.perf_counter() - t0
+        best = 1e9
+        for _ in range(3):
+            cx.barrier()
+            t0 = time.perf_counter()
+            _lib.check(fn())
+            best = min(best, cx.reduce_max(time.perf_counter() - t0))
+        return first, best
+
+    tk0, tk = steady(lambda: lib.capy_keypair_batch(512, n, pws_h, 64, None, pubs_h))
+    ts0, ts = steady(lambda: lib.capy_schnorr_sign_batch(512, n, pws_h, 64, None, msgs_h, offs_h, h_h, z_h))
+    tv0, tv = steady(lambda: lib.capy_schnorr_verify_batch(512, n, pubs_h, msgs_h, offs_h, h_h, z_h, st_h))
+    all_ok = not any(st_h)
+    f = rng.randrange(n)
+    msgs_h[f * msg_len + 3] = bytes([msgs_h.raw[f * msg_len + 3] ^ 1])
+    _lib.check(lib.capy_schnorr_verify_batch(512, n, pubs_h, msgs_h, offs_h, h_h, z_h, st_h))
+    bad = [i for i in range(n) if st_h[i]]
+    msgs_h[f * msg_len + 3] = bytes([msgs_h.raw[f * msg_len + 3] ^ 1])
+    assert all_ok and bad == [f], "config 5: verification"
+    sample = [(pws_h.raw[64 * i:64 * i + 64], msgs_h.raw[msg_len * i:msg_len * (i + 1)], bytes(pubs_h[112 * i:112 * i + 112]),
+               bytes(h_h[56 * i:56 * i + 56]), bytes(z_h[56 * i:56 * i + 56])) for i in (0, n - 1)]
+    res = {"what": "Schnorr D512, %d x %d-byte messages per GPU, host-buffer C ABI (PCIe inclusive), constant-address lookups for the "
+                   "secret scalars (the default)" % (n, msg_len),
+           "keypair_per_s": cx.world * n / tk, "sign_per_s": cx.world * n / ts, "verify_per_s": cx.world * n / tv,
+           "first_call_per_s": {"keypair": n / tk0, "sign": n / ts0, "verify": n / tv0},
+           "all_verified": all_ok, "one_flipped_byte_fails_alone": bad == [f]}
+    return res, sample
+
+
+def check_config_samples(samples):
+    """cpu_baseline's leg: the sampled inputs / outputs of the config legs against the oracle (bit-exact)"""
+    from oracle import oracle as O
+
+    out = {}
+    if samples.get(2):
+        for key, got in samples[2]:
+            assert O.kmac_xof(key, b"", 8192, b"SKE", 512) == got, "config 2 sample"
+        out["2"] = "%d units equal the oracle's kmac_xof" % len(samples[2])
+    if samples.get(3):
+        pw, z, plain, ct, tag = samples[3]
+        assert O.sha3_encrypt(pw, z, plain, 512) == (ct, tag), "config 3 sample"
+        out["3"] = "message 0 (ciphertext + tag) equals the oracle's sha3_encrypt"
+    if samples.get(5):
+        for pw, msg, pub, h, z in samples[5]:
+            assert O.keypair_pub(pw, 512) == pub and O.sign(pw, msg, 512) == (h, z), "config 5 sample"
+        out["5"] = "%d key pairs and signatures equal the oracle's" % len(samples[5])
+    return out
+
+
 def crossover(a):
     """Where a caller that holds n items should switch from the reference's own CPU path to the batched GPU call: the
     host-buffer entry points (PCIe included: what the Rust shim calls) timed per CALL for small n, the CPU port of the
@@ -286,10 +492,31 @@ def crossover(a):
     O.select_keccak(False)
 
 
+def self_launch(a):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start torch.distributed.run with N ranks of this very
+    file as a CHILD process -- before this process has imported torch or touched the GPU (a process that has initialised HIP
+    must not exec, and does not need to) --, relay its output and return its exit code.  Ranks that have to share a device
+    (fewer GPUs than ranks: a rehearsal on a one-GPU box) fall back to gloo for the timing barrier inside the ranks."""
+    import socket
+    import subprocess
+
+    with socket.socket() as so:  # a free port for the rendezvous
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this driver (RCCL needs it)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench] --gpus %d without a launcher: starting %s" % (a.gpus, " ".join(cmd[1:8])), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     a = parse()
     if a.crossover:
         return crossover(a)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a))
     # the first `import torch` on a fresh box pages the image in (minutes on a bad day): heartbeat on stderr
     import threading
 
@@ -312,14 +539,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus != world and world == 1 and a.gpus > 1:
-        print("bench.py: --gpus %d needs torch.distributed.run with %d ranks" % (a.gpus, a.gpus), file=sys.stderr)
-        sys.exit(2)
     ndev = torch.cuda.device_count()
-    dev_index = local_rank % max(1, ndev)  # == local_rank on a real N-GPU node; lets 2 ranks share 1 GPU in rehearsals
+    if ndev == 0:
+        print("bench.py: no GPU visible", file=sys.stderr)
+        sys.exit(3)
+    dev_index = local_rank % ndev  # == local_rank on a real N-GPU node; lets several ranks share one GPU in rehearsals
+    share = (world + ndev - 1) // ndev  # ranks per device: 1 on a real node
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    backend = os.environ.get("CAPY_BENCH_BACKEND", "nccl")  # "gloo" only for single-GPU rehearsals of the N>1 path
+    # RCCL cannot put two ranks on one device: a rehearsal with fewer GPUs than ranks takes gloo for the timing barrier
+    backend = os.environ.get("CAPY_BENCH_BACKEND", "nccl" if share == 1 else "gloo")
     # CAPY_BENCH_FORCE_DIST=1: run the process-group code path (init, barrier, max-reduce) with a single rank too --
     # the only way to exercise the RCCL calls of the N > 1 path on a one-GPU box (two ranks cannot share a device)
     use_dist = world > 1 or os.environ.get("CAPY_BENCH_FORCE_DIST") == "1"
@@ -344,7 +573,10 @@ def main():
     # ---- synthetic inputs resident in HBM
     B = a.batch
     free, _total = torch.cuda.mem_get_info()
-    fit = int((free - (6 << 30)) // MSG_STRIDE)  # leave room for the Ed448 leg (1.4 GB with its table scratch) and torch itself
+    # leave room for the Ed448 leg (1.4 GB with its table scratch) and torch itself; ranks that share a device share its memory
+    fit = int((free // share - (6 << 30)) // MSG_STRIDE)
+    if share > 1:
+        fit = min(fit, 2048)  # a rehearsal: several ranks on one card run one after the other anyway
     if B > fit:
         B = max(64, fit // 64 * 64)
     _lib.check(lib.capy_set_sponge_lanes(a.lanes))
@@ -489,6 +721,31 @@ def main():
             ed_sample = (sc[:56 * 4].cpu().numpy().tobytes(), pts[:112 * 4].cpu().numpy().tobytes(),
                          out[:112 * 4].cpu().numpy().tobytes())
 
+    # ---- secondary: BASELINE configs 2, 3 (as specified + saturating) and 5, every rank its share, max over the ranks
+    cfg_res, cfg_samples = {}, {}
+    if not a.no_configs:
+        del msgs, digests  # the headline batch fills the HBM: the config legs need their own buffers
+        torch.cuda.empty_cache()
+
+        def reduce_max(x):
+            if not use_dist:
+                return x
+            t = torch.tensor([x], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+
+        cx = Ctx(lib, _lib, torch, dev, stream, world, rank, barrier, reduce_max)
+        t_cfg = time.perf_counter()
+        if share > 1:  # rehearsal: ranks share one card
+            cfg_res["2"], cfg_samples[2] = config2(cx, n=1 << 16, reps=5)
+            cfg_res["3"], cfg_samples[3] = config3(cx, specified_total=8 * world, saturating=((4096, 1 << 16),))
+            cfg_res["5"], cfg_samples[5] = config5(cx, n=1 << 12)
+        else:
+            cfg_res["2"], cfg_samples[2] = config2(cx)
+            cfg_res["3"], cfg_samples[3] = config3(cx)
+            cfg_res["5"], cfg_samples[5] = config5(cx)
+        cfg_res["seconds_spent"] = time.perf_counter() - t_cfg
+
     # which kernel the library picked for this shape (one launch per step, or P phase launches of the mixed kernel)
     kind, phases = C.c_int(0), C.c_int(1)
     _lib.check(lib.capy_sha3_launch_plan(256, B, MSG_BYTES, MSG_STRIDE, C.byref(kind), C.byref(phases)))
@@ -567,7 +824,10 @@ def main():
                        "batch_per_gpu": B, "msg_bytes": MSG_BYTES, "msg_stride": MSG_STRIDE,
                        "parallelism": "batch-sharded x%d, no collective" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "frac_note": "the nominal bound of a hash (SURVEY 8d); what binds is integer VALU issue: read frac beside "
+                                      "binding_resource / frac_of_one_wave_ceiling below",
+                         "traffic": traffic,
                          "traffic_note": ("bytes per launch from profiles/%s (rocprofv3 PMC on this build of the kernels: "
                                           "FETCH_SIZE x2 = TCC_EA0_RDREQ x 128 B, all requests are 128-B; + WRITE_SIZE)"
                                           % pm_file) if traffic is not None else
@@ -615,8 +875,17 @@ def main():
                                   "peak_note": "1024 SIMDs x clock / 4 cycles per instruction (the issue rate of a stream of 4-cycle "
                                                "instructions; 21 % of this one are simple instructions that can pair, so 1.0 is not a bound)",
                                   "source": "profiles/%s" % pm_file}
+        if cfg_res:
+            if valu_live:  # config 2 / 3 against the bare paired permutation loop measured in this run
+                bare = valu_live * 1e9 / 136.0  # permutations/s
+                cfg_res["2"]["frac_of_paired_loop"] = cfg_res["2"]["device_permutations_per_s"] / world / bare
+                for e in cfg_res["3"]["saturating"]:
+                    e["frac_of_paired_loop"] = e["device_permutations_per_s"] / world / bare
+            res["configs"] = cfg_res
         if not a.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(a.cpu_seconds)
+            if cfg_samples:
+                res["configs"]["oracle_spot_checks"] = check_config_samples(cfg_samples)
             if ed:
                 res["ed448"]["cpu_port_scalar_mults_per_s_1thread"] = cpu_baseline_ed448(min(5.0, a.cpu_seconds), ed_sample)
         print(json.dumps(res), flush=True)

@@ -22,6 +22,7 @@ CAPY_ERR_HIP = -3
 CAPY_ERR_UNSUPPORTED = -4
 CAPY_HARDEN_OFF, CAPY_HARDEN_ALL, CAPY_HARDEN_PROTOCOL = 0, 1, 4
 CAPY_OPT_DEFAULT = -1
+CAPY_ABI_VERSION = 5  # include/capyhip.h: the ABI this binding is written against
 
 
 class CallOptions(C.Structure):
@@ -37,6 +38,9 @@ class CallOptions(C.Structure):
 SIGNATURES = {
     "capy_last_error": (C.c_char_p, []),
     "capy_version": (C.c_char_p, []),
+    "capy_abi_version": (C.c_int, []),
+    "capy_set_min_items_per_device": (C.c_int, [sz]),
+    "capy_debug_affinity_plan": (C.c_int, [C.c_char_p, vp, C.c_int, vp, C.c_int]),
     "capy_device_count": (C.c_int, []),
     "capy_set_device": (C.c_int, [C.c_int]),
     "capy_set_devices": (C.c_int, [vp, C.c_int]),
@@ -155,6 +159,14 @@ def lib():
             )
         _share_hip_runtime_with_torch()
         l = C.CDLL(LIB_PATH)
+        # ABI identity first: an older library lacks entry points or gives arguments another meaning (capyhip.h lists the history)
+        try:
+            l.capy_abi_version.restype = C.c_int
+            have = l.capy_abi_version()
+        except AttributeError:
+            have = 0  # r01 .. r04 libraries have no capy_abi_version
+        if have < CAPY_ABI_VERSION:
+            raise ImportError("%s has ABI version %d, this binding needs >= %d: rebuild the library" % (LIB_PATH, have, CAPY_ABI_VERSION))
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)  # AttributeError if the library does not export a declared symbol
             fn.restype = res

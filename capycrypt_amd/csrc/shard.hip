@@ -85,6 +85,9 @@ int parse_call_options(const capy_call_options *opt, CallOpts &out)
 
 static std::mutex g_dev_mu;
 static std::vector<int> g_dev_ids;  // empty: not configured
+// capy_set_min_items_per_device: a sharded call uses only as many of the listed devices as leave each at least this many
+// items (1 = every device that gets an item).  Latency-bound batches gain nothing from a finer cut: INTEGRATION.md section 5.
+static std::atomic<size_t> g_min_items_per_device{1};
 // a worker of run_sharded never shards again (its body is the single-device form of the same entry point)
 static thread_local bool g_in_shard = false;
 
@@ -114,6 +117,18 @@ static std::vector<size_t> shard_bounds(size_t n, size_t world, const uint64_t *
         while (i < n && (long double)(off[i] - off[0]) + (long double)(off[i + 1] - off[i]) / 2 <= target) i++;
         b[r] = i;
     }
+    return b;
+}
+
+// the cut of a sharded call: the minimum-shard rule first (only the first `used` devices of the list take part; the others
+// get empty shards), then the byte- or count-balanced cut over those
+static std::vector<size_t> shard_bounds_ruled(size_t n, size_t world, const uint64_t *off)
+{
+    const size_t min_items = g_min_items_per_device.load();
+    if (min_items <= 1) return shard_bounds(n, world, off);  // the default: the plain cut over the whole list
+    const size_t used = std::max<size_t>(1, std::min(world, n / min_items));
+    std::vector<size_t> b = shard_bounds(n, used, off);
+    b.resize(world + 1, n);
     return b;
 }
 
@@ -149,6 +164,15 @@ static bool parse_cpulist(const char *text, cpu_set_t *set)
     }
     return any > 0;
 }
+// The CPUs a worker pins itself to: the device's local_cpulist intersected with the CPUs this process may use (never leave
+// the container's set); false = leave the affinity alone (unparsable list, or an empty intersection)
+static bool affinity_intersection(const char *local_cpulist, const cpu_set_t &have, cpu_set_t *both)
+{
+    cpu_set_t want;
+    if (!parse_cpulist(local_cpulist, &want)) return false;
+    CPU_AND(both, &want, &have);
+    return CPU_COUNT(both) > 0;
+}
 static void pin_to_device_cpus(int device)
 {
     if (debug_knob("worker_affinity", 1) == 0) return;
@@ -164,11 +188,28 @@ static void pin_to_device_cpus(int device)
     char line[4096] = {0};
     const bool ok = fgets(line, sizeof line, f) != nullptr;
     fclose(f);
-    cpu_set_t want, have, both;
-    if (!ok || !parse_cpulist(line, &want) || sched_getaffinity(0, sizeof have, &have) != 0) return;
-    CPU_AND(&both, &want, &have);  // never leave the CPUs this process may use (containers)
-    if (CPU_COUNT(&both) > 0) (void)sched_setaffinity(0, sizeof both, &both);
+    cpu_set_t have, both;
+    if (!ok || sched_getaffinity(0, sizeof have, &have) != 0) return;
+    if (affinity_intersection(line, have, &both)) (void)sched_setaffinity(0, sizeof both, &both);
 }
+}  // namespace
+// test hook (capy_debug_affinity_plan): the same arithmetic on a caller-supplied sysfs string and allowed-CPU list
+int affinity_plan(const char *local_cpulist, const int *allowed, int n_allowed, int *out, int capacity)
+{
+    cpu_set_t have, both;
+    CPU_ZERO(&have);
+    for (int i = 0; i < n_allowed; i++)
+        if (allowed[i] >= 0 && allowed[i] < CPU_SETSIZE) CPU_SET(allowed[i], &have);
+    if (!affinity_intersection(local_cpulist, have, &both)) return 0;
+    int k = 0;
+    for (int c = 0; c < CPU_SETSIZE; c++)
+        if (CPU_ISSET(c, &both)) {
+            if (k < capacity) out[k] = c;
+            k++;
+        }
+    return k;
+}
+namespace {
 
 // completion flag of one submitted job; shared with the submitting thread, so it outlives a worker that is replaced
 struct Latch {
@@ -283,7 +324,7 @@ int run_sharded(const std::vector<int> &ids, size_t n, const uint64_t *byte_offs
         if (cur >= 0 && cur != ids[0]) (void)hipSetDevice(cur);
         return rc;
     }
-    const std::vector<size_t> b = shard_bounds(n, world, byte_offsets);
+    const std::vector<size_t> b = shard_bounds_ruled(n, world, byte_offsets);
     std::vector<int> rcs(world, CAPY_OK);
     std::vector<std::string> errs(world);
     std::vector<std::shared_ptr<Latch>> latches;
@@ -322,7 +363,21 @@ using namespace capy;
 extern "C" {
 
 const char *capy_last_error(void) { return capy::g_err.c_str(); }
-const char *capy_version(void) { return "capyhip 0.3 (gfx950)"; }
+const char *capy_version(void) { return "capyhip 0.5 (gfx950)"; }
+int capy_abi_version(void) { return CAPY_ABI_VERSION; }
+
+int capy_set_min_items_per_device(size_t n)
+{
+    capy::g_min_items_per_device.store(n ? n : 1);
+    return CAPY_OK;
+}
+
+int capy_debug_affinity_plan(const char *local_cpulist, const int *allowed_cpus, int n_allowed, int *out_cpus, int capacity)
+{
+    if (!local_cpulist || (!allowed_cpus && n_allowed) || (!out_cpus && capacity) || n_allowed < 0 || capacity < 0)
+        return capy::fail(CAPY_ERR_ARG, "null or invalid argument");
+    return capy::affinity_plan(local_cpulist, allowed_cpus, n_allowed, out_cpus, capacity);
+}
 
 int capy_device_count(void)
 {
@@ -358,7 +413,7 @@ int capy_set_devices(const int *ids, int n)
 int capy_shard_plan(size_t n, int n_devices, const uint64_t *byte_offsets, uint64_t *bounds)
 {
     if (n_devices < 1 || !bounds) return fail(CAPY_ERR_ARG, "bad shard plan request");
-    const std::vector<size_t> b = shard_bounds(n, (size_t)n_devices, byte_offsets);
+    const std::vector<size_t> b = shard_bounds_ruled(n, (size_t)n_devices, byte_offsets);
     for (int r = 0; r <= n_devices; r++) bounds[r] = b[r];
     return CAPY_OK;
 }

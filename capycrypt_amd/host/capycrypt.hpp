@@ -57,8 +57,17 @@ inline const capy_call_options *&opts_slot()
     return p;
 }
 inline const capy_call_options *opts() { return opts_slot(); }
+// ABI identity (include/capyhip.h: CAPY_ABI_VERSION): the library found at run time must be at least the one this header was
+// compiled against (a library older than r05 does not export capy_abi_version at all and fails to load: just as loud)
+inline void check_abi()
+{
+    static const int have = capy_abi_version();
+    if (have < CAPY_ABI_VERSION)
+        throw std::runtime_error("libcapyhip: ABI version " + std::to_string(have) + " < " + std::to_string(CAPY_ABI_VERSION) + " (" + capy_version() + ")");
+}
 inline void check(int rc)
 {
+    check_abi();
     if (rc == CAPY_ERR_UNSUPPORTED_SECPARAM) throw OperationError("UnsupportedSecurityParameter");
     if (rc != CAPY_OK) throw std::runtime_error(std::string("libcapyhip: ") + capy_last_error());
 }

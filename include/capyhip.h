@@ -82,6 +82,18 @@ typedef struct capy_call_options {
 } capy_call_options;
 #define CAPY_CALL_OPTIONS_INIT {(uint32_t)sizeof(capy_call_options), CAPY_OPT_DEFAULT, CAPY_OPT_DEFAULT, 0, NULL}
 
+/* ABI identity.  CAPY_ABI_VERSION is a monotonic integer, raised whenever an entry point is added or the meaning of an
+ * argument changes; a binding compares capy_abi_version() of the library it loaded with the CAPY_ABI_VERSION it was
+ * written against (refuse an older library, accept a newer one) -- capy_version() is for
+ * humans.  History:
+ *   1  r01: sponge + Ed448 batch entry points               2  r02: per-item key lengths (key_offsets), capy_set_devices,
+ *                                                               capy_ed448_validate_batch, one-item-per-wave families
+ *   3  r03: capy_ed448_set_hardened / _set_scalar_star / _set_generator, KEM sponge half, key_encrypt / key_decrypt
+ *   4  r04: capy_call_options and the *_ex entry points, generator handles, five further *_dev forms;
+ *           capy_ed448_set_hardened values 2 and 3 refused (1 = every multiplication again, 4 = the protocol default)
+ *   5  r05: capy_abi_version, capy_set_min_items_per_device, capy_debug_last_sponge_kernel, capy_debug_affinity_plan */
+#define CAPY_ABI_VERSION 5
+int capy_abi_version(void);
 const char *capy_last_error(void);
 const char *capy_version(void);
 int capy_device_count(void);
@@ -99,6 +111,12 @@ int capy_set_device(int device); /* device used by the calling thread's subseque
  * capy_get_devices writes at most `capacity` ids and returns the length of the configured list. */
 int capy_set_devices(const int *ids, int n);
 int capy_get_devices(int *ids, int capacity);
+/* The minimum-shard rule: a sharded call uses only as many of the listed devices (the first ones) as leave each at least
+ * `n` items; default 1.  Small batches are latency-bound -- one device runs 1024 messages of 5 MiB through sha3_encrypt in
+ * 1.4 x the time it needs for 128, and 32 768 Ed448 multiplications in 0.19 x the time of 262 144 -- so cutting them finer
+ * buys nothing and costs a PCIe hop per device; INTEGRATION.md section 5 lists the batch sizes per operation from which a
+ * second device pays.  Process-wide; n = 0 restores the default. */
+int capy_set_min_items_per_device(size_t n);
 /* The cut capy_set_devices uses: bounds[r] .. bounds[r+1] is the item range of device r of n_devices (bounds has
  * n_devices + 1 entries).  byte_offsets = the n+1 message offsets of the call (balance by bytes: an item goes to the
  * shard its midpoint falls in), or NULL (balance by count).  Pure host arithmetic. */
@@ -121,6 +139,12 @@ int capy_debug_last_curve_kernel(int *variable_base, int *fixed_base);
  * per sponge (two lanes per item), 24 the same in time slices, 25 the same on the rotating-occupancy schedule, 26 two passes;
  * 0 = none yet.  Lets the tests assert that the path they mean to cover is the one that ran. */
 int capy_debug_last_sponge_kernel(int *kind, int *launches);
+/* Test hook for the CPU pinning of the per-device workers (pure host arithmetic, no GPU needed): parses `local_cpulist`
+ * (the text of /sys/bus/pci/devices/<bdf>/local_cpulist, e.g. "0-15,128-143\n"), intersects it with the n_allowed CPU
+ * numbers in allowed_cpus (the process's affinity mask) and writes the result, ascending, to out_cpus (at most `capacity`
+ * of them).  Returns the size of the intersection; 0 = the worker would leave its affinity alone (unparsable list, or no
+ * common CPU).  <0 = CAPY_ERR_ARG. */
+int capy_debug_affinity_plan(const char *local_cpulist, const int *allowed_cpus, int n_allowed, int *out_cpus, int capacity);
 
 /* ------------------------------------------------------------------ sponge (src/sha3) */
 

@@ -33,7 +33,7 @@ def _batch(rng, n):
     return msgs
 
 
-@pytest.mark.parametrize("ids", [[0, 0], [0, 0, 0], [0]])
+@pytest.mark.parametrize("ids", [[0, 0], [0, 0, 0], [0], [0] * 8])
 def test_sharded_calls_equal_the_single_device_call(devices, ids):
     from capycrypt_amd import ops
 

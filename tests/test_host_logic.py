@@ -423,3 +423,92 @@ def test_bench_helpers_on_the_cpu():
             import warnings
 
             warnings.warn("%s was taken on other kernel sources: re-run tools/refresh_profiles.sh" % os.path.basename(newest))
+
+
+def test_worker_cpu_pinning_arithmetic_on_fake_sysfs_strings():
+    """csrc/shard.hip: parse_cpulist + the intersection with the process's affinity mask that every per-device worker applies
+    (pin_to_device_cpus) -- on a one-GPU box everything is one NUMA node, so without this hook the first execution of the
+    logic on a real topology would be the first 8-GPU run.  capy_debug_affinity_plan is pure host arithmetic."""
+    import ctypes as C
+
+    from capycrypt_amd import _lib
+
+    lib = _lib.lib()
+
+    def plan(text, allowed, capacity=64):
+        out = (C.c_int * max(1, capacity))()
+        arr = (C.c_int * max(1, len(allowed)))(*allowed)
+        k = lib.capy_debug_affinity_plan(text, arr, len(allowed), out, capacity)
+        return k, list(out[:min(k, capacity)]) if k > 0 else []
+
+    # the shape of a dual-socket EPYC host: the device hangs off socket 0 (first SMT halves 0-15, second 128-143)
+    assert plan(b"0-15,128-143\n", list(range(256))) == (32, list(range(16)) + list(range(128, 144)))
+    # the container's share is narrower than the node: never leave it
+    assert plan(b"0-15,128-143\n", [4, 5, 6, 7, 130, 200, 201]) == (5, [4, 5, 6, 7, 130])
+    # single CPUs, spaces, no newline
+    assert plan(b"3, 9,11", [0, 3, 9, 10, 11]) == (3, [3, 9, 11])
+    # a device on the OTHER socket: no common CPU -> the worker keeps the affinity it has
+    assert plan(b"64-127,192-255", list(range(0, 16))) == (0, [])
+    # unparsable or empty lists leave the affinity alone
+    for bad in (b"", b"\n", b"abc", b"-3", b"4-", b"4-x"):
+        assert plan(bad, list(range(8)))[0] == 0, bad
+    # more CPUs than the caller has room for: the full count comes back, the array holds the first `capacity`
+    assert plan(b"0-63", list(range(64)), capacity=4) == (64, [0, 1, 2, 3])
+    # CPU numbers beyond CPU_SETSIZE (1024) are ignored, not wrapped
+    assert plan(b"1020-1030", [1022, 1023, 1024, 1029]) == (2, [1022, 1023])
+    assert lib.capy_debug_affinity_plan(None, None, 0, None, 0) == _lib.CAPY_ERR_ARG
+
+
+def test_abi_identity_and_minimum_shard_rule():
+    """capy_abi_version() is the integer of include/capyhip.h; the Python binding refuses an older library; the minimum-shard
+    rule of capy_set_min_items_per_device shows in capy_shard_plan (the cut the sharded calls really use)."""
+    import ctypes as C
+    import re
+
+    from capycrypt_amd import _lib
+
+    lib = _lib.lib()
+    hdr = open(os.path.join(ROOT, "include", "capyhip.h")).read()
+    want = int(re.search(r"#define CAPY_ABI_VERSION (\d+)", hdr).group(1))
+    assert lib.capy_abi_version() == want == _lib.CAPY_ABI_VERSION
+    assert b"capyhip 0.%d" % want in lib.capy_version()
+    out = (C.c_uint64 * 9)()
+    try:
+        _lib.check(lib.capy_set_min_items_per_device(1000))
+        _lib.check(lib.capy_shard_plan(3500, 8, None, out))  # 3500 items, at least 1000 each: three devices take part
+        assert list(out) == [0, 1167, 2334, 3500, 3500, 3500, 3500, 3500, 3500]
+        _lib.check(lib.capy_shard_plan(999, 8, None, out))  # fewer than the minimum: one device takes everything
+        assert list(out) == [0] + [999] * 8
+        _lib.check(lib.capy_shard_plan(8000, 8, None, out))
+        assert list(out) == [1000 * i for i in range(9)]
+    finally:
+        _lib.check(lib.capy_set_min_items_per_device(0))
+    _lib.check(lib.capy_shard_plan(10, 8, None, out))
+    assert list(out) == [0, 2, 4, 5, 6, 7, 8, 9, 10]  # the default: every device that can get an item
+
+
+def test_bench_launches_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus N` without a launcher starts torch.distributed.run as a child (before torch is imported or a GPU
+    touched) with N ranks of the same file and returns its exit code; with WORLD_SIZE set (the driver's launch) it does not."""
+    import subprocess
+    import sys
+
+    import bench
+
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "3"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and cmd[cmd.index("--nproc-per-node") + 1] == "8"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and os.path.basename(cmd[-5]) == "bench.py" and cmd[-4:] == ["--gpus", "8", "--steps", "3"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert "torch" not in seen["env"].get("CAPY_TOUCHED", "")  # (nothing of torch is needed to get here)
