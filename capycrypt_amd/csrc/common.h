@@ -130,6 +130,9 @@ void *workspace(hipStream_t stream, WsSlot slot, size_t bytes);  // nullptr on a
 void workspace_release();                                           // free this thread's scratch (synchronises)
 void workspace_scrub(hipStream_t stream, WsSlot slot, size_t bytes);  // zero a slot's first bytes, stream-ordered
 void workspace_scrub_many(hipStream_t stream, const WsSlot *slots, const size_t *bytes, int count);  // the same, one launch
+// nesting of scrub guards on the calling thread (+1 / -1): the outermost guard of a call starts a new record of scrubbed ranges
+// for the test hook capy_debug_secret_scratch_nonzero, inner guards (keyed sponge states of a phase schedule) add to it
+void workspace_scrub_scope(int delta);
 // a slot of the calling thread's scratch as a typed pointer, or return CAPY_ERR_HIP from the enclosing function
 #define CAPY_WS(var, type, stream, slot, bytes)                                      \
     type var = reinterpret_cast<type>(capy::workspace(stream, slot, bytes));          \
@@ -144,7 +147,7 @@ struct WsScrubGuard {
         size_t bytes;
     } items[4];
     int count = 0;
-    explicit WsScrubGuard(hipStream_t s) : stream(s) {}
+    explicit WsScrubGuard(hipStream_t s) : stream(s) { workspace_scrub_scope(+1); }
     WsScrubGuard(const WsScrubGuard &) = delete;
     WsScrubGuard &operator=(const WsScrubGuard &) = delete;
     void add(WsSlot slot, size_t bytes)
@@ -160,6 +163,7 @@ struct WsScrubGuard {
             bytes[i] = items[i].bytes;
         }
         workspace_scrub_many(stream, slots, bytes, count);
+        workspace_scrub_scope(-1);
     }
 };
 

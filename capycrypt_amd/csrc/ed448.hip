@@ -20,8 +20,8 @@ namespace capy {
 #ifndef CAPY_ED448_WAVES
 #define CAPY_ED448_WAVES 2
 #endif
-#ifndef CAPY_ED448_WAVE_MAX_DEFAULT
-#define CAPY_ED448_WAVE_MAX_DEFAULT 8192
+#ifndef CAPY_ED448_WAVE_MAX_PER_SIMD
+#define CAPY_ED448_WAVE_MAX_PER_SIMD 8  // one item per wave up to 8 items per SIMD: 8192 on MI355X
 #endif
 #ifdef CAPY_ED448_NUMVGPR
 __attribute__((amdgpu_num_vgpr(CAPY_ED448_NUMVGPR)))
@@ -435,21 +435,34 @@ __global__ void sc_sign_z_kernel(uint64_t n, const uint8_t *k_be, const uint8_t 
 // ------------------------------------------------------------------ launchers
 static inline dim3 grid64(size_t n) { return dim3((unsigned)((n + 63) / 64)); }
 
+// SIMDs of the current device (4 per compute unit; 1024 on a whole MI355X).  Every batch-size threshold of the kernel-family
+// choice below is a multiple of it -- the families differ in lanes per item, so what matters is items per SIMD -- as in the
+// sponge launcher (sponge_launch.hip: device_simds); on a partitioned device (CPX: 128 SIMDs) or a smaller part the
+// literals of r04 chose every family wrongly by the partition factor.  The CAPY_DEBUG knobs and the
+// capy_ed448_set_* setters stay absolute item counts.
+static size_t dev_simds()
+{
+    static std::atomic<unsigned> cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 1024;
+    unsigned v = cached[dev].load();
+    if (!v) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        v = 4u * (unsigned)cus;
+        cached[dev].store(v);
+    }
+    return v;
+}
+
 // Two items per lane (one shared inversion) once the batch still gives every SIMD two waves at half the wave count:
 // 2 waves x 4 SIMDs x CUs x 128 items = 262 144 on MI355X.  CAPY_DEBUG=ed448_pair=0/1 forces it off / on (A/B).
 static size_t pair_min_items()
 {
-    static const size_t v = [] {
-        const double e = debug_knob("ed448_pair", -1);
-        if (e == 0) return (size_t)-1;
-        if (e == 1) return (size_t)128;
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-            cus = 256;
-        return (size_t)cus * 4 * 2 * 128;
-    }();
-    return v;
+    static const double e = debug_knob("ed448_pair", -1);
+    if (e == 0) return (size_t)-1;
+    if (e == 1) return (size_t)128;
+    return dev_simds() * 2 * 128;
 }
 
 // Constant-address table lookups (capy_ed448_set_hardened / capy_call_options::hardened): table reads that do not depend
@@ -491,7 +504,7 @@ static size_t wave_max_items()
     const long forced = g_wave_max.load();
     if (forced >= 0) return (size_t)forced;
     static const long env = (long)debug_knob("ed448_wave_max", -1);
-    return env >= 0 ? (size_t)env : (size_t)CAPY_ED448_WAVE_MAX_DEFAULT;
+    return env >= 0 ? (size_t)env : (size_t)CAPY_ED448_WAVE_MAX_PER_SIMD * dev_simds();
 }
 
 // Four lanes per item (ed448_quad.h) for quad_min < n <= quad_max public-scalar multiplications: below, a wave per item is
@@ -502,15 +515,15 @@ static size_t quad_min_items()
 {
     const long f = g_quad_min.load();
     if (f >= 0) return (size_t)f;
-    static const long v = (long)debug_knob("ed448_quad_min", 4096);
-    return (size_t)(v < 0 ? 0 : v);
+    static const long v = (long)debug_knob("ed448_quad_min", -1);
+    return v >= 0 ? (size_t)v : 4 * dev_simds();  // 4096
 }
 static size_t quad_max_items()
 {
     const long f = g_quad_max.load();
     if (f >= 0) return (size_t)f;
-    static const long v = (long)debug_knob("ed448_quad_max", 32768);
-    return (size_t)(v < 0 ? 0 : v);
+    static const long v = (long)debug_knob("ed448_quad_max", -1);
+    return v >= 0 ? (size_t)v : 32 * dev_simds();  // 32 768
 }
 
 // Two lanes per item (ed448_duo.h) for duo_min < n <= duo_max public-scalar multiplications (checked before the quad range):
@@ -520,23 +533,23 @@ static size_t duo_min_items()
 {
     const long f = g_duo_min.load();
     if (f >= 0) return (size_t)f;
-    static const long v = (long)debug_knob("ed448_duo_min", 16384);
-    return (size_t)(v < 0 ? 0 : v);
+    static const long v = (long)debug_knob("ed448_duo_min", -1);
+    return v >= 0 ? (size_t)v : 16 * dev_simds();  // 16 384
 }
 static size_t duo_max_items()
 {
     const long f = g_duo_max.load();
     if (f >= 0) return (size_t)f;
-    static const long v = (long)debug_knob("ed448_duo_max", 32768);
-    return (size_t)(v < 0 ? 0 : v);
+    static const long v = (long)debug_knob("ed448_duo_max", -1);
+    return v >= 0 ? (size_t)v : 32 * dev_simds();  // 32 768
 }
 // the constant-address quad kernel (secret scalars): quad_min < n <= this.  One round of waves up to 16 384 items (LDS: four
 // waves per compute unit); beyond, a second round -- still ahead of the one-item-per-lane hardened kernel up to 32 768.
 static size_t quad_ct_max_items()
 {
     if (g_quad_max.load() >= 0) return (size_t)g_quad_max.load();  // capy_ed448_set_quad_range moves both
-    static const long v = (long)debug_knob("ed448_quad_ct_max", 32768);
-    return (size_t)(v < 0 ? 0 : v);
+    static const long v = (long)debug_knob("ed448_quad_ct_max", -1);
+    return v >= 0 ? (size_t)v : 32 * dev_simds();  // 32 768
 }
 static bool duo_range(size_t n) { return n > duo_min_items() && n <= duo_max_items(); }
 static bool quad_range(size_t n) { return !duo_range(n) && n > quad_min_items() && n <= quad_max_items(); }
@@ -547,14 +560,14 @@ static bool quad_range(size_t n) { return !duo_range(n) && n > quad_min_items() 
 // which takes the kernel family of ITS size (one item per wave, four or two lanes per item: 0.4-1.8 ms), on the same stream.
 // CAPY_DEBUG=ed448_peel=0 switches it off.
 // batches of at most one wave per SIMD in the one-item-per-lane form take the *_1w kernels
-static size_t one_wave_items() { return 65536; }
+static size_t one_wave_items() { return 64 * dev_simds(); }  // 65 536
 static size_t peel_remainder(size_t n)
 {
     static const bool on = debug_knob("ed448_peel", 1) != 0;
-    const size_t quantum = 65536;  // 1024 SIMDs x 64 lanes
+    const size_t quantum = 64 * dev_simds();  // SIMDs x 64 lanes: 65 536
     if (!on || n <= quantum) return 0;
     const size_t x = n % quantum;
-    return x <= 32768 ? x : 0;
+    return x <= quantum / 2 ? x : 0;
 }
 
 // secret: the scalars are key material (see harden())
@@ -862,6 +875,8 @@ static int dsm_launch(size_t n, const uint8_t *a, const uint8_t *b, const uint8_
     const uint32_t *gt = nullptr;
     int rc = ensure_gtab(&gt);
     if (rc) return rc;
+    // the test hook reports the family of the double multiplication's variable-base part like a variable-base launch
+    t_last_vb_kernel = duo_range(n) ? 1 + 64 : (quad_range(n) ? 1 + 32 : (n <= wave_max_items() ? 1 + 16 : 1));
     if (duo_range(n)) {  // two lanes per item (ed448_duo.h)
         const size_t slots = (n + 31) / 32 * 32;
         CAPY_WS(dtab, uint32_t *, s, WS_TABLE, slots * VB_TABLE_DWORDS * 4);

@@ -165,11 +165,14 @@ static void note_kernel(int kind, int launches)
 // waves of a SIMD (r03, profiles/r03_chipfull.txt: 32 768 x 5 MiB 353 -> 451 GiB/s, 49 152 x 4 MiB 405 -> 472, 98 304 x
 // 1 MiB 432 -> 515 against the two-pass form; at 131 072 x 1 MiB the two passes win again, 541 vs 527).
 // CAPY_DEBUG=fused_max=N overrides for A/B.
-static const size_t FUSED_ONE_WAVE_ITEMS = 16384;
-static const size_t FUSED_MAX_ITEMS = [] {
-    const double v = debug_knob("fused_max", 98304);
-    return (size_t)(v > 0 ? v : 98304);
-}();
+static unsigned device_simds();
+static size_t fused_one_wave_items() { return 16 * (size_t)device_simds(); }  // 16 384 on MI355X
+static size_t fused_max_items()
+{
+    static const double v = debug_knob("fused_max", 0);
+    return v > 0 ? (size_t)v : 96 * (size_t)device_simds();  // 98 304
+}
+
 // Kernel choice by batch size relative to the device's SIMD count S (1024 on MI355X; measured crossovers, profiles/):
 //   n <= 32 S        two lanes per sponge, at most one wave per SIMD
 //   32 S < n < 64 S  rotating one-lane / two-lane schedule when eligible (sponge_mixed.h), else one lane
@@ -1133,7 +1136,7 @@ int symmetric_crypt_dev(bool encrypt, int d, size_t n, const uint8_t *keka, size
     // From 35 items per SIMD on: one lane per sponge (sponge_fused1.h), at every larger batch size; below, four lanes per item
     // (sponge_fused.h).  CAPY_DEBUG=fused1_min=N moves the boundary (A/B, tests).
     const bool one_lane = fused_shape && n >= fused1_min_items() && (key_len & 7) == 0 && (((uintptr_t)keka | keka_stride) & 7) == 0;
-    const bool fused_ok = fused_shape && (one_lane || n <= FUSED_MAX_ITEMS);
+    const bool fused_ok = fused_shape && (one_lane || n <= fused_max_items());
     if (fused_ok) {
         FusedParams fp;
         memset(&fp, 0, sizeof fp);
@@ -1167,7 +1170,7 @@ int symmetric_crypt_dev(bool encrypt, int d, size_t n, const uint8_t *keka, size
         fp.tag_len = (uint32_t)tag_len;
         fp.decrypt = encrypt ? 0 : 1;
         fp.staged = (g_debug_flags.load() & 64) ? 1 : 0;  // A/B switch (debug bit 6)
-        fp.paired = (n > FUSED_ONE_WAVE_ITEMS && !fp.staged) ? 1 : 0;
+        fp.paired = (n > fused_one_wave_items() && !fp.staged) ? 1 : 0;
         fp.n = n;
         // One wave per item (sponge_wide.h) while every wave still has most of a SIMD pair's LDS bandwidth to itself:
         // 1.3x per permutation at n = 128, break-even near one wave per SIMD (profiles/r02_wide_lane_probe.txt).

@@ -214,7 +214,26 @@ __global__ __launch_bounds__(256) void scrub_kernel(const ScrubRanges r)
         reinterpret_cast<uint4 *>(p)[q] = uint4{0, 0, 0, 0};
     if (blockIdx.x == 0 && threadIdx.x < (nb & 15)) p[quads * 16 + threadIdx.x] = 0;
 }
-static thread_local ScrubRanges t_last_scrub{};  // what the calling thread's last protocol call scrubbed (test hook)
+// what the calling thread's LAST guarded call scrubbed (capy_debug_secret_scratch_nonzero): a protocol call nests scrub guards
+// (z || pw and ke || ka outside, the keyed sponge states of a phase schedule inside), so the ranges of one outermost scope
+// accumulate -- at most 16, one entry per block; the next outermost guard starts afresh
+static thread_local std::vector<std::pair<uint8_t *, uint64_t>> t_scrubbed;
+static thread_local int t_scrub_depth = 0;
+void workspace_scrub_scope(int delta)
+{
+    if (delta > 0 && t_scrub_depth++ == 0) t_scrubbed.clear();
+    if (delta < 0 && t_scrub_depth > 0) t_scrub_depth--;
+}
+static void note_scrubbed(uint8_t *p, uint64_t nb)
+{
+    for (auto &e : t_scrubbed)
+        if (e.first == p) {
+            e.second = std::max(e.second, nb);
+            return;
+        }
+    if (t_scrubbed.size() >= 16) t_scrubbed.erase(t_scrubbed.begin());
+    t_scrubbed.emplace_back(p, nb);
+}
 void workspace_scrub_many(hipStream_t stream, const WsSlot *slots, const size_t *bytes, int count)
 {
     int dev = 0;
@@ -234,7 +253,7 @@ void workspace_scrub_many(hipStream_t stream, const WsSlot *slots, const size_t 
         }
     }
     if (!k) return;
-    t_last_scrub = r;
+    for (int i = 0; i < k; i++) note_scrubbed(r.ptr[i], r.bytes[i]);
     const unsigned gx = (unsigned)std::min<uint64_t>((most / 16 + 255) / 256 + 1, 4096);
     hipLaunchKernelGGL(scrub_kernel, dim3(gx, (unsigned)k), dim3(256), 0, stream, r);
     if (hipGetLastError() != hipSuccess)  // never leave secrets behind because a launch failed: fall back to memsets
@@ -425,10 +444,9 @@ int capy_debug_secret_scratch_nonzero(void *stream, uint64_t *nonzero_bytes)
     CAPY_REQUIRE(nonzero_bytes != nullptr, "nonzero_bytes");
     CAPY_HIP(hipStreamSynchronize((hipStream_t)stream));
     uint64_t total = 0;
-    for (int k = 0; k < 4; k++) {
-        if (!t_last_scrub.ptr[k] || !t_last_scrub.bytes[k]) continue;
-        std::vector<uint8_t> h(t_last_scrub.bytes[k]);
-        CAPY_HIP(hipMemcpy(h.data(), t_last_scrub.ptr[k], h.size(), hipMemcpyDeviceToHost));
+    for (const auto &e : t_scrubbed) {
+        std::vector<uint8_t> h(e.second);
+        CAPY_HIP(hipMemcpy(h.data(), e.first, h.size(), hipMemcpyDeviceToHost));
         for (uint8_t b : h) total += b != 0;
     }
     *nonzero_bytes = total;

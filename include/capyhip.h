@@ -125,8 +125,9 @@ int capy_device_synchronize(void); /* every configured device, else the current 
 /* Free the calling thread's pooled device scratch on every device (synchronises); also done when the thread ends. */
 int capy_release_workspace(void);
 /* Test hook: how many bytes of the scratch ranges that the calling thread's LAST protocol call declared secret (secret
- * scalars, nonces, shared points, derived keys, z || pw) are non-zero now.  Synchronises `stream`.  Must be 0 once the
- * call has returned and the stream is idle. */
+ * scalars, nonces, shared points, derived keys, z || pw, and the keyed sponge states that the phase / time-slice schedules
+ * carry between launches) are non-zero now.  Synchronises `stream`.  Must be 0 once the call has returned and the stream is
+ * idle. */
 int capy_debug_secret_scratch_nonzero(void *stream, uint64_t *nonzero_bytes);
 /* Test hook: which kernel family the calling thread's last variable-base / fixed-base launch took: 1 indexed lookups,
  * 2 constant-address lookups, + 16 for the one-item-per-wave kernels of small batches; 0 = none yet. */

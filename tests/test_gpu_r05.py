@@ -1,0 +1,163 @@
+"""Round-5 GPU tests outside the fused kernel: kernel-family boundaries as multiples of the SIMD count, the scrub of keyed sponge
+states on the rotating schedules, the seeded soaks as tests, every output of the full-size configs 2 and 5 against a
+second kernel family."""
+import ctypes as C
+import os
+import random
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+
+    from capycrypt_amd import _lib
+    from oracle import oracle
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return _lib, _lib.lib(), oracle, torch
+
+
+def _rand(env, nbytes, seed):
+    _lib, lib, _, torch = env
+    t = torch.empty((nbytes + 7) // 8 * 8, dtype=torch.uint8, device="cuda")
+    _lib.check(lib.capy_fill_random_dev(t.data_ptr(), t.numel(), seed, None))
+    return t
+
+
+def _simds(torch):
+    return 4 * torch.cuda.get_device_properties(0).multi_processor_count
+
+
+def test_ed448_family_boundaries_are_multiples_of_the_simd_count(env):
+    """csrc/ed448.hip (r05, VERDICT r4 item 6 / ADVICE r4): the batch sizes at which the variable-base launcher changes kernel
+    family are 4 S, 16 S, 32 S items for S SIMDs (r04: the literals 4096 / 16 384 / 32 768 of a whole MI355X).  Asserted on the
+    family each call really launched (capy_debug_last_curve_kernel): 17 one item per wave, 33 four lanes per item, 65 two lanes
+    per item, 1 one item per lane; with constant-address lookups 18, 34 (quad, table in LDS), 2.  On the full chip (S = 1024)
+    these are exactly r04's boundaries."""
+    _lib, lib, O, torch = env
+    S = _simds(torch)
+    nmax = 32 * S + 1
+    sc, tsc = _rand(env, nmax * 56, 11), _rand(env, nmax * 56, 12)
+    pts = torch.empty(nmax * 112, dtype=torch.uint8, device="cuda")
+    out = torch.empty(nmax * 112, dtype=torch.uint8, device="cuda")
+    _lib.check(lib.capy_ed448_basemul_batch_dev(nmax, tsc.data_ptr(), pts.data_ptr(), None))
+    fam = C.c_int(0)
+
+    def family(n):
+        _lib.check(lib.capy_ed448_scalarmul_batch_dev(n, sc.data_ptr(), pts.data_ptr(), out.data_ptr(), None))
+        lib.capy_debug_last_curve_kernel(C.byref(fam), None)
+        return fam.value
+
+    try:
+        _lib.check(lib.capy_ed448_set_hardened(_lib.CAPY_HARDEN_OFF))
+        got = {n: family(n) for n in (4 * S, 4 * S + 1, 16 * S, 16 * S + 1, 32 * S, 32 * S + 1)}
+        assert got == {4 * S: 17, 4 * S + 1: 33, 16 * S: 33, 16 * S + 1: 65, 32 * S: 65, 32 * S + 1: 1}, got
+        _lib.check(lib.capy_ed448_set_hardened(_lib.CAPY_HARDEN_ALL))
+        got = {n: family(n) for n in (4 * S, 4 * S + 1, 32 * S, 32 * S + 1)}
+        assert got == {4 * S: 18, 4 * S + 1: 34, 32 * S: 34, 32 * S + 1: 2}, got
+        torch.cuda.synchronize()
+    finally:
+        _lib.check(lib.capy_ed448_set_hardened(_lib.CAPY_HARDEN_PROTOCOL))
+    if S == 1024:  # the whole chip: r04's literals
+        assert (4 * S, 16 * S, 32 * S) == (4096, 16384, 32768)
+
+
+def test_keyed_states_of_the_phase_schedules_are_scrubbed(env):
+    """the rotating-occupancy schedule (64 S < n < 128 S keyed digests of >= 512 blocks) carried KMAC-keyed
+    sponge states -- keyed by the Schnorr secret in sign -- through pooled scratch and never zeroed them; keccak-f is invertible,
+    so a full state plus the known message blocks gives the key back.  Every phase / slice schedule now scrubs through a scope
+    guard.  A keyed KMAC batch in the rot range, then capy_debug_secret_scratch_nonzero == 0 -- and the same after the one-lane
+    fused kernel's schedules."""
+    _lib, lib, O, torch = env
+    S = _simds(torch)
+    n, ln = 70 * S, 136 * 520
+    keys, msgs = _rand(env, n * 32, 21), _rand(env, n * (ln + 8), 22)
+    outs = torch.empty(n * 64, dtype=torch.uint8, device="cuda")
+    _lib.check(lib.capy_kmac_xof_batch_dev(512, n, keys.data_ptr(), 32, 32, None, msgs.data_ptr(), None, ln, ln + 8, 512, b"T", 1, outs.data_ptr(), 64, None))
+    kind, launches = C.c_int(0), C.c_int(0)
+    lib.capy_debug_last_sponge_kernel(C.byref(kind), C.byref(launches))
+    assert kind.value == 8 and launches.value > 2, (kind.value, launches.value)  # the rotating-occupancy schedule did run
+    # item 0 against the oracle: the schedule computes what the reference does
+    assert bytes(outs[:64].cpu().numpy()) == O.kmac_xof(bytes(keys[:32].cpu().numpy()), bytes(msgs[:ln].cpu().numpy()), 512, b"T", 512)
+    nz = C.c_uint64(99)
+    _lib.check(lib.capy_debug_secret_scratch_nonzero(None, C.byref(nz)))
+    assert nz.value == 0
+    del msgs
+    # the fused one-lane kernel on its rotating schedule (states keyed by ke / ka)
+    n = 40 * S
+    m, pws, zs = _rand(env, n * (ln + 8), 23), _rand(env, n * 16, 24), _rand(env, n * 512, 25)
+    tags = torch.empty(n * 64, dtype=torch.uint8, device="cuda")
+    _lib.check(lib.capy_sha3_encrypt_batch_dev(512, n, pws.data_ptr(), 16, None, n * 16, zs.data_ptr(), m.data_ptr(), None, ln, ln + 8, tags.data_ptr(), None))
+    lib.capy_debug_last_sponge_kernel(C.byref(kind), C.byref(launches))
+    assert kind.value == 25
+    _lib.check(lib.capy_debug_secret_scratch_nonzero(None, C.byref(nz)))
+    assert nz.value == 0
+
+
+@pytest.mark.parametrize("tool", ["fuzz_soak.py", "fuzz_soak_dev.py", "fuzz_shapes.py"])
+def test_seeded_differential_soaks(tool):
+    """the randomised differential soaks of tools/ (every host-buffer entry point; the *_dev forms with random
+    alignments / strides / streams and guard bytes; the sponge launcher's automatic kernel choice against a forced one over big
+    random shapes -- the one-lane fused kernel and its schedules included) as tests: 30 s each, fixed seed, so a failure
+    reproduces with `SECONDS=30 SEED=5 python tools/<tool>`.  The tools print one FAIL line per finding and exit non-zero."""
+    env = dict(os.environ, SECONDS="30", SEED="5")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool)], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "failures 0" in r.stdout.splitlines()[-1], r.stdout[-4000:] + r.stderr[-2000:]
+
+
+def test_config2_full_size_every_output_against_a_second_kernel_family(env):
+    """BASELINE config 2 at its full size (2^20 units, 1 GiB of output): every byte of the uniform-framing kernel's output equals
+    the generic one-lane kernel's (bench.config2 compares on the device), three units equal the oracle's."""
+    _lib, lib, O, torch = env
+    import bench
+
+    cx = bench.Ctx(lib, _lib, torch, torch.device("cuda", 0), torch.cuda.current_stream())
+    res, sample = bench.config2(cx, reps=3)
+    assert res["all_outputs_equal_second_kernel_family"] and res["kernel"]["kind"] == 7
+    for key, got in sample:
+        assert O.kmac_xof(key, b"", 8192, b"SKE", 512) == got
+
+
+def test_config5_full_size_every_output_against_a_second_kernel_family(env):
+    """BASELINE config 5 at its full size (2^16 x 1 KiB): every public key, every (h, z) and every verification status agree
+    between the default kernel families (constant-address lookups: the matrix-core fixed base for keypair / sign; the
+    one-item-per-lane double multiplication for verify) and a second family (indexed lookups; the four-lanes-per-item double
+    multiplication) -- all 2^16 items compared, not a sample; two items against the oracle."""
+    _lib, lib, O, torch = env
+    n, ml = 1 << 16, 1024
+    rng = random.Random(0xC5)
+    msgs = C.create_string_buffer(rng.randbytes(n * ml), n * ml)
+    pws = C.create_string_buffer(rng.randbytes(n * 64), n * 64)
+    offs = (C.c_uint64 * (n + 1))(*[i * ml for i in range(n + 1)])
+    fam = C.c_int(0)
+
+    def run():
+        pubs, h, z, st = (C.c_uint8 * (n * 112))(), (C.c_uint8 * (n * 56))(), (C.c_uint8 * (n * 56))(), (C.c_int32 * n)()
+        _lib.check(lib.capy_keypair_batch(512, n, pws, 64, None, pubs))
+        _lib.check(lib.capy_schnorr_sign_batch(512, n, pws, 64, None, msgs, offs, h, z))
+        _lib.check(lib.capy_schnorr_verify_batch(512, n, pubs, msgs, offs, h, z, st))
+        lib.capy_debug_last_curve_kernel(C.byref(fam), None)
+        return bytes(pubs), bytes(h), bytes(z), list(st), fam.value
+
+    first = run()
+    try:
+        _lib.check(lib.capy_ed448_set_hardened(_lib.CAPY_HARDEN_OFF))
+        _lib.check(lib.capy_ed448_set_quad_range(4096, 1 << 17))  # verify's double multiplication: four lanes per item
+        second = run()
+    finally:
+        _lib.check(lib.capy_ed448_set_hardened(_lib.CAPY_HARDEN_PROTOCOL))
+        _lib.check(lib.capy_ed448_set_quad_range(-1, -1))
+    assert first[4] != second[4], (first[4], second[4])  # the verify legs did take different kernel families
+    assert first[:3] == second[:3] and first[3] == second[3] == [0] * n
+    for i in (0, n - 1):
+        pw, m = pws.raw[64 * i:64 * i + 64], msgs.raw[ml * i:ml * (i + 1)]
+        assert O.keypair_pub(pw, 512) == first[0][112 * i:112 * i + 112]
+        assert O.sign(pw, m, 512) == (first[1][56 * i:56 * i + 56], first[2][56 * i:56 * i + 56])
