@@ -141,8 +141,19 @@ int capy_cshake_batch_dev(int d, size_t n, const uint8_t *xs, const uint64_t *of
         // Synchronous (ragged batches read their offsets back to size the copy, and the scratch copy must outlive the
         // launch): crate-internal and unreachable through kmac_xof, so not a path worth a stream-ordered allocator
         hipStream_t s = (hipStream_t)stream;
+        // this corner synchronises (twice for ragged batches): not capturable -- say so instead of breaking the capture
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+            return fail(CAPY_ERR_UNSUPPORTED, "cshake with empty N and S synchronises the stream: not available under stream capture");
+        (void)hipGetLastError();
         const uint64_t w = (1600 - (uint64_t)d) / 8, r1 = (1600 - 2 * (uint64_t)d) / 8;
         DevBuf y, meta;  // meta: n + 1 starts of the copies, then their n lengths
+        // Kernels on the CALLER's stream read y / meta; ~DevBuf only waits for the thread's default stream before the block goes
+        // back to the cache.  Declared after the buffers, so it runs before their destructors on EVERY return path.
+        struct SyncOnExit {
+            hipStream_t s;
+            ~SyncOnExit() { (void)hipStreamSynchronize(s); }
+        } sync_on_exit{s};
         uint64_t ylen = 0, ystride = 0;
         uint8_t sfx;
         MsgView v;
@@ -172,9 +183,7 @@ int capy_cshake_batch_dev(int d, size_t n, const uint8_t *xs, const uint64_t *of
                            offsets ? meta.as<uint64_t>() : nullptr, ystride, xs, offsets, uniform_len,
                            msg_stride ? msg_stride : uniform_len, (uint64_t)n, (uint32_t)w, (uint32_t)r1);
         CAPY_HIP(hipGetLastError());
-        const int rc = cshake_launch(d, n, v, l_bits, fn_name, 0, custom, 0, outs, out_stride, s, true);
-        CAPY_HIP(hipStreamSynchronize(s));  // the scratch copy is released on return
-        return rc;
+        return cshake_launch(d, n, v, l_bits, fn_name, 0, custom, 0, outs, out_stride, s, true);  // (synchronised on exit)
     }
     return cshake_launch(d, n, view_dev(xs, offsets, uniform_len, msg_stride), l_bits, fn_name, fn_len, custom,
                          custom_len, outs, out_stride, (hipStream_t)stream);

@@ -132,6 +132,12 @@ def ed448_scalarmul(scalar_be, p_xy):
     return bytes(out)
 
 
+def ed448_set_generator(xy=None):
+    """The generator of every fixed-base multiplication of the oracle (key pairs, signatures, ECDHIES): a candidate from
+    tests/golden/ed448_generator_candidates.json, or None for the RFC 8032 base point (oracle_ed448.c: oracle_ed448_set_generator)."""
+    lib().oracle_ed448_set_generator(_buf(xy) if xy is not None else None)
+
+
 def ed448_basemul(scalar_be):
     out = (C.c_uint8 * 112)()
     lib().oracle_ed448_basemul(_buf(scalar_be), out)

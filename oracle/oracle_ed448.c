@@ -269,7 +269,18 @@ static const uint8_t G_XY[112] = {
     0x73, 0x73, 0xea, 0x4b, 0x62, 0xc7, 0xc9, 0x56, 0x37, 0x20, 0x76, 0x88, 0x24, 0xbc, 0xb6, 0x6e, 0x71, 0x46,
     0x3f, 0x69};
 
-void oracle_ed448_generator(uint8_t out_xy[112]) { memcpy(out_xy, G_XY, 112); }
+/* The generator every fixed-base multiplication below uses: the RFC 8032 base point (assumption (i) about the absent curve
+ * crate) unless a test installs a candidate (tests/golden/ed448_generator_candidates.json) -- the same
+ * hedge as capy_ed448_set_generator on the product side.  NULL restores the RFC point.  Not thread safe (tests only). */
+static uint8_t g_gen_xy[112];
+static int g_gen_set = 0;
+void oracle_ed448_set_generator(const uint8_t *xy)
+{
+    g_gen_set = xy != NULL;
+    if (xy) memcpy(g_gen_xy, xy, 112);
+}
+static const uint8_t *gen_xy(void) { return g_gen_set ? g_gen_xy : G_XY; }
+void oracle_ed448_generator(uint8_t out_xy[112]) { memcpy(out_xy, gen_xy(), 112); }
 
 void oracle_ed448_scalarmul(const uint8_t scalar_be[56], const uint8_t p_xy[112], uint8_t out_xy[112])
 {
@@ -281,7 +292,7 @@ void oracle_ed448_scalarmul(const uint8_t scalar_be[56], const uint8_t p_xy[112]
 
 void oracle_ed448_basemul(const uint8_t scalar_be[56], uint8_t out_xy[112])
 {
-    oracle_ed448_scalarmul(scalar_be, G_XY, out_xy);
+    oracle_ed448_scalarmul(scalar_be, gen_xy(), out_xy);
 }
 
 void oracle_ed448_add(const uint8_t p_xy[112], const uint8_t q_xy[112], uint8_t out_xy[112])

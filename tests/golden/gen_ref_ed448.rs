@@ -109,6 +109,10 @@ fn main() {
     }
     println!("{}", serde_json::to_string_pretty(&json!({
         "_comment": "emitted by tests/golden/gen_ref_ed448.rs from capycrypt 0.7.5 / tiny_ed448_goldilocks 0.1.8",
+        // FIRST: the crate's generator in affine form.  The consumer compares it with the named candidates of
+        // tests/golden/ed448_generator_candidates.json (the RFC 8032 base point; the point with y = -3 and even x) and runs
+        // every other check under the one that matches -- assumption (i) of DESIGN.md section 2 settled by one field.
+        "generator": point_xy_hex(&ExtendedPoint::generator()),
         "sign": sign, "basemul": basemul, "scalarmul": scalarmul, "ecdh": ecdh, "scalars": scalars,
     })).unwrap());
 }

@@ -527,9 +527,10 @@ def test_time_sliced_fused_encrypt_matches_the_two_pass_form(capy, O):
     rng = random.Random(0x51CE)
     sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     try:
-        # one, two and three waves per SIMD and launch (16 384 < n <= 22 528, 32 768 < n <= 43 008, 49 152 < n <= 61 440)
-        for d, n, ln in ((512, 16400, 136 * 600 + 77), (256, 20003, 168 * 520), (512, 22528, 136 * 1030 + 8), (512, 33000, 136 * 520 + 16),
-                         (384, 50001, 152 * 515)):
+        # four lanes per item in slices of one and two waves per SIMD (16 384 < n <= 22 528, 32 768 < n <= 35 840: kind 22); from
+        # 35 items per SIMD the one-lane-per-sponge kernel on its rotating schedule (kind 25; r04's third slice level is gone)
+        for d, n, ln, want_kind in ((512, 16400, 136 * 600 + 77, 22), (256, 20003, 168 * 520, 22), (512, 22528, 136 * 1030 + 8, 22),
+                                    (512, 33000, 136 * 520 + 16, 22), (384, 50001, 152 * 515, 25)):
             stride = (ln + 7) // 8 * 8 + 8
             pl = 32
             def rand(nbytes, seed):
@@ -546,6 +547,12 @@ def test_time_sliced_fused_encrypt_matches_the_two_pass_form(capy, O):
                                                           tags.data_ptr(), sp))
                 torch.cuda.synchronize()
                 res[name] = (m, tags)
+                if name == "sliced":  # assert the schedule that ran
+                    kind, launches = C.c_int(0), C.c_int(0)
+                    lib.capy_debug_last_sponge_kernel(C.byref(kind), C.byref(launches))
+                    S = 4 * torch.cuda.get_device_properties(0).multi_processor_count
+                    if S == 1024:
+                        assert kind.value == want_kind and launches.value > 1, (n, kind.value, launches.value)
             _lib.check(lib.capy_set_sponge_lanes(0))
             assert torch.equal(res["sliced"][0], res["two-pass"][0]), (d, n, ln)
             assert torch.equal(res["sliced"][1], res["two-pass"][1]), (d, n, ln)
@@ -613,6 +620,14 @@ def test_time_sliced_uniform_digests_match_the_one_lane_kernel(capy, O):
                     _lib.check(lib.capy_sha3_batch_dev(d, n, msgs.data_ptr(), None, ln, stride, o.data_ptr(), sp))
                 torch.cuda.synchronize()
                 outs[name] = o
+                if name == "sliced":  # the sliced path must be the one that ran (9: uniform-framing kernel in time slices)
+                    kind, launches = C.c_int(0), C.c_int(0)
+                    lib.capy_debug_last_sponge_kernel(C.byref(kind), C.byref(launches))
+                    S = 4 * torch.cuda.get_device_properties(0).multi_processor_count
+                    if S == 1024:
+                        assert kind.value == 9 and launches.value > 1, (n, kind.value, launches.value)
+                    elif kind.value != 9:
+                        pytest.skip("batch sizes of this test are sliced on a 1024-SIMD device only (this one: %d SIMDs)" % S)
             _lib.check(lib.capy_set_sponge_lanes(0))
             assert torch.equal(outs["sliced"], outs["one-lane"]), (d, n, ln, keyed)
             row = os_ if keyed else d // 8

@@ -161,3 +161,51 @@ def test_config5_full_size_every_output_against_a_second_kernel_family(env):
         pw, m = pws.raw[64 * i:64 * i + 64], msgs.raw[ml * i:ml * (i + 1)]
         assert O.keypair_pub(pw, 512) == first[0][112 * i:112 * i + 112]
         assert O.sign(pw, m, 512) == (first[1][56 * i:56 * i + 56], first[2][56 * i:56 * i + 56])
+
+
+def test_named_generator_candidate_y_minus_3(env):
+    """VERDICT r4 item 8: assumption (i) about the absent curve crate is that ExtendedPoint::generator() is the RFC 8032 base
+    point.  The reference's lineage (README.md:159) suggests one concrete alternative: the point with y = -3 mod p and even x
+    (tests/golden/ed448_generator_candidates.json, derived by tests/golden/gen_generator_candidates.py).  Through a generator
+    handle every protocol call -- KeyPair::new, sign, verify, key_encrypt, key_decrypt, on the wave-per-item and the
+    lane-per-item kernels, indexed and constant-address tables -- must equal the oracle running under the same generator, so
+    that aligning with the crate, should it use this point, is one call (capy_ed448_set_generator) and not a rebuild."""
+    import json
+
+    _lib, lib, O, torch = env
+    from capycrypt_amd import ops
+
+    with open(os.path.join(ROOT, "tests", "golden", "ed448_generator_candidates.json")) as f:
+        cand = {c["name"]: bytes.fromhex(c["xy_le_hex"]) for c in json.load(f)["candidates"]}
+    assert cand["rfc8032"] == ops.ed448_get_generator() == O.ed448_generator()
+    g = cand["y_minus_3"]
+    assert ops.ed448_validate_batch([g]) == [True]
+    handle = C.c_int(-1)
+    _lib.check(lib.capy_ed448_generator_create(g, C.byref(handle)))
+    rng = random.Random(0x93)
+    try:
+        O.ed448_set_generator(g)
+        assert O.ed448_generator() == g
+        for n in (37, 9001):  # one item per wave; one item per lane / four lanes per item
+            pws = [rng.randbytes(rng.randrange(1, 70)) for _ in range(n)]
+            msgs = [rng.randbytes(rng.randrange(0, 400)) for _ in range(n)]
+            ks = [rng.randbytes(56) for _ in range(n)]
+            check = range(n) if n < 100 else [0, 1, n // 2, n - 1] + [rng.randrange(n) for _ in range(12)]
+            for hardened in (_lib.CAPY_HARDEN_PROTOCOL, _lib.CAPY_HARDEN_OFF):
+                opt = _lib.CallOptions(hardened=hardened, generator=handle.value)
+                pubs = ops.keypair_batch(pws, 512, options=opt)
+                sigs = ops.schnorr_sign_batch(pws, msgs, 512, options=opt)
+                assert all(ops.schnorr_verify_batch(pubs, msgs, sigs, 512, options=opt))
+                cts, zs, tags = ops.key_encrypt_batch(pubs, ks, msgs, 256, options=opt)
+                back, ok = ops.key_decrypt_batch(pws, zs, cts, tags, 256, options=opt)
+                assert all(ok) and back == msgs
+                for i in check:
+                    assert pubs[i] == O.keypair_pub(pws[i], 512), (n, i)
+                    assert sigs[i] == O.sign(pws[i], msgs[i], 512), (n, i)
+                    assert O.verify(pubs[i], msgs[i], 512, *sigs[i])
+                    assert (cts[i], zs[i], tags[i]) == O.key_encrypt(pubs[i], ks[i], msgs[i], 256), (n, i)
+            # under the RFC generator the same signatures do not verify: the two candidates are told apart by one call
+            assert not any(ops.schnorr_verify_batch(pubs[:20], msgs[:20], sigs[:20], 512))
+    finally:
+        O.ed448_set_generator(None)
+    assert O.ed448_generator() == cand["rfc8032"]

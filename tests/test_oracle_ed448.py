@@ -179,6 +179,21 @@ def _check_reference_file(path):
     signatures the file holds."""
     with open(path) as f:
         v = json.load(f)
+    # Which generator the crate uses (assumption (i)): the file's first field against the named candidates; every check below
+    # then runs with that generator installed in the oracle (capy_ed448_set_generator does the same for the library).
+    if "generator" in v:
+        with open(os.path.join(HERE, "golden", "ed448_generator_candidates.json")) as f:
+            cands = {c["xy_le_hex"]: c["name"] for c in json.load(f)["candidates"]}
+        assert v["generator"] in cands, "the crate's generator is neither the RFC 8032 base point nor the y = -3 point: %s" % v["generator"]
+        print("the reference's generator is candidate %r" % cands[v["generator"]])
+        O.ed448_set_generator(H(v["generator"]))
+    try:
+        return _check_reference_vectors(v)
+    finally:
+        O.ed448_set_generator(None)
+
+
+def _check_reference_vectors(v):
     for t in v["sign"]:
         assert O.keypair_pub(H(t["pw"]), t["d"]).hex() == t["pub"]
     for t in v["basemul"]:
@@ -230,13 +245,36 @@ def test_reference_emitted_vectors():
 
 def test_reference_consumer_recognises_every_reading(tmp_path):
     """Dry run of the consumer above: ref_ed448.json as gen_ref_ed448.rs would emit it, simulated with the oracle for each
-    of the three readings of `*` / `-` -- the consumer must accept the file and name the reading that produced it."""
+    of the three readings of `*` / `-` and for both named generator candidates -- the consumer must accept the file, name
+    the reading that produced it, and run under the generator the file declares (a file made under the y = -3 point fails
+    when its `generator` field is dropped, i.e. under the RFC base point)."""
     with open(os.path.join(HERE, "golden", "ed448_vectors.json")) as f:
         doc = json.load(f)
+    with open(os.path.join(HERE, "golden", "ed448_generator_candidates.json")) as f:
+        gens = {c["name"]: c["xy_le_hex"] for c in json.load(f)["candidates"]}
     ks = [t["k"] for t in doc["scalarmul"]][:12]
     n = len(ks)
-    for star in (0, 1, 2):
-        out = {"sign": [], "basemul": [], "scalarmul": [], "ecdh": [], "scalars": []}
+    for star, gname in ((0, "rfc8032"), (1, "rfc8032"), (2, "rfc8032"), (0, "y_minus_3"), (1, "y_minus_3")):
+        out = {"generator": gens[gname], "sign": [], "basemul": [], "scalarmul": [], "ecdh": [], "scalars": []}
+        O.ed448_set_generator(H(gens[gname]))
+        try:
+            _simulate_reference_file(out, doc, ks, n, star)
+        finally:
+            O.ed448_set_generator(None)
+        path = tmp_path / ("ref_%d_%s.json" % (star, gname))
+        path.write_text(json.dumps(out))
+        assert _check_reference_file(str(path)) == star
+        if gname != "rfc8032":
+            del out["generator"]
+            path.write_text(json.dumps(out))
+            import pytest
+
+            with pytest.raises(AssertionError):
+                _check_reference_file(str(path))
+
+
+def _simulate_reference_file(out, doc, ks, n, star):
+    if True:
         O.set_scalar_star(star)
         try:
             for t in doc["sign"][:6]:
@@ -255,9 +293,6 @@ def test_reference_consumer_recognises_every_reading(tmp_path):
             out["scalars"].append({"k": k, "mul_mod_4": E.sc_to_bytes(4 * ki % E.R).hex(),
                                    "star_4": E.sc_to_bytes(4 * ki % (E.R if star == 0 else 2**448)).hex(),
                                    "k_minus_4k": E.sc_to_bytes((ki - 4 * ki) % E.R).hex()})
-        path = tmp_path / ("ref_%d.json" % star)
-        path.write_text(json.dumps(out))
-        assert _check_reference_file(str(path)) == star
 
 
 def test_scalar_star_readings_differ_and_all_verify():
@@ -306,3 +341,43 @@ def test_protocol_roundtrips():
         assert ok and pt == msg
         pt, ok = O.key_decrypt(b"other", zxy, ct, tag, d)  # tests/integration_tests.rs:267-281
         assert not ok and pt == ct
+
+
+def test_generator_candidates_fixture_and_oracle_under_a_candidate():
+    """tests/golden/ed448_generator_candidates.json (gen_generator_candidates.py): both named candidates for the absent crate's
+    ExtendedPoint::generator() -- the RFC 8032 base point and the point with y = -3, x even -- are re-derived here, lie on the
+    curve, have the prime order r; and with a candidate installed (oracle_ed448_set_generator) the C oracle's key pair /
+    signature / ECDHIES flow is the python model's composition over that generator."""
+    import json
+    import random
+
+    from oracle import ed448_ref as E
+    from oracle import oracle as O
+
+    with open(os.path.join(HERE, "golden", "ed448_generator_candidates.json")) as f:
+        cands = {c["name"]: c for c in json.load(f)["candidates"]}
+    assert set(cands) == {"rfc8032", "y_minus_3"}
+    for name, c in cands.items():
+        pt = E.pt_from_bytes(bytes.fromhex(c["xy_le_hex"]))
+        assert pt == (int(c["x_hex_be"], 16), int(c["y_hex_be"], 16))
+        assert E.on_curve(pt) and E.scalarmul(E.R, pt) == E.IDENT and pt != E.IDENT
+    assert E.pt_from_bytes(bytes.fromhex(cands["rfc8032"]["xy_le_hex"])) == E.G
+    x, y = E.pt_from_bytes(bytes.fromhex(cands["y_minus_3"]["xy_le_hex"]))
+    assert y == E.P - 3 and x % 2 == 0 and (x * x + y * y - 1 - E.D * x * x * y * y) % E.P == 0
+    g = bytes.fromhex(cands["y_minus_3"]["xy_le_hex"])
+    rng = random.Random(3)
+    try:
+        O.ed448_set_generator(g)
+        assert O.ed448_generator() == g
+        k = rng.randbytes(56)
+        assert O.ed448_basemul(k) == E.pt_to_bytes(E.scalarmul(E.sc_from_bytes(k), (x, y)))
+        pw, msg = b"password", rng.randbytes(100)
+        pub = O.keypair_pub(pw, 512)
+        h, z = O.sign(pw, msg, 512)
+        assert O.verify(pub, msg, 512, h, z)
+        ct, zxy, tag = O.key_encrypt(pub, rng.randbytes(56), msg, 512)
+        assert O.key_decrypt(pw, zxy, ct, tag, 512) == (msg, True)
+    finally:
+        O.ed448_set_generator(None)
+    assert O.ed448_generator() == E.pt_to_bytes(E.G)
+    assert not O.verify(pub, msg, 512, h, z)  # made under the candidate: does not verify under the RFC point
