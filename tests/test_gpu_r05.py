@@ -196,14 +196,16 @@ def test_named_generator_candidate_y_minus_3(env):
                 pubs = ops.keypair_batch(pws, 512, options=opt)
                 sigs = ops.schnorr_sign_batch(pws, msgs, 512, options=opt)
                 assert all(ops.schnorr_verify_batch(pubs, msgs, sigs, 512, options=opt))
-                cts, zs, tags = ops.key_encrypt_batch(pubs, ks, msgs, 256, options=opt)
+                pubs256 = ops.keypair_batch(pws, 256, options=opt)  # (the key pair's d is the d of key_encrypt / key_decrypt)
+                cts, zs, tags = ops.key_encrypt_batch(pubs256, ks, msgs, 256, options=opt)
                 back, ok = ops.key_decrypt_batch(pws, zs, cts, tags, 256, options=opt)
                 assert all(ok) and back == msgs
                 for i in check:
                     assert pubs[i] == O.keypair_pub(pws[i], 512), (n, i)
                     assert sigs[i] == O.sign(pws[i], msgs[i], 512), (n, i)
                     assert O.verify(pubs[i], msgs[i], 512, *sigs[i])
-                    assert (cts[i], zs[i], tags[i]) == O.key_encrypt(pubs[i], ks[i], msgs[i], 256), (n, i)
+                    assert pubs256[i] == O.keypair_pub(pws[i], 256), (n, i)
+                    assert (cts[i], zs[i], tags[i]) == O.key_encrypt(pubs256[i], ks[i], msgs[i], 256), (n, i)
             # under the RFC generator the same signatures do not verify: the two candidates are told apart by one call
             assert not any(ops.schnorr_verify_batch(pubs[:20], msgs[:20], sigs[:20], 512))
     finally:

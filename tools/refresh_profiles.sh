@@ -4,19 +4,19 @@
 # Writes raw rocprofv3 output under gpurun_out/ and the summaries under profiles/<round>_*.
 # Counter passes are separate runs (rocprofv3 refuses / mis-handles large counter sets; never mix --pmc with traces).
 set -o pipefail
-R=${1:-r04}
+R=${1:-r05}
 export TMPDIR=/tmp
 OUT=gpurun_out
 mkdir -p $OUT profiles
 python bench.py --steps 5 --warmup 1 > $OUT/bench.json 2> $OUT/bench.err && tail -1 $OUT/bench.json > profiles/${R}_bench_line.json
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$R -o bench -- \
-    python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/prof_bench.log 2>&1 \
+    python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-configs > $OUT/prof_bench.log 2>&1 \
     && cp $OUT/prof_$R/bench_kernel_stats.csv profiles/${R}_bench_kernel_stats.csv
 for C in "FETCH_SIZE" "WRITE_SIZE" \
          "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE"; do
     n=$(echo $C | cut -d" " -f1)
     timeout -k 10 300 rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_${R}_$n -o pmc -- \
-        python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/pmc_$n.log 2>&1 || echo "PMC pass $n failed"
+        python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-configs > $OUT/pmc_$n.log 2>&1 || echo "PMC pass $n failed"
 done
 # two more kernels for the summary: the uniform-framing kernel on short messages (2^22 x 64 B) and the wave-per-item
 # sha3_encrypt kernel on BASELINE config 3 as specified (128 x 5 MiB); SQ counters only
