@@ -75,25 +75,25 @@ void tag_compare_launch(const uint8_t *a, uint64_t a_stride, const uint8_t *b, u
                        b_stride, status, (uint64_t)n);
 }
 
-// first batch size that takes the one-lane-per-sponge fused kernel.  From 32 items per SIMD on there is a sponge for every lane
-// of the chip, but just above that size the one-lane form runs mostly lone waves (477 GiB/s against 497-501 for the four-lane
-// form in time slices of two waves per SIMD); measured crossover 35 items per SIMD (profiles/r05_fused_one_lane.txt)
+// first batch size that takes the one-lane-per-sponge fused kernel: from 32 items per SIMD on there is a sponge for every lane of
+// the chip (33 000 x 1 MiB: 513 GiB/s on the rotating schedule against 500 for the four-lane form in time slices,
+// profiles/r05_fused_one_lane.txt)
 static size_t fused1_min_items()
 {
     static const long forced = (long)debug_knob("fused1_min", -1);
-    return forced >= 0 ? (size_t)forced : 35 * (size_t)device_simds() + 1;
+    return forced >= 0 ? (size_t)forced : 32 * (size_t)device_simds() + 1;
 }
 
 // The plan of the rotating-occupancy schedule for the one-lane fused kernel: bundles of 128 items (four waves), C compute units,
 // Cp of them doubled up per phase, P phases, every bundle doubled up in `a` of them (the arithmetic of rot_plan above);
-// nb1 / nb2 = the speed of a lone wave (unrolled plain round) over that of a wave that shares its SIMD (rolled blocked round);
-// swept 1.25 .. 1.6 over 36 864 .. 61 440 x 1 MiB: best at 1.45 (profiles/r05_fused_one_lane.txt); CAPY_DEBUG=fused1_ratio=R for A/B.
-static bool fused1_rot_plan(uint64_t n, uint64_t nf, size_t simds, RotPlan &m)
+// nb1 / nb2 = the speed of a lone wave (unrolled plain round) over that of a wave that shares its SIMD (rolled blocked round),
+// swept over 33 000 .. 61 440 x 1 MiB (profiles/r05_fused_one_lane.txt): 1.45 with the lone role on the line stores, 1.6 with
+// per-lane stores in the lone role (lone_direct: where lone waves dominate the schedule, fused1_launch).
+// CAPY_DEBUG=fused1_ratio=R for A/B.
+static bool fused1_rot_plan(uint64_t n, uint64_t nf, size_t simds, bool lone_direct, RotPlan &m)
 {
-    static const double ratio = [] {
-        const double v = debug_knob("fused1_ratio", 0.0);
-        return (v >= 1.0 && v <= 2.5) ? v : 1.45;
-    }();
+    static const double forced_ratio = debug_knob("fused1_ratio", 0.0);
+    const double ratio = (forced_ratio >= 1.0 && forced_ratio <= 2.5) ? forced_ratio : (lone_direct ? 1.6 : 1.45);
     if (n <= 32 * simds || n >= 64 * simds) return false;
     m.nf = nf;
     m.C = (uint32_t)(simds / 4);
@@ -152,7 +152,12 @@ static int fused1_launch(int rw, FusedParams &fp, const MsgView &m, hipStream_t 
     // CAPY_DEBUG=fused1_rot=0 switches it off.
     static const bool rot_on = debug_knob("fused1_rot", 1) != 0;
     RotPlan rp;
-    if (rot_on && long_uniform && fused1_rot_plan(fp.n, nfull, simds, rp)) {
+    // below 44 items per SIMD most of the blocks are absorbed by lone waves: those store per lane (sponge_fused1.h: lone_direct;
+    // 36 864 / 40 960 x 1 MiB 511 / 533 -> 551 / 562 GiB/s at 1.08-1.16 x the bytes written; from 45 056 items on the two forms
+    // are equal and the line stores keep the traffic at 1.00 x).  CAPY_DEBUG=fused1_lone_direct=0 / 1 forces it (A/B).
+    static const int forced_lone = (int)debug_knob("fused1_lone_direct", -1);
+    fp.lone_direct = forced_lone >= 0 ? (uint32_t)(forced_lone != 0) : (fp.n < 44 * simds ? 1u : 0u);
+    if (rot_on && long_uniform && fused1_rot_plan(fp.n, nfull, simds, fp.lone_direct != 0, rp)) {
         const size_t done_bytes = (groups * 4 + 255) & ~(size_t)255, state_bytes = groups * 50 * 64 * 4;
         WsScrubGuard scrub(s);  // keyed sponge states: zeroed however this returns
         CAPY_WS(slws, uint8_t *, s, WS_STATE, done_bytes + state_bytes);
@@ -273,8 +278,8 @@ int symmetric_crypt_dev(bool encrypt, int d, size_t n, const uint8_t *keka, size
     const Framing ff = cshake_framing(d);
     const bool fused_shape = fused_enabled() && ff.stride == (uint32_t)ff.rw * 8 && m.aligned8 && m.msgs != nullptr &&
                              tag_len <= 64 && (tag_len & 3) == 0;
-    // From 35 items per SIMD on: one lane per sponge (sponge_fused1.h), at every larger batch size; below, four lanes per item
-    // (sponge_fused.h).  CAPY_DEBUG=fused1_min=N moves the boundary (A/B, tests).
+    // More than 32 items per SIMD: one lane per sponge (sponge_fused1.h), at every larger batch size; up to there, four lanes per
+    // item (sponge_fused.h).  CAPY_DEBUG=fused1_min=N moves the boundary (A/B, tests).
     const bool one_lane = fused_shape && n >= fused1_min_items() && (key_len & 7) == 0 && (((uintptr_t)keka | keka_stride) & 7) == 0;
     const bool fused_ok = fused_shape && (one_lane || n <= fused_max_items());
     if (fused_ok) {
@@ -341,13 +346,9 @@ int symmetric_crypt_dev(bool encrypt, int d, size_t n, const uint8_t *keka, size
             const uint64_t nfull = m.offsets ? 0 : m.uniform_len / ((uint64_t)ff.rw * 8);
             const size_t groups = (n + 15) / 16;
             static const bool slices_on = debug_knob("fused_slices", 1) != 0;
-            // level k = waves per SIMD and launch: k = 1 for 16 384 < n <= 22 528, k = 2 for 32 768 < n <= 43 008 (beyond the limit
-            // of a level the single launch with k + 1 waves on some SIMDs is as fast; from 35 840 items on the one-lane-per-sponge
-            // kernel takes the batch, so r04's third level, 49 152 < n <= 61 440, is gone)
-            uint32_t level = 0;
-            static const size_t level_limit[3] = {0, 22, 42};  // items per SIMD up to which level k pays
-            for (uint32_t k = 1; k <= 2; k++)
-                if (groups > k * simds && groups * 16 <= simds * level_limit[k]) level = k;
+            // level 1 = one wave per SIMD and launch, for 16 384 < n <= 22 528 (beyond, the single launch with two waves on some
+            // SIMDs is as fast).  Beyond 32 768 items the one-lane-per-sponge kernel takes the batch: r04's levels 2 and 3 are gone.
+            const uint32_t level = (groups > simds && groups * 16 <= simds * 22) ? 1 : 0;
             if (slices_on && !fp.staged && !fp.wide && !m.offsets && !m.order && level && nfull >= 512 && nfull < 0xfffffff0u) {
                 const uint32_t turns = (uint32_t)std::min<uint64_t>(64, nfull / 64);  // >= 8 turns per group
                 const uint32_t bp = (uint32_t)((nfull + turns - 1) / turns);
@@ -357,7 +358,7 @@ int symmetric_crypt_dev(bool encrypt, int d, size_t n, const uint8_t *keka, size
                 CAPY_WS(slws, uint8_t *, s, WS_STATE, done_bytes + state_bytes);
                 slscrub.add(WS_STATE, done_bytes + state_bytes);
                 CAPY_HIP(hipMemsetAsync(slws, 0xff, done_bytes, s));  // SLICE_FRESH
-                fp.paired = level == 1 ? 0 : level;  // the instance compiled for exactly `level` waves per SIMD
+                fp.paired = 0;  // the instance compiled for exactly one wave per SIMD
                 fp.sl_groups = (uint32_t)groups;
                 fp.sl_grid = (uint32_t)(level * simds);
                 fp.sl_blocks = bp;

@@ -1,4 +1,5 @@
-// sponge_fused.h — sha3_encrypt / sha3_decrypt in ONE pass over the message (small batches).
+// sponge_fused.h — sha3_encrypt / sha3_decrypt in ONE pass over the message, four lanes per item: batches of up to 32 items per SIMD
+// (beyond: one lane per sponge, sponge_fused1.h; up to one item per SIMD: one wave per item, sponge_wide.h).
 //
 // The reference computes, per message (src/sha3/encryptable.rs:39-42 and :71-75),
 //     t = kmac_xof(ka, m, 512, "SKA")          -- absorbs the whole plaintext
@@ -54,7 +55,7 @@ struct FusedParams {
     // instance (0: not this form; 1 lone wave per SIMD, 2 two waves, 4 three or four), A/B switch for per-lane stores
     // instead of whole lines, occupancy cap in waves per SIMD (0: none), and the rotating-occupancy schedule's phase
     // (sponge_fused1.h: fused1_rot_kernel; rot_G == 0: not that schedule)
-    uint32_t one_lane, direct_stores, cap_waves, store_policy;
+    uint32_t one_lane, direct_stores, lone_direct, cap_waves, store_policy;
     uint32_t rot_phase, rot_Cp, rot_G, rot_nb1, rot_nb2;
 };
 constexpr uint32_t SLICE_FRESH = 0xffffffffu, SLICE_FINISHED = 0xfffffffeu;
@@ -73,11 +74,9 @@ __device__ __forceinline__ uint32_t quad_swap_pairs(uint32_t v)
 // STAGED = true: the round-1 form (wave-cooperative 8-byte transfers through LDS, four barriers per block), kept for A/B.
 // PAIRED (r03): the launch puts two or three waves on a SIMD (16 384 < n <= 49 152): the hot loop runs the blocked round
 // with raised priority around its DPP / rotation blocks (sponge_kernels_k2.h: keccak_round_k2_blocked).
-// PAIRED: 0 = one wave per SIMD (and compiled for exactly one); 1 = two or more (the blocked round with priority), as many as
-// fit; 2 / 3 = the same round, compiled for at most two / three waves per SIMD: the time-sliced launches that hold exactly that
-// many (see the launcher)
+// PAIRED: 0 = one wave per SIMD (and compiled for exactly one); 1 = two waves (22 528 < n <= 32 768: the blocked round with priority)
 template <int RW, bool STAGED = false, int PAIRED = 0>
-__global__ __launch_bounds__(64) CAPY_WAVES_PER_SIMD(PAIRED == 0 ? 1 : (PAIRED == 1 ? 8 : PAIRED)) void sponge_fused_crypt_kernel(const FusedParams fp)
+__global__ __launch_bounds__(64) CAPY_WAVES_PER_SIMD(PAIRED == 0 ? 1 : 8) void sponge_fused_crypt_kernel(const FusedParams fp)
 {
     constexpr uint32_t RB = RW * 8;
     constexpr int NIT = 16;                       // items per wave

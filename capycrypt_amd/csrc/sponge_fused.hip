@@ -38,7 +38,6 @@ hipError_t launch_sponge_fused(int rw, const FusedParams &fp, hipStream_t s)
         return hipGetLastError();                                                                                        \
     }
     CAPY_FUSED_PAIRED(1)  // more than one wave per SIMD
-    CAPY_FUSED_PAIRED(2)  // time-sliced launches of exactly two waves per SIMD
 #undef CAPY_FUSED_PAIRED
     switch (rw) {
     case 17: hipLaunchKernelGGL(sponge_fused_crypt_kernel<17>, grid, block, 0, s, fp); break;

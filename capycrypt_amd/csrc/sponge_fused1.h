@@ -97,13 +97,19 @@ __device__ __forceinline__ uint64_t fused1_trailer_word(uint32_t rel, uint32_t l
 // One pass of line stores.  FINAL = false: items whose ring holds a complete line (avail >= 128) write it; FINAL = true: every
 // item writes what it still holds (the last, partial line of its range).  Lane l serves the 16-byte chunk l % 8 of item
 // 8 k + l / 8 for k = 0 .. 3, straight from that item's record.  Returns false (wave-uniform) when no item had anything.
-template <bool FINAL, bool ROLLED>
-__device__ __forceinline__ bool fused1_flush_pass(uint32_t role, uint32_t q, uint32_t lane, fused1_lds_u8 *ring, fused1_lds_u32x4 *home,
-                                                  uint32_t policy)
+// REGS (the instances with registers to spare: FORM 2, 3): the owner lanes keep their record in registers (`mine`) and publish it
+// here; otherwise (FORM 4) it lives in LDS only and `mine` is a scratch copy.
+template <bool FINAL, bool ROLLED, bool REGS>
+__device__ __forceinline__ bool fused1_flush_pass(fused1_u32x4 &mine, uint32_t role, uint32_t q, uint32_t lane, fused1_lds_u8 *ring,
+                                                  fused1_lds_u32x4 *home, uint32_t policy)
 {
-    fused1_u32x4 mine = home[q];
+    if constexpr (!REGS) mine = home[q];
     const bool has = FINAL ? mine.z > mine.w : mine.z >= 128;
     if (__builtin_amdgcn_ballot_w64(has) == 0) return false;
+    if constexpr (REGS) {
+        if (role == 1) home[q] = mine;
+        fused1_wave_sync();
+    }
     const uint32_t c16 = 16 * (lane & 7);
     auto serve = [&](uint32_t k) {
         const uint32_t j = 8 * k + (lane >> 3);
@@ -133,12 +139,14 @@ __device__ __forceinline__ bool fused1_flush_pass(uint32_t role, uint32_t q, uin
         for (uint32_t k = 0; k < 4; k++) serve(k);
     }
     fused1_wave_sync();
-    if (has && role == 1) {
+    if (has) {
         mine.z -= mine.z < 128 ? mine.z : 128;
         mine.w = 0;
-        home[q] = mine;
+        if constexpr (!REGS) {
+            if (role == 1) home[q] = mine;
+        }
     }
-    fused1_wave_sync();
+    if constexpr (!REGS) fused1_wave_sync();
     return true;
 }
 
@@ -254,6 +262,15 @@ __device__ __forceinline__ uint32_t fused1_body(const FusedParams &fp, uint32_t 
             fused1_wave_sync();
         }
         if (t_end > t0) {
+            // fp.lone_direct: FORM 1 (a lone wave per SIMD: the lone role of the rotating schedule) stores per lane instead.  A lone
+            // wave pays every LDS round trip and every instruction of the ring in full (474 against 520 GiB/s,
+            // profiles/r05_fused_one_lane.txt), and at one wave per SIMD most partial lines of a block's two stores still meet in L2
+            // (bytes written 1.08-1.16 x; at two waves per SIMD it is 1.42 x, which is what the ring is for).  The launcher sets it
+            // where lone waves dominate the schedule (below 44 items per SIMD: +5-8 % there, nothing above).
+            // fp.direct_stores: the same for every instance (A/B).
+            constexpr bool ALWAYS_DIRECT = false;
+            constexpr bool REGS = FORM != 4;  // the store side of an item in registers (and published to LDS for the store passes)
+            const bool direct = fp.direct_stores || (FORM == 1 && fp.lone_direct);  // wave-uniform
             uint64_t pf[RW];
 #pragma unroll
             for (int w = 0; w < RW; w++) pf[w] = 0;
@@ -262,17 +279,26 @@ __device__ __forceinline__ uint32_t fused1_body(const FusedParams &fp, uint32_t 
 #pragma unroll
                 for (int w = 0; w < RW; w++) pf[w] = load_global_u64(at + 8 * w);
             };
+            fused1_u32x4 r = home[q];
+            uint32_t my_end = myend[q];
             if constexpr (FORM != 4) {
-                const fused1_u32x4 r = home[q];
-                if (t0 < myend[q]) load_block(reinterpret_cast<const uint8_t *>(((uint64_t)r.y << 32) | r.x));
+                if (t0 < my_end) load_block(reinterpret_cast<const uint8_t *>(((uint64_t)r.y << 32) | r.x));
             }
             // The ring holds two lines: what is left of a line after a store pass (at most 120 bytes) plus the words filed since
             // must not exceed 256 bytes.  A 136-byte block fits in one go; the 152- and 168-byte blocks of D384 / D256 are filed
             // in two parts with a store pass in between (the first 128 bytes complete a line whatever was left).
             constexpr int W1 = (RB + 120 > FUSED1_RING) ? 16 : RW;
+            auto advance = [&](uint32_t bytes) {
+                const uint64_t e2 = (((uint64_t)r.y << 32) | r.x) + bytes;
+                r.x = (uint32_t)e2;
+                r.y = (uint32_t)(e2 >> 32);
+                r.z += bytes;
+            };
             for (uint32_t t = t0; t < t_end; t++) {
-                fused1_u32x4 r = home[q];
-                const uint32_t my_end = myend[q];
+                if constexpr (!REGS) {
+                    r = home[q];
+                    my_end = myend[q];
+                }
                 const bool live = t < my_end;
                 uint8_t *blk = reinterpret_cast<uint8_t *>(((uint64_t)r.y << 32) | r.x);
                 if (live) {
@@ -295,14 +321,10 @@ __device__ __forceinline__ uint32_t fused1_body(const FusedParams &fp, uint32_t 
                         }
                     }
                     if (role == 1) {
-                        if (fp.direct_stores) {
+                        if (direct) {
 #pragma unroll
                             for (int w = 0; w < RW; w++) store_global_u64(blk + 8 * w, pf[w] ^ state_word(a, w));
-                            const uint64_t e2 = (((uint64_t)r.y << 32) | r.x) + RB;
-                            r.x = (uint32_t)e2;
-                            r.y = (uint32_t)(e2 >> 32);
-                            home[q] = r;
-                        } else {
+                        } else if constexpr (!ALWAYS_DIRECT) {
                             // per-item rotation of the ring by 16 q: the 8 items of a store group hit different banks
                             uint32_t rp = (r.x + 16 * q) & 255;
                             fused1_lds_u8 *row = ring + q * FUSED1_RING;
@@ -316,48 +338,53 @@ __device__ __forceinline__ uint32_t fused1_body(const FusedParams &fp, uint32_t 
                             // began, mod 16)
                             if (t == t0 && (r.x & 8)) store_global_u64(blk, pf[0] ^ state_word(a, 0));
                             if (t + 1 == my_end && !(r.x & 8)) store_global_u64(blk + 8 * (RW - 1), pf[RW - 1] ^ state_word(a, RW - 1));
-                            const uint64_t e2 = (((uint64_t)r.y << 32) | r.x) + 8 * W1;
-                            r.x = (uint32_t)e2;
-                            r.y = (uint32_t)(e2 >> 32);
-                            r.z += 8 * W1;
-                            home[q] = r;
                         }
                     }
+                    // (both lanes of a pair advance their copy; only the keystream lane's is ever published)
+                    advance(direct ? RB : 8 * W1);
+                    if constexpr (!REGS) {
+                        if (role == 1) home[q] = r;
+                    }
                 }
-                if constexpr (W1 < RW) {
-                    fused1_wave_sync();
-                    if (!fp.direct_stores) {  // wave-uniform
-                        while (fused1_flush_pass<false, FORM == 4>(role, q, lane, ring, home, fp.store_policy)) {
+                if constexpr (!ALWAYS_DIRECT && W1 < RW) {
+                    if (!direct) {  // wave-uniform
+                        fused1_wave_sync();
+                        while (fused1_flush_pass<false, FORM == 4, REGS>(r, role, q, lane, ring, home, fp.store_policy)) {
                         }
-                        if (live && role == 1) {
-                            r = home[q];
-                            uint32_t rp = (r.x + 16 * q) & 255;
-                            fused1_lds_u8 *row = ring + q * FUSED1_RING;
+                        if (live) {
+                            if (role == 1) {
+                                uint32_t rp = (r.x + 16 * q) & 255;
+                                fused1_lds_u8 *row = ring + q * FUSED1_RING;
 #pragma unroll
-                            for (int w = W1; w < RW; w++) {
-                                *reinterpret_cast<fused1_lds_u64 *>(row + rp) = pf[w] ^ state_word(a, w);
-                                rp = (rp + 8) & 255;
+                                for (int w = W1; w < RW; w++) {
+                                    *reinterpret_cast<fused1_lds_u64 *>(row + rp) = pf[w] ^ state_word(a, w);
+                                    rp = (rp + 8) & 255;
+                                }
                             }
-                            const uint64_t e2 = (((uint64_t)r.y << 32) | r.x) + 8 * (RW - W1);
-                            r.x = (uint32_t)e2;
-                            r.y = (uint32_t)(e2 >> 32);
-                            r.z += 8 * (RW - W1);
-                            home[q] = r;
+                            advance(8 * (RW - W1));
+                            if constexpr (!REGS) {
+                                if (role == 1) home[q] = r;
+                            }
                         }
                     }
                 }
                 if constexpr (FORM != 4) {
                     if (t + 1 < my_end) load_block(blk + RB);
                 }
-                fused1_wave_sync();
-                if (!fp.direct_stores) {  // wave-uniform
-                    while (fused1_flush_pass<false, FORM == 4>(role, q, lane, ring, home, fp.store_policy)) {
+                if constexpr (!ALWAYS_DIRECT) {
+                    if (!direct) {  // wave-uniform
+                        fused1_wave_sync();
+                        while (fused1_flush_pass<false, FORM == 4, REGS>(r, role, q, lane, ring, home, fp.store_policy)) {
+                        }
                     }
                 }
                 if (live) fused1_hot<FORM>(a);
             }
-            if (!fp.direct_stores) {
-                while (fused1_flush_pass<true, true>(role, q, lane, ring, home, fp.store_policy)) {
+            if constexpr (!ALWAYS_DIRECT) {
+                if (!direct) {
+                    fused1_wave_sync();
+                    while (fused1_flush_pass<true, true, REGS>(r, role, q, lane, ring, home, fp.store_policy)) {
+                    }
                 }
             }
         }

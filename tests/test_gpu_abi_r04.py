@@ -527,10 +527,10 @@ def test_time_sliced_fused_encrypt_matches_the_two_pass_form(capy, O):
     rng = random.Random(0x51CE)
     sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     try:
-        # four lanes per item in slices of one and two waves per SIMD (16 384 < n <= 22 528, 32 768 < n <= 35 840: kind 22); from
-        # 35 items per SIMD the one-lane-per-sponge kernel on its rotating schedule (kind 25; r04's third slice level is gone)
+        # four lanes per item in slices of one wave per SIMD (16 384 < n <= 22 528: kind 22); beyond 32 items per SIMD the
+        # one-lane-per-sponge kernel on its rotating schedule (kind 25; r04's second and third slice levels are gone)
         for d, n, ln, want_kind in ((512, 16400, 136 * 600 + 77, 22), (256, 20003, 168 * 520, 22), (512, 22528, 136 * 1030 + 8, 22),
-                                    (512, 33000, 136 * 520 + 16, 22), (384, 50001, 152 * 515, 25)):
+                                    (512, 33000, 136 * 520 + 16, 25), (384, 50001, 152 * 515, 25)):
             stride = (ln + 7) // 8 * 8 + 8
             pl = 32
             def rand(nbytes, seed):
