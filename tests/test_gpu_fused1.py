@@ -202,3 +202,50 @@ def test_kem_and_ecdhies_keys_take_the_same_kernel(env):
         _lib.check(lib.capy_set_sponge_lanes(0))
     assert res["auto"][2] == ONE_LANE and res["two-pass"][2] == TWO_PASS
     assert torch.equal(res["auto"][0], res["two-pass"][0]) and torch.equal(res["auto"][1], res["two-pass"][1])
+
+
+def test_ecdhies_symmetric_half_takes_the_kernel_with_56_byte_keys_and_tags(env):
+    """KeyEncryptable (src/ecc/encryptable.rs:34-94) at a chip-filling size: its symmetric half hands the kernel 56-byte ke / ka
+    at a 112-byte stride and asks for 56-byte tags (the sponge callers: 64 / 128 / 64) -- heads, tag stores and the D256 rate
+    differ.  key_encrypt against the two-pass form for every byte, two items against the oracle, then key_decrypt with one
+    forged tag."""
+    _lib, lib, O, torch = env
+    S = _simds(torch)
+    n, ln, d = 33 * S + 9, 168 * 3 + 21, 256
+    stride = (ln + 7) // 8 * 8 + 8
+    rng = random.Random(0xEC)
+    pw_len = 24
+    pws, ks, plain = _rand(lib, _lib, torch, n * pw_len, 41), _rand(lib, _lib, torch, n * 56, 42), _rand(lib, _lib, torch, n * stride, 43)
+    pubs = torch.empty(n * 112, dtype=torch.uint8, device="cuda")
+    _lib.check(lib.capy_keypair_batch_dev(d, n, pws.data_ptr(), pw_len, None, pubs.data_ptr(), None))
+    res = {}
+    try:
+        for name, lanes in (("auto", 0), ("two-pass", 1 | (1 << 16))):
+            _lib.check(lib.capy_set_sponge_lanes(lanes))
+            m = plain.clone()
+            zxy = torch.zeros(n * 112, dtype=torch.uint8, device="cuda")
+            tags = torch.zeros(n * 56, dtype=torch.uint8, device="cuda")
+            _lib.check(lib.capy_key_encrypt_batch_dev(d, n, pubs.data_ptr(), ks.data_ptr(), m.data_ptr(), None, ln, stride, zxy.data_ptr(), tags.data_ptr(), None))
+            torch.cuda.synchronize()
+            res[name] = (m, zxy, tags, _last(lib)[0])
+    finally:
+        _lib.check(lib.capy_set_sponge_lanes(0))
+    assert res["auto"][3] == ONE_LANE and res["two-pass"][3] == TWO_PASS
+    for k in range(3):
+        assert torch.equal(res["auto"][k], res["two-pass"][k]), k
+    m, zxy, tags, _ = res["auto"]
+    for i in (0, n - 1):
+        want = O.key_encrypt(bytes(pubs[112 * i:112 * i + 112].cpu().numpy()), bytes(ks[56 * i:56 * i + 56].cpu().numpy()),
+                             bytes(plain[i * stride:i * stride + ln].cpu().numpy()), d)
+        got = (bytes(m[i * stride:i * stride + ln].cpu().numpy()), bytes(zxy[112 * i:112 * i + 112].cpu().numpy()), bytes(tags[56 * i:56 * i + 56].cpu().numpy()))
+        assert got == want, i
+    f = rng.randrange(n)
+    tags[56 * f] ^= 0x80
+    ct = m[f * stride:f * stride + ln].clone()
+    status = torch.full((n,), 9, dtype=torch.int32, device="cuda")
+    _lib.check(lib.capy_key_decrypt_batch_dev(d, n, pws.data_ptr(), pw_len, None, zxy.data_ptr(), m.data_ptr(), None, ln, stride, tags.data_ptr(), status.data_ptr(), None))
+    torch.cuda.synchronize()
+    assert _last(lib)[0] == ONE_LANE
+    want = plain.clone()
+    want[f * stride:f * stride + ln] = ct
+    assert int(status[f]) == 1 and int((status != 0).sum()) == 1 and torch.equal(m, want)
