@@ -225,6 +225,7 @@ class Ctx:
         self.world, self.rank = world, rank
         self.barrier = barrier or (lambda: torch.cuda.synchronize())
         self.reduce_max = reduce_max or (lambda x: x)
+        self.min_over_ranks = (lambda x: x)  # set by bench.py's main at world_size > 1 (called by every rank at the same point)
 
     def rand(self, nbytes, seed):
         t = self.torch.empty((nbytes + 7) // 8 * 8, dtype=self.torch.uint8, device=self.dev)
@@ -270,14 +271,21 @@ def config2(cx, n=1 << 20, reps=30):
         _lib.check(lib.capy_set_sponge_lanes(0))
     same = bool(torch.equal(out, ref))
     sample = [(bytes(keys[64 * i:64 * i + 64].cpu().numpy()), bytes(ref[1024 * i:1024 * i + 1024].cpu().numpy())) for i in (0, n // 2, n - 1)]
-    res = {"what": "%d x KMACXOF256 1 KiB squeeze (64-B keys) per GPU" % n, "seconds": s, "units_per_s": cx.world * n / s,
-           "out_GBps": cx.world * n * 1024 / s / 1e9,
-           # 9 permutations run on the device per unit: 2 absorb (key block, suffix block) + 7 between the 8 squeeze blocks; the
-           # reference runs 11 (the shared prefix block, folded into the initial state here, and a wasted last one)
-           "device_permutations_per_s": cx.world * n * 9 / s, "kernel": kern,
+    res = {"what": "%d x KMACXOF256 1 KiB squeeze (64-B keys) per GPU" % n, "units_per_gpu": n, "seconds": s, "kernel": kern,
            "all_outputs_equal_second_kernel_family": same}
     assert same, "config 2: kernel families disagree"
-    return res, sample
+    return derive_config2(res, cx.world), sample
+
+
+def derive_config2(res, world):
+    """throughputs from the (max-over-ranks) seconds"""
+    n, s = res["units_per_gpu"], res["seconds"]
+    res["units_per_s"] = world * n / s
+    res["out_GBps"] = world * n * 1024 / s / 1e9
+    # 9 permutations run on the device per unit: 2 absorb (key block, suffix block) + 7 between the 8 squeeze blocks; the
+    # reference runs 11 (the shared prefix block, folded into the initial state here, and a wasted last one)
+    res["device_permutations_per_s"] = world * n * 9 / s
+    return res
 
 
 def config3(cx, specified_total=1024, saturating=((65536, 1 << 20), (131072, 1 << 20), (32768, MSG_BYTES), (49152, MSG_BYTES))):
@@ -287,6 +295,9 @@ def config3(cx, specified_total=1024, saturating=((65536, 1 << 20), (131072, 1 <
     lib, _lib, torch = cx.lib, cx._lib, cx.torch
     res = {"what": "sha3_encrypt / sha3_decrypt D512, device-resident; GiB/s = message bytes / 2^30 / seconds, whole job"}
     sample = None
+    # every rank must take the same saturating sizes (the legs are reduced over the ranks afterwards): the SMALLEST free memory
+    # decides -- asked first, where every rank still arrives (the only collective inside a leg)
+    free = cx.min_over_ranks(torch.cuda.mem_get_info()[0])
 
     def one(nmsg, ln, stride, reps):
         nonlocal sample
@@ -327,8 +338,8 @@ def config3(cx, specified_total=1024, saturating=((65536, 1 << 20), (131072, 1 <
 
     per_rank = max(1, specified_total // cx.world)
     te, td, kern = one(per_rank, MSG_BYTES, MSG_BYTES + 128, 2)
-    res["as_specified"] = {"messages_total": per_rank * cx.world, "messages_per_gpu": per_rank, "enc_seconds": te, "dec_seconds": td,
-                           "enc_GiBps": per_rank * cx.world * MSG_BYTES / te / 2**30, "kernel": kern,
+    res["as_specified"] = {"messages_total": per_rank * cx.world, "messages_per_gpu": per_rank, "msg_bytes": MSG_BYTES, "enc_seconds": te,
+                           "dec_seconds": td, "kernel": kern,
                            "note": "a chain-latency workload: every sponge is 38 553 serial permutations whatever the batch"}
     if cx.world == 1 and per_rank != 128:
         te8, td8, kern8 = one(128, MSG_BYTES, MSG_BYTES + 128, 2)
@@ -336,18 +347,28 @@ def config3(cx, specified_total=1024, saturating=((65536, 1 << 20), (131072, 1 <
                                         "note": "what each of eight GPUs would run: config 3 as specified does not scale -- one GPU takes the "
                                                 "whole config in %.2f x the time eight GPUs need for their eighth" % (te / te8)}
     sat = []
-    free, _ = torch.cuda.mem_get_info()
     for nmsg, ln in saturating:
         if nmsg * (ln + 128) > free - (8 << 30):
             continue
         te, td, kern = one(nmsg, ln, ln + 128, 2)
-        sat.append({"messages_per_gpu": nmsg, "msg_bytes": ln, "enc_seconds": te, "dec_seconds": td,
-                    "enc_GiBps": cx.world * nmsg * ln / te / 2**30, "dec_GiBps": cx.world * nmsg * ln / td / 2**30,
-                    "algorithmic_GBps": 2 * cx.world * nmsg * ln / te / 1e9, "frac_of_hbm_peak": 2 * nmsg * ln / te / 1e9 / HBM_PEAK_GBS,
-                    # two permutations per 136-byte block (tag sponge + keystream sponge)
-                    "device_permutations_per_s": cx.world * nmsg * (ln // 136 + 3) * 2 / te, "kernel": kern})
+        sat.append({"messages_per_gpu": nmsg, "msg_bytes": ln, "enc_seconds": te, "dec_seconds": td, "kernel": kern})
     res["saturating"] = sat
-    return res, sample
+    return derive_config3(res, cx.world), sample
+
+
+def derive_config3(res, world):
+    """throughputs from the (max-over-ranks) seconds"""
+    e = res["as_specified"]
+    e["enc_GiBps"] = e["messages_per_gpu"] * world * e["msg_bytes"] / e["enc_seconds"] / 2**30
+    for e in res["saturating"]:
+        nmsg, ln, te, td = e["messages_per_gpu"], e["msg_bytes"], e["enc_seconds"], e["dec_seconds"]
+        e["enc_GiBps"] = world * nmsg * ln / te / 2**30
+        e["dec_GiBps"] = world * nmsg * ln / td / 2**30
+        e["algorithmic_GBps"] = 2 * world * nmsg * ln / te / 1e9
+        e["frac_of_hbm_peak"] = 2 * nmsg * ln / te / 1e9 / HBM_PEAK_GBS
+        # two permutations per 136-byte block (tag sponge + keystream sponge)
+        e["device_permutations_per_s"] = world * nmsg * (ln // 136 + 3) * 2 / te
+    return res
 
 
 def config5(cx, n=1 << 16, msg_len=1024):
@@ -391,10 +412,62 @@ def config5(cx, n=1 << 16, msg_len=1024):
                bytes(h_h[56 * i:56 * i + 56]), bytes(z_h[56 * i:56 * i + 56])) for i in (0, n - 1)]
     res = {"what": "Schnorr D512, %d x %d-byte messages per GPU, host-buffer C ABI (PCIe inclusive), constant-address lookups for the "
                    "secret scalars (the default)" % (n, msg_len),
-           "keypair_per_s": cx.world * n / tk, "sign_per_s": cx.world * n / ts, "verify_per_s": cx.world * n / tv,
-           "first_call_per_s": {"keypair": n / tk0, "sign": n / ts0, "verify": n / tv0},
+           "items_per_gpu": n, "keypair_seconds": tk, "sign_seconds": ts, "verify_seconds": tv,
+           "first_call_seconds": {"keypair": tk0, "sign": ts0, "verify": tv0},
            "all_verified": all_ok, "one_flipped_byte_fails_alone": bad == [f]}
-    return res, sample
+    return derive_config5(res, cx.world), sample
+
+
+def derive_config5(res, world):
+    n = res["items_per_gpu"]
+    for k in ("keypair", "sign", "verify"):
+        res[k + "_per_s"] = world * n / res[k + "_seconds"]
+    res["first_call_per_s"] = {k: n / v for k, v in res["first_call_seconds"].items()}
+    return res
+
+
+def _seconds_leaves(obj, path=()):
+    """(path, value) of every float leaf whose key ends in 'seconds', in a deterministic order"""
+    out = []
+    if isinstance(obj, dict):
+        for k in sorted(obj):
+            v = obj[k]
+            if isinstance(v, (dict, list)):
+                out += _seconds_leaves(v, path + (k,))
+            elif isinstance(v, float) and str(k).endswith("seconds"):
+                out.append((path + (k,), v))
+    elif isinstance(obj, list):
+        for i, v in enumerate(obj):
+            out += _seconds_leaves(v, path + (i,))
+    return out
+
+
+def run_config_leg(fn, derive, cx, max_reduce, **kw):
+    """One config leg at world_size N: every rank runs `fn` WITHOUT a collective inside (cx.barrier is a local synchronise there),
+    so a rank that fails cannot leave the others hanging in a barrier; then ONE fixed-size MAX-reduction carries every rank's
+    seconds and failure flag, and the throughputs are derived from the slowest rank's times.  Returns (result or error dict,
+    sample or None)."""
+    res, sample, err = None, None, ""
+    try:
+        res, sample = fn(cx, **kw)
+    except Exception as e:  # an assertion of the leg, or an error return of the library
+        err = "%s: %s" % (type(e).__name__, e)
+    if max_reduce is None:  # one rank
+        if err:
+            raise RuntimeError(err)
+        return res, sample
+    leaves = _seconds_leaves(res) if res is not None else []
+    vec = [1.0 if err else 0.0, float(len(leaves))] + [v for _, v in leaves]
+    vec += [0.0] * (64 - len(vec))
+    red = max_reduce(vec[:64])
+    if red[0] > 0 or err or int(red[1]) != len(leaves):
+        return {"error": err or "a rank failed this leg (see its stderr)"}, None
+    for (path, _), v in zip(leaves, red[2:]):
+        o = res
+        for k in path[:-1]:
+            o = o[k]
+        o[path[-1]] = v
+    return derive(res, cx.world), sample
 
 
 def check_config_samples(samples):
@@ -734,16 +807,25 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             return float(t.item())
 
-        cx = Ctx(lib, _lib, torch, dev, stream, world, rank, barrier, reduce_max)
+        # inside a leg: local synchronisation only (run_config_leg reduces afterwards)
+        cx = Ctx(lib, _lib, torch, dev, stream, world, rank)
+        vec_max = None
+        if use_dist:
+            def vec_max(vec):
+                t = torch.tensor(vec, dtype=torch.float64, device=red_dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                return [float(x) for x in t.tolist()]
+
+            cx.min_over_ranks = lambda x: -reduce_max(-float(x))
         t_cfg = time.perf_counter()
-        if share > 1:  # rehearsal: ranks share one card
-            cfg_res["2"], cfg_samples[2] = config2(cx, n=1 << 16, reps=5)
-            cfg_res["3"], cfg_samples[3] = config3(cx, specified_total=8 * world, saturating=((4096, 1 << 16),))
-            cfg_res["5"], cfg_samples[5] = config5(cx, n=1 << 12)
-        else:
-            cfg_res["2"], cfg_samples[2] = config2(cx)
-            cfg_res["3"], cfg_samples[3] = config3(cx)
-            cfg_res["5"], cfg_samples[5] = config5(cx)
+        barrier()
+        small = share > 1  # rehearsal: ranks share one card
+        cfg_res["2"], cfg_samples[2] = run_config_leg(config2, derive_config2, cx, vec_max, **(dict(n=1 << 16, reps=5) if small else {}))
+        barrier()
+        cfg_res["3"], cfg_samples[3] = run_config_leg(config3, derive_config3, cx, vec_max,
+                                                      **(dict(specified_total=8 * world, saturating=((4096, 1 << 16),)) if small else {}))
+        barrier()
+        cfg_res["5"], cfg_samples[5] = run_config_leg(config5, derive_config5, cx, vec_max, **(dict(n=1 << 12) if small else {}))
         cfg_res["seconds_spent"] = time.perf_counter() - t_cfg
 
     # which kernel the library picked for this shape (one launch per step, or P phase launches of the mixed kernel)
@@ -878,13 +960,14 @@ def main():
         if cfg_res:
             if valu_live:  # config 2 / 3 against the bare paired permutation loop measured in this run
                 bare = valu_live * 1e9 / 136.0  # permutations/s
-                cfg_res["2"]["frac_of_paired_loop"] = cfg_res["2"]["device_permutations_per_s"] / world / bare
-                for e in cfg_res["3"]["saturating"]:
+                if "device_permutations_per_s" in cfg_res["2"]:
+                    cfg_res["2"]["frac_of_paired_loop"] = cfg_res["2"]["device_permutations_per_s"] / world / bare
+                for e in cfg_res["3"].get("saturating", []):
                     e["frac_of_paired_loop"] = e["device_permutations_per_s"] / world / bare
             res["configs"] = cfg_res
         if not a.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(a.cpu_seconds)
-            if cfg_samples:
+            if any(v is not None for v in cfg_samples.values()):
                 res["configs"]["oracle_spot_checks"] = check_config_samples(cfg_samples)
             if ed:
                 res["ed448"]["cpu_port_scalar_mults_per_s_1thread"] = cpu_baseline_ed448(min(5.0, a.cpu_seconds), ed_sample)
