@@ -205,6 +205,8 @@ static int fused1_launch(int rw, FusedParams &fp, const MsgView &m, hipStream_t 
         const size_t q = (groups + simds - 1) / simds;
         if (!(q >= 4 && groups * 5 > (5 * q - 1) * simds)) level = 2;
     }
+    static const uint32_t forced_level = (uint32_t)debug_knob("fused1_level", 0);  // A/B: slices of this many waves per SIMD
+    if (forced_level >= 1 && forced_level <= 3 && groups > forced_level * simds) level = forced_level;
     if (slices_on && level && long_uniform) {
         static const uint64_t max_turns = (uint64_t)debug_knob("fused1_turns", 64);
         const uint32_t turns = (uint32_t)std::min<uint64_t>(max_turns ? max_turns : 64, nfull / 64);  // >= 8 turns per group

@@ -35,6 +35,9 @@ namespace capy {
 #ifndef CAPY_F1_ROT_DOUBLED
 #define CAPY_F1_ROT_DOUBLED 3  // 2: the doubled-up role unrolled as well (A/B)
 #endif
+#ifndef CAPY_F1_FORM2_WAVES
+#define CAPY_F1_FORM2_WAVES 2  // 3: the unrolled instance squeezed into 168 VGPRs (A/B)
+#endif
 #ifndef CAPY_F1_LB
 #define CAPY_F1_LB 4
 #endif
@@ -494,7 +497,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // One launch: wave w works on wave-group w (sl_groups == 0), or -- time slices, as in sponge_fused.h -- on wave-group
 // (sl_launch * gridDim.x + w) mod sl_groups for at most sl_blocks full blocks, progress in sl_done, states in sl_state.
 template <int RW, int FORM, bool DECRYPT>
-__global__ __launch_bounds__(64, (FORM == 1 ? 1 : (FORM == 2 ? 2 : CAPY_F1_LB))) CAPY_WAVES_PER_SIMD(FORM == 1 ? 1 : (FORM == 2 ? 2 : 4)) void sponge_fused1_kernel(const FusedParams fp)
+__global__ __launch_bounds__(64, (FORM == 1 ? 1 : (FORM == 2 ? CAPY_F1_FORM2_WAVES : CAPY_F1_LB))) CAPY_WAVES_PER_SIMD(FORM == 1 ? 1 : (FORM == 2 ? CAPY_F1_FORM2_WAVES : 4)) void sponge_fused1_kernel(const FusedParams fp)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_lds[FUSED1_LDS_WAVE];
     fused1_lds_u8 *lds = (fused1_lds_u8 *)s_lds;
