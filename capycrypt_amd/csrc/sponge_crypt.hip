@@ -208,8 +208,11 @@ static int fused1_launch(int rw, FusedParams &fp, const MsgView &m, hipStream_t 
     static const uint32_t forced_level = (uint32_t)debug_knob("fused1_level", 0);  // A/B: slices of this many waves per SIMD
     if (forced_level >= 1 && forced_level <= 3 && groups > forced_level * simds) level = forced_level;
     if (slices_on && level && long_uniform) {
+        // turns per group: at most 64 (fewer leave a coarser last launch: 16 turns 586-604 GiB/s where 64 give 637-645; 128 and 256
+        // only add state traffic; choosing the count whose last launch is fullest moved nothing beyond the noise), at least 8.
+        // CAPY_DEBUG=fused1_turns=T forces it.
         static const uint64_t max_turns = (uint64_t)debug_knob("fused1_turns", 64);
-        const uint32_t turns = (uint32_t)std::min<uint64_t>(max_turns ? max_turns : 64, nfull / 64);  // >= 8 turns per group
+        const uint32_t turns = (uint32_t)std::min<uint64_t>(max_turns ? max_turns : 64, nfull / 64);
         const uint32_t bp = (uint32_t)((nfull + turns - 1) / turns);
         const uint32_t need0 = (uint32_t)((nfull + bp - 1) / bp);
         const size_t done_bytes = (groups * 4 + 255) & ~(size_t)255, state_bytes = groups * 50 * 64 * 4;
