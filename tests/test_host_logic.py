@@ -512,3 +512,41 @@ def test_bench_launches_its_own_ranks(monkeypatch):
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and os.path.basename(cmd[-5]) == "bench.py" and cmd[-4:] == ["--gpus", "8", "--steps", "3"]
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
     assert "torch" not in seen["env"].get("CAPY_TOUCHED", "")  # (nothing of torch is needed to get here)
+
+
+def test_bench_config_legs_reduce_once_and_survive_a_failing_rank():
+    """bench.py at world_size N: a config leg runs without collectives inside, then ONE fixed-size MAX-reduction carries every
+    rank's seconds and a failure flag (run_config_leg).  Simulated here with two 'ranks': the slowest rank's seconds end up in
+    the result and the throughputs are derived from them; a rank whose leg raises turns the leg into an error entry on every
+    rank instead of leaving the others in a barrier."""
+    import bench
+
+    class Cx:
+        world = 2
+
+    def leg(seconds):
+        def fn(cx, n=1000):
+            res = {"units_per_gpu": n, "seconds": seconds, "kernel": {"kind": 7, "launches": 1}, "nested": [{"enc_seconds": seconds * 2}]}
+            return bench.derive_config2(res, cx.world), ("sample",)
+        return fn
+
+    # this rank measured 0.5 s, the other 0.8 s (and 1.6 s for the nested figure): the reduction returns the element-wise maximum
+    other = [0.0, 2.0, 1.6, 0.8] + [0.0] * 60
+    res, sample = bench.run_config_leg(leg(0.5), bench.derive_config2, Cx(), lambda v: [max(a, b) for a, b in zip(v, other)])
+    assert res["seconds"] == 0.8 and res["nested"][0]["enc_seconds"] == 1.6 and sample == ("sample",)
+    assert res["units_per_s"] == 2 * 1000 / 0.8
+    assert [p for p, _ in bench._seconds_leaves(res)] == [("nested", 0, "enc_seconds"), ("seconds",)]
+    # the other rank failed (flag 1 in slot 0): this rank reports an error entry, and so does a rank whose own leg raises
+    failed = [1.0] + [0.0] * 63
+    res, sample = bench.run_config_leg(leg(0.5), bench.derive_config2, Cx(), lambda v: [max(a, b) for a, b in zip(v, failed)])
+    assert "error" in res and sample is None
+
+    def boom(cx):
+        raise AssertionError("round trip failed")
+
+    seen = []
+    res, sample = bench.run_config_leg(boom, bench.derive_config2, Cx(), lambda v: seen.append(v) or v)
+    assert "round trip failed" in res["error"] and seen and seen[0][0] == 1.0 and len(seen[0]) == 64  # it still took part in the reduction
+    # one rank (no reduction): a failure is raised, not swallowed
+    with pytest.raises(RuntimeError):
+        bench.run_config_leg(boom, bench.derive_config2, Cx(), None)
