@@ -338,8 +338,7 @@ int symmetric_crypt_dev(bool encrypt, int d, size_t n, const uint8_t *keka, size
             tag_compare_launch(tags, tag_len, tag2, tag_len, (uint32_t)tag_len, status, n, s);
             return keystream(status);
         }
-        // Just above a whole number of waves per SIMD (16 384 < n <= 22 528, 32 768 < n <= 43 008, 49 152 < n <= 61 440 uniform long
-        // messages): TIME SLICES instead of a further wave on some SIMDs.
+        // Just above one wave per SIMD (16 384 < n <= 22 528 uniform long messages): TIME SLICES instead of a second wave on some SIMDs.
         // One launch of the whole batch puts a second wave on (n - 16 384) / 16 SIMDs, those run the paired round at 1 / 1.52 of
         // a lone wave's rate and the launch takes the two-waves time (0.30 s for 5 MiB messages) however few they are.  Here
         // every launch holds exactly one wave per SIMD: launch k works on the wave-groups (k C + w) mod G for `bp` full blocks,
