@@ -146,6 +146,21 @@ __global__ __launch_bounds__(64) CAPY_ONE_WAVE_PER_SIMD void vb_duo_kernel(uint6
 #endif
 }
 
+// two lanes per item with constant-address lookups, the table half in registers and half in LDS (ed448_duo.h): secret scalars,
+// 16 k .. 32 k items in ONE round of waves
+__global__ __launch_bounds__(64) CAPY_ONE_WAVE_PER_SIMD void vb_duo_ct_kernel(uint64_t n, const uint8_t *scalars_be, uint64_t scalar_stride,
+                                                          const uint8_t *points_xy, uint64_t point_stride, uint8_t *out_xy)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ uint32_t tab[duo::DUO_CT_LDS_DWORDS];
+    const uint64_t slot = ((uint64_t)blockIdx.x * 64 + threadIdx.x) >> 1;
+    const uint64_t i = slot < n ? slot : n - 1;  // pairs past the batch redo the last item, write nothing
+    const bool p = threadIdx.x & 1;
+    const duo::Half r = duo::scalarmul_ct(scalars_be + i * scalar_stride, points_xy + i * point_stride, tab, p);
+    duo::store_affine(out_xy + i * 112, r, p, slot < n);
+#endif
+}
+
 __global__ __launch_bounds__(64) CAPY_ONE_WAVE_PER_SIMD void dsm_duo_kernel(uint64_t n, const uint8_t *a_be, const uint8_t *b_be, const uint8_t *points_xy,
                                                         uint8_t *out_xy, uint32_t *table_ws, const uint32_t *gtab)
 {
@@ -595,6 +610,16 @@ static int vb_launch(size_t n, const uint8_t *scalars, uint64_t scalar_stride, c
         else
             hipLaunchKernelGGL(wave::vb_wave_kernel<false>, dim3((unsigned)n), dim3(64), 0, s, (uint64_t)n, scalars, scalar_stride,
                                points, point_stride, out);
+        CAPY_HIP(hipGetLastError());
+        return CAPY_OK;
+    }
+    // two lanes per item, constant-address lookups, the table half in registers and half in LDS: one round of waves where the
+    // quad form needs two (16 S < n <= 32 S).  CAPY_DEBUG=ed448_duo_ct=0 switches it off (A/B).
+    static const bool duo_ct_on = debug_knob("ed448_duo_ct", 1) != 0;
+    if (quad_ct && duo_ct_on && n > 16 * dev_simds() && n <= 32 * dev_simds() && g_quad_max.load() < 0) {
+        t_last_vb_kernel = 2 + 64;
+        hipLaunchKernelGGL(vb_duo_ct_kernel, dim3((unsigned)((n + 31) / 32)), dim3(64), 0, s, (uint64_t)n, scalars, scalar_stride, points,
+                           point_stride, out);
         CAPY_HIP(hipGetLastError());
         return CAPY_OK;
     }

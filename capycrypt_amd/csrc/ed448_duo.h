@@ -148,6 +148,130 @@ __device__ __forceinline__ Half scalarmul(const uint8_t *k_be, const uint8_t *xy
     return acc;
 }
 
+// ---- constant-address form (secret scalars, 16 k .. 32 k items: KeyEncryptable's k V and s Z,
+// /root/reference/src/ecc/encryptable.rs:37,78), r05.  The constant-address quad kernel (ed448_quad.h) needs 32 KiB of LDS per
+// wave of 16 items, so a compute unit holds four of its waves and 32 768 items take two rounds (2.35 ms against 1.25 ms for
+// 16 384).  Two lanes per item put those 32 768 items on one wave per SIMD -- if the window table of 32 items fits 40 KiB.
+// It does not in LDS alone (8 rows x 4 fields x 64 B = 2 KiB per item), so the table is SPLIT: rows 1 .. 4 of an item stay in
+// the REGISTERS of its two lanes (each lane its own two fields of a row: 32 dwords, 128 VGPRs for four rows -- the kernel runs
+// at one wave per SIMD, where 512 registers per lane are there to be used), rows 5 .. 8 in LDS (32 pieces of 16 bytes per lane,
+// lane l owning bytes 16 l .. 16 l + 15 of every 1 KiB line: conflict-free, 32 KiB per wave).  Every row of both halves is read
+// for every window and the wanted one kept by an arithmetic mask (ct_mask / ct_take, ed448_algo.h): 128 v_bitop3_b32 on the
+// register rows + 32 LDS reads and 128 v_bitop3_b32 on the others; no address, branch or exec mask depends on the scalar.
+constexpr int DUO_CT_ROWS = CtWin::HALF;                       // rows 1 .. HALF (8)
+constexpr int DUO_CT_REG_ROWS = DUO_CT_ROWS / 2;               // 1 .. 4 in registers
+constexpr int DUO_CT_LDS_ROWS = DUO_CT_ROWS - DUO_CT_REG_ROWS;  // 5 .. 8 in LDS
+constexpr int DUO_CT_LDS_DWORDS = DUO_CT_LDS_ROWS * 8 * 256;   // rows x 16-byte pieces (2 fields x 4) x (64 lanes x 4 dwords)
+
+__device__ __forceinline__ void ct_store_row(uint32_t *lds, int row, const Half &h)
+{
+    const uint32_t lane = threadIdx.x & 63;
+#pragma unroll
+    for (int pc = 0; pc < 8; pc++) {
+        const Fe &f = pc < 4 ? h.u : h.v;
+        const int b = 4 * (pc & 3);
+        const uint4 v = {f.l[b], f.l[b + 1], f.l[b + 2], f.l[b + 3]};
+        *reinterpret_cast<uint4 *>(lds + ((row * 8 + pc) * 64 + lane) * 4) = v;
+    }
+}
+__device__ __forceinline__ Half ct_load_row(const uint32_t *lds, int row)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    Half h;
+#pragma unroll
+    for (int pc = 0; pc < 8; pc++) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(lds + ((row * 8 + pc) * 64 + lane) * 4);
+        Fe &f = pc < 4 ? h.u : h.v;
+        const int b = 4 * (pc & 3);
+        f.l[b] = v.x, f.l[b + 1] = v.y, f.l[b + 2] = v.z, f.l[b + 3] = v.w;
+    }
+    return h;
+}
+
+// this lane's half of sign(digit) * tab[|digit|]: (Y2, Z2) | (X2, d T2); every row of both halves of the table is read
+__device__ __forceinline__ Half ct_entry(const Half (&regs)[DUO_CT_REG_ROWS], const uint32_t *lds, int digit, bool p)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const bool neg = digit < 0;
+    const uint32_t idx = (uint32_t)(neg ? -digit : digit);
+    Half e;
+    e.u = fe_zero();
+    e.v = fe_zero();
+#pragma unroll
+    for (int row = 0; row < DUO_CT_REG_ROWS; row++) {
+        const uint32_t m = ct_mask((uint32_t)(row + 1) == idx);
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            e.u.l[i] = ct_take(e.u.l[i], regs[row].u.l[i], m);
+            e.v.l[i] = ct_take(e.v.l[i], regs[row].v.l[i], m);
+        }
+    }
+#pragma unroll
+    for (int row = 0; row < DUO_CT_LDS_ROWS; row++) {
+        const uint32_t m = ct_mask((uint32_t)(row + 1 + DUO_CT_REG_ROWS) == idx);
+#pragma unroll
+        for (int pc = 0; pc < 8; pc++) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(lds + ((row * 8 + pc) * 64 + lane) * 4);
+            Fe &f = pc < 4 ? e.u : e.v;
+            const int b = 4 * (pc & 3);
+            f.l[b] = ct_take(f.l[b], v.x, m);
+            f.l[b + 1] = ct_take(f.l[b + 1], v.y, m);
+            f.l[b + 2] = ct_take(f.l[b + 2], v.z, m);
+            f.l[b + 3] = ct_take(f.l[b + 3], v.w, m);
+        }
+    }
+    // digit 0: no row matched; the zeros become the cached identity (Y2, Z2) = (1, 1) | (X2, d T2) = (0, 0)
+    const uint32_t one0 = ct_mask(idx == 0) & (p ? 0u : 1u);
+    e.u.l[0] |= one0;
+    e.v.l[0] |= one0;
+    // -(x, y) = (-x, y): X2 and d T2 change sign, both live in lane 1 -- a select of data, not of an address
+    e.u = fe_sel(neg && p, e.u, fe_neg_nr(e.u));
+    e.v = fe_sel(neg && p, e.v, fe_neg_nr(e.v));
+    return e;
+}
+
+// [k]P with constant-address lookups; lds = the wave's DUO_CT_LDS_DWORDS.  4-bit signed windows as the other hardened kernels.
+__device__ __forceinline__ Half scalarmul_ct(const uint8_t *k_be, const uint8_t *xy, uint32_t *lds, bool p)
+{
+    const Fe px = fe_from_bytes(xy), py = fe_from_bytes(xy + 56);
+    Half pc;  // P in cached form: (y, 1) | (x, d x y)
+    pc.u = fe_sel(p, py, px);
+    pc.v = fe_sel(p, fe_one(), fe_mul_d(fe_mul(px, py)));
+    // rows 1 .. 4 through LDS into registers, then rows 5 .. 8 into the same LDS slots (two rolled loops: the additions are not
+    // unrolled eight times)
+    Half acc = identity(p);
+#pragma unroll 1
+    for (int j = 0; j < DUO_CT_REG_ROWS; j++) {
+        acc = add_cached(acc, pc, p);
+        Half row = acc;
+        row.v = fe_sel(p, acc.v, fe_mul_d(acc.v));
+        ct_store_row(lds, j, row);
+    }
+    Half regs[DUO_CT_REG_ROWS];
+#pragma unroll
+    for (int j = 0; j < DUO_CT_REG_ROWS; j++) regs[j] = ct_load_row(lds, j);
+#pragma unroll 1
+    for (int j = 0; j < DUO_CT_LDS_ROWS; j++) {
+        acc = add_cached(acc, pc, p);
+        Half row = acc;
+        row.v = fe_sel(p, acc.v, fe_mul_d(acc.v));
+        ct_store_row(lds, j, row);
+    }
+    uint32_t k[14], w[15];
+    sc_from_be(k, k_be);
+    const uint32_t top = sc_recode_signed<CT_WBITS>(w, k);
+    sc_msb_align<CT_WBITS>(w);
+    acc = add_cached(identity(p), ct_entry(regs, lds, (int)top, p), p);
+#pragma unroll 1
+    for (int i = 0; i < CtWin::NWIN; i++) {
+        const Half e = ct_entry(regs, lds, sc_next_digit_msb<CT_WBITS>(w), p);
+#pragma unroll 1
+        for (int j = 0; j < CT_WBITS; j++) acc = dbl(acc, p);
+        acc = add_cached(acc, e, p);
+    }
+    return acc;
+}
+
 // acc += [a]G from the shared fixed-base table on E (rows of FB_TAB_ENTRIES affine cached entries (x, y, d x y), 12-bit
 // signed windows, row FbWin::NWIN = the recoding carry): 39 additions in pair form, (y, 1) | (x, d x y) per entry.
 __device__ __forceinline__ Half add_fixed_base(Half acc, const uint8_t *a_be, const uint32_t *gtab, bool p)

@@ -24,7 +24,7 @@ OBJ = os.path.join(ROOT, "capycrypt_amd", "csrc", "ed448.o")
 
 # kernel-name substrings; in every one of these kernels the scalar pointer is the second argument (byte offset 8)
 HARDENED = ["12vb_ct_kernelE", "12fb_ct_kernelE", "13fb_ct7_kernelILb1E", "18fb_ct7_pair_kernelILb1E", "10fb2_kernelILb1ELb0E",
-            "14vb_wave_kernelILb1E", "14fb_wave_kernelILb1E", "17vb_quad_ct_kernelE", "15vb_ct_kernel_1wE"]
+            "14vb_wave_kernelILb1E", "14fb_wave_kernelILb1E", "17vb_quad_ct_kernelE", "15vb_ct_kernel_1wE", "16vb_duo_ct_kernelE"]
 INDEXED = ["9vb_kernelE", "10vb2_kernelE", "9fb_kernelILb1E", "10fb2_kernelILb0ELb1E", "14vb_wave_kernelILb0E", "14fb_wave_kernelILb0E",
            "14vb_quad_kernelE", "13vb_duo_kernelE", "12vb_kernel_1wE"]
 

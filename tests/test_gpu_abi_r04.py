@@ -400,8 +400,10 @@ def test_lanes_per_item_kernels_equal_the_other_families(capy, O, family):
 
 
 def test_constant_address_quad_kernel_equals_the_other_hardened_kernels(capy, O):
-    """vb_quad_ct_kernel (csrc/ed448_quad.h, r04): secret-scalar variable-base multiplications of 4096 < n <= 32768 items with
-    four lanes per item and the window table in LDS, every row read per window.  Bytes must equal those of the
+    """vb_quad_ct_kernel (csrc/ed448_quad.h, r04): secret-scalar variable-base multiplications of 4096 < n <= 16 384 items with
+    four lanes per item and the window table in LDS, every row read per window; vb_duo_ct_kernel (csrc/ed448_duo.h, r05) for
+    16 384 < n <= 32 768: two lanes per item, rows 1-4 of the table in registers and rows 5-8 in LDS, one round of waves where the
+    quad form needed two.  Bytes must equal those of the
     one-item-per-lane / one-item-per-wave hardened kernels (capy_ed448_set_quad_range(0, 0)) and of the indexed kernels, on
     edge scalars, the identity and a point of order 2, at sizes with ragged last waves and beyond one round of waves; a
     sample is checked against the oracle; and the protocol calls that use it (key_encrypt / key_decrypt) round-trip."""
@@ -418,7 +420,7 @@ def test_constant_address_quad_kernel_equals_the_other_hardened_kernels(capy, O)
     edge_k = [0, 1, 2, R - 1, R, R + 1, (1 << 448) - 1, 1 << 447, 8, 0x8888, (1 << 448) - 8]
     fam = C.c_int(0)
     try:
-        for n in (4097, 9001, 16384, 20000):
+        for n in (4097, 9001, 16384, 20000, 32768):
             sc = torch.empty(n * 56, dtype=torch.uint8, device="cuda")
             tsc = torch.empty(n * 56, dtype=torch.uint8, device="cuda")
             for t, seed in ((sc, 1), (tsc, 3)):
@@ -438,7 +440,11 @@ def test_constant_address_quad_kernel_equals_the_other_hardened_kernels(capy, O)
                 vb = torch.zeros(n * 112, dtype=torch.uint8, device="cuda")
                 _lib.check(lib.capy_ed448_scalarmul_batch_dev(n, sc.data_ptr(), pts.data_ptr(), vb.data_ptr(), sp))
                 lib.capy_debug_last_curve_kernel(C.byref(fam), None)
-                assert (fam.value == 34) == (name == "quad_ct"), (n, name, fam.value)
+                # r05: between 16 and 32 items per SIMD the constant-address form is the two-lanes-per-item kernel (66: table half
+                # in registers, half in LDS, one round of waves); below, the quad form (34)
+                S = 4 * torch.cuda.get_device_properties(0).multi_processor_count
+                want_ct = 66 if 16 * S < n <= 32 * S else 34
+                assert (fam.value == want_ct) == (name == "quad_ct"), (n, name, fam.value)
                 torch.cuda.synchronize()
                 outs[name] = vb
             assert torch.equal(outs["indexed"], outs["quad_ct"]), n

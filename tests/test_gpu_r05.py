@@ -40,8 +40,8 @@ def test_ed448_family_boundaries_are_multiples_of_the_simd_count(env):
     """csrc/ed448.hip (r05, VERDICT r4 item 6 / ADVICE r4): the batch sizes at which the variable-base launcher changes kernel
     family are 4 S, 16 S, 32 S items for S SIMDs (r04: the literals 4096 / 16 384 / 32 768 of a whole MI355X).  Asserted on the
     family each call really launched (capy_debug_last_curve_kernel): 17 one item per wave, 33 four lanes per item, 65 two lanes
-    per item, 1 one item per lane; with constant-address lookups 18, 34 (quad, table in LDS), 2.  On the full chip (S = 1024)
-    these are exactly r04's boundaries."""
+    per item, 1 one item per lane; with constant-address lookups 18, 34 (quad, table in LDS), 66 (two lanes per item, table
+    half in registers and half in LDS: r05), 2.  On the full chip (S = 1024) these are exactly r04's boundaries."""
     _lib, lib, O, torch = env
     S = _simds(torch)
     nmax = 32 * S + 1
@@ -61,8 +61,8 @@ def test_ed448_family_boundaries_are_multiples_of_the_simd_count(env):
         got = {n: family(n) for n in (4 * S, 4 * S + 1, 16 * S, 16 * S + 1, 32 * S, 32 * S + 1)}
         assert got == {4 * S: 17, 4 * S + 1: 33, 16 * S: 33, 16 * S + 1: 65, 32 * S: 65, 32 * S + 1: 1}, got
         _lib.check(lib.capy_ed448_set_hardened(_lib.CAPY_HARDEN_ALL))
-        got = {n: family(n) for n in (4 * S, 4 * S + 1, 32 * S, 32 * S + 1)}
-        assert got == {4 * S: 18, 4 * S + 1: 34, 32 * S: 34, 32 * S + 1: 2}, got
+        got = {n: family(n) for n in (4 * S, 4 * S + 1, 16 * S, 16 * S + 1, 32 * S, 32 * S + 1)}
+        assert got == {4 * S: 18, 4 * S + 1: 34, 16 * S: 34, 16 * S + 1: 66, 32 * S: 66, 32 * S + 1: 2}, got
         torch.cuda.synchronize()
     finally:
         _lib.check(lib.capy_ed448_set_hardened(_lib.CAPY_HARDEN_PROTOCOL))
