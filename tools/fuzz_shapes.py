@@ -28,7 +28,7 @@ budget = float(os.environ.get("SECONDS", "240"))
 cap_bytes = int(os.environ.get("CAP_BYTES", str(6 << 30)))
 rng = random.Random(seed)
 DS = (224, 256, 384, 512)
-stats, failures, plans = {}, [], {}
+stats, failures, plans, crypt_kinds = {}, [], {}, {}
 
 
 def logn(lo, hi):
@@ -159,13 +159,19 @@ def op_encrypt():
     zs = fill(n * 512, rng.getrandbits(32))
     plain = fill(n * stride, rng.getrandbits(32))
     res = {}
-    for lanes in (0, rng.choice((1, 2, 1 | (1 << 16)))):
+    # the forced form is mostly the two-pass one (bit 16: no fused kernel at all), so that the fused kernels are compared with
+    # different code and not with themselves
+    for lanes in (0, rng.choice((2, 1 | (1 << 16), 1 | (1 << 16), 1 | (1 << 16)))):
         m = plain.clone()
         tags = torch.zeros(n * 64, dtype=torch.uint8, device=dev)
         rc = with_lanes(lanes, lambda: lib.capy_sha3_encrypt_batch_dev(d, n, pws.data_ptr(), pl, None, n * pl, zs.data_ptr(), m.data_ptr(), None,
                                                                        ln, stride, tags.data_ptr(), sp))
         torch.cuda.synchronize()
         res[lanes] = (rc, m, tags)
+        if lanes == 0:
+            k, l = C.c_int(0), C.c_int(0)
+            lib.capy_debug_last_sponge_kernel(C.byref(k), C.byref(l))
+            crypt_kinds[k.value] = crypt_kinds.get(k.value, 0) + 1
     (rc0, m0, t0), (rc1, m1, t1) = res[0], [v for k, v in res.items() if k != 0][0]
     same = rc0 == 0 and rc1 == 0 and torch.equal(m0, m1) and torch.equal(t0, t1)
     bad = []
@@ -204,6 +210,8 @@ while time.time() - t0 < budget:
         print("# %4.0f s: %s plans %s" % (last - t0, {k: v[0] for k, v in stats.items()}, dict(sorted(plans.items()))), flush=True)
 print("# fuzz_shapes seed %d, %.0f s on %s" % (seed, time.time() - t0, lib.capy_version().decode()))
 print("# capy_sha3_launch_plan kinds taken by the automatic choice (see include/capyhip.h):", dict(sorted(plans.items())))
+print("# sha3_encrypt schedules taken by the automatic choice (capy_debug_last_sponge_kernel: 20 / 21 / 22 four lanes per item, one wave per "
+      "item, four lanes in slices; 23 / 24 / 25 one lane per sponge: one launch, slices, rotating occupancy; 26 two passes):", dict(sorted(crypt_kinds.items())))
 for k in sorted(stats):
     print("%-30s calls %5d   failures %d" % (k, stats[k][0], stats[k][1]))
 print("# total calls %d, failures %d" % (sum(v[0] for v in stats.values()), len(failures)))
