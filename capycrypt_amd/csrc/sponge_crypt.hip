@@ -1,8 +1,8 @@
 // sponge_crypt.hip — the symmetric half of the encryptable traits on device buffers: sha3_encrypt / sha3_decrypt
 // (/root/reference/src/sha3/encryptable.rs:29-83), the sponge half of key_encrypt / key_decrypt (src/ecc/encryptable.rs:43-46,
 // 82-93) and of kem_encrypt / kem_decrypt (src/kem/encryptable.rs:55-57, 96-103), composed from the KMAC launches of
-// sponge_launch.hip or run in ONE pass by the fused kernels (sponge_fused.h: four lanes per item; sponge_wide.h: one wave per
-// item; sponge_fused1.h: one lane per sponge), with those kernels' schedules.  NO CPU fallback for the data path.
+// sponge_launch.hip or run in ONE pass by the fused kernels (sponge_fused.h: four lanes per item; sponge_wide_il.h: two waves
+// per item; sponge_fused1.h: one lane per sponge), with those kernels' schedules.  NO CPU fallback for the data path.
 #include <string.h>
 #include <algorithm>
 #include <string>
@@ -322,12 +322,11 @@ int symmetric_crypt_dev(bool encrypt, int d, size_t n, const uint8_t *keka, size
         fp.staged = (sponge_debug_flags() & 64) ? 1 : 0;  // A/B switch (debug bit 6)
         fp.paired = (n > fused_one_wave_items() && !fp.staged) ? 1 : 0;
         fp.n = n;
-        // One wave per item (sponge_wide.h) while every wave still has most of a SIMD pair's LDS bandwidth to itself:
-        // 1.3x per permutation at n = 128, break-even near one wave per SIMD (profiles/r02_wide_lane_probe.txt).
-        // Worth it only when the serial chains are long; debug bits 4 / 5: never / always (A/B and tests).
+        // Two waves per item (sponge_wide_il.h: a sponge spread over the lanes of a wave) while the batch leaves SIMDs idle
+        // anyway: 2.6 us per block instead of 4.8, at any message length; break-even with the four-lane kernel near two waves
+        // per SIMD (n = SIMDs).  Debug bits 4 / 5: never / for up to 4096 items (A/B and tests).
         {
             const unsigned dbg = sponge_debug_flags();
-            // any message length (r03: 1.3-2.0x the four-lane kernel from 64 B to 5 MiB at n <= 1024, profiles/r03_small_calls.txt)
             fp.wide = ((dbg & 32) && n <= 4096) || (!(dbg & 16) && n <= wide_max_items()) ? 1 : 0;
         }
         fp.tags = encrypt ? tags : tag2;
@@ -382,7 +381,7 @@ int symmetric_crypt_dev(bool encrypt, int d, size_t n, const uint8_t *keka, size
                 fp.sl_groups = 0;
             } else {
                 CAPY_HIP(launch_sponge_fused(ff.rw, fp, s));
-                note_kernel(fp.wide ? 21 : 20, 1);
+                note_kernel(fp.wide ? 27 : 20, 1);
             }
         }
         if (encrypt) return CAPY_OK;

@@ -40,7 +40,7 @@ struct FusedParams {
     uint32_t tag_len;
     uint32_t decrypt;
     const uint32_t *order;  // optional processing order, see SpongeParams::order
-    uint32_t wide;          // launcher's choice: 1 = one wave per item (sponge_wide.h), 0 = four lanes per item (here)
+    uint32_t wide;          // launcher's choice: 1 = two waves per item (sponge_wide_il.h), 0 = four lanes per item (here)
     uint32_t staged;        // A/B (debug bit 6): the round-1 form of this kernel, blocks staged through LDS
     uint32_t paired;        // launcher's choice: more than one wave per SIMD -> the blocked round with priority
     uint64_t n;

@@ -7,16 +7,7 @@ namespace capy {
 
 hipError_t launch_sponge_fused(int rw, const FusedParams &fp, hipStream_t s)
 {
-    if (fp.wide) {  // very small batches: one wave per item, a sponge spread over 25 lanes
-        const dim3 wgrid((unsigned)fp.n), wblock(64);
-        switch (rw) {
-        case 17: hipLaunchKernelGGL(sponge_wide_crypt_kernel<17>, wgrid, wblock, 0, s, fp); break;
-        case 19: hipLaunchKernelGGL(sponge_wide_crypt_kernel<19>, wgrid, wblock, 0, s, fp); break;
-        case 21: hipLaunchKernelGGL(sponge_wide_crypt_kernel<21>, wgrid, wblock, 0, s, fp); break;
-        default: return hipErrorInvalidValue;
-        }
-        return hipGetLastError();
-    }
+    if (fp.wide) return launch_sponge_il_crypt(rw, fp, s);  // very small batches: two waves per item (sponge_wide_il.h)
     const dim3 grid(fp.sl_groups ? fp.sl_grid : (unsigned)((fp.n + 15) / 16)), block(64);
     if (fp.staged) {
         switch (rw) {

@@ -23,7 +23,8 @@ void kmac_head(int d, size_t key_len, SpongeParams &p);
 unsigned device_simds();      // SIMDs of the current device (4 per compute unit)
 unsigned sponge_debug_flags();
 bool fused_enabled();          // capy_set_sponge_lanes bit 16 clear
-size_t wide_max_items();       // largest batch of the one-wave-per-item kernels
+size_t wide_max_items();
+       // largest batch of the one-wave-per-item kernels
 
 // test hook (capy_debug_last_sponge_kernel): what the calling thread's last launch took
 void note_kernel(int kind, int launches);

@@ -28,6 +28,10 @@ hipError_t launch_sponge_fused1_rot(int rw, const FusedParams &fp, unsigned cus,
 // digests of very small batches of long messages: two items per wave, a sponge spread over 25 lanes (sponge_wide.h);
 // rw in {9, 13, 17, 18, 19, 21}, digest mode only, no raw prefix bytes
 hipError_t launch_sponge_wide_digest(int rw, const SpongeParams &p, hipStream_t s);
+// the same with ONE item per wave and bit-interleaved Keccak lanes (sponge_wide_il.h): the shortest permutation, for batches
+// of at most one item per SIMD; the crypt form takes two waves per item (rw in {17, 19, 21}, the shapes of fp.wide)
+hipError_t launch_sponge_il_digest(int rw, const SpongeParams &p, hipStream_t s);
+hipError_t launch_sponge_il_crypt(int rw, const FusedParams &fp, hipStream_t s);
 // chip-full digest / XOF launches with wave-uniform framing (sponge_uniform.h); rw in {9, 13, 17, 18, 19, 21};
 // waves = 1..3: occupancy cap in waves per SIMD (A/B), else none
 hipError_t launch_sponge_uniform(int rw, const SpongeParams &p, int waves, hipStream_t s, unsigned sliced_grid = 0);

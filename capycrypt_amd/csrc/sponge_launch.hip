@@ -489,6 +489,19 @@ static int try_launch_uniform_sliced(int rw, const SpongeParams &p, int forced, 
     return 1;
 }
 
+// One item per wave with bit-interleaved Keccak lanes (sponge_wide_il.h) where the two-items-per-wave kernel would leave SIMDs
+// idle anyway: at most one item per SIMD.  Debug bit 11 / CAPY_DEBUG=wide_il=0: never (A/B and tests: the kernel of
+// sponge_wide.h, which otherwise only runs between one and two items per SIMD, then takes these batches too).
+static bool wide_il_enabled(unsigned dbg)
+{
+    static const bool on = debug_knob("wide_il", 1) != 0;
+    return on && !(dbg & 2048);
+}
+static bool il_digest_ok(int rw, const SpongeParams &p, int forced, unsigned dbg)
+{
+    return wide_digest_ok(rw, p, forced, dbg) && wide_il_enabled(dbg) && (p.n <= wide_max_items() || ((dbg & 32) && p.n <= 4096));
+}
+
 static int sponge_plan(int rw, const SpongeParams &p, int *phases)
 {
     const int forced = g_lanes_per_sponge.load();
@@ -496,6 +509,7 @@ static int sponge_plan(int rw, const SpongeParams &p, int *phases)
     *phases = 1;
     MixedPlan m;
     const unsigned dbg = g_debug_flags.load();
+    if (il_digest_ok(rw, p, forced, dbg)) return 10;
     if (wide_digest_ok(rw, p, forced, dbg)) return 6;
     if (uniform_kernel_ok(rw, p, forced, dbg, simds)) return 7;
     if ((forced == 3 || (forced == 0 && g_mixed_enabled.load())) && mixed_plan(rw, p, forced == 3, m)) {
@@ -605,7 +619,9 @@ static int launch_sponge(int rw, const SpongeParams &p, hipStream_t s)
     // permutation while every wave has most of a SIMD pair's LDS bandwidth to itself (n / 2 waves <= SIMDs / 2).
     // Debug bit 4 / 5: never / always.
     int kind = 1;
-    if (wide_digest_ok(rw, p2, forced, q.debug_flags))
+    if (il_digest_ok(rw, p2, forced, q.debug_flags))
+        kind = 10, e = launch_sponge_il_digest(rw, p2, s);
+    else if (wide_digest_ok(rw, p2, forced, q.debug_flags))
         kind = 6, e = launch_sponge_wide_digest(rw, p2, s);
     else if (forced == 2 || ((forced == 0 || forced == 3) && p.n <= 32 * simds))
         kind = 2, e = launch_sponge_k2(rw, (int)p.out_mode, p2, s);
@@ -882,7 +898,8 @@ int capy_set_sponge_lanes(int lanes)
 {
     // undocumented A/B switches in the high bits; bit 18 of the argument = debug bit 8 (no paired latency-tuned instance)
     // bit 19 = debug bit 9 (blocked two-lane round in forced two-lane launches); bit 20 = debug bit 10 (SPONGE_BLOCK_OUT)
-    g_debug_flags.store((((unsigned)lanes >> 8) & 0xff) | ((((unsigned)lanes >> 18) & 7) << 8));
+    // bit 21 = debug bit 11 (the wave-per-item kernels of sponge_wide.h instead of the bit-interleaved ones of sponge_wide_il.h)
+    g_debug_flags.store((((unsigned)lanes >> 8) & 0xff) | ((((unsigned)lanes >> 18) & 15) << 8));
     g_fused_enabled.store((((unsigned)lanes >> 16) & 1) == 0);  // bit 16: disable the fused encrypt kernel
     g_mixed_enabled.store((((unsigned)lanes >> 17) & 1) == 0);  // bit 17: disable the mixed one/two-lane schedule
     lanes &= 0xff;

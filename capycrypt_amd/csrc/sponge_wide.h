@@ -1,22 +1,21 @@
-// sponge_wide.h — sha3_encrypt / sha3_decrypt for VERY small batches of long messages: one WAVE per item.
+// sponge_wide.h — a sponge spread over 25 GPU lanes, one 64-bit Keccak lane per GPU lane, two sponges per wave: the digest
+// kernel for batches of up to two items per SIMD (sponge_wide_digest_kernel below), and the round primitives that the
+// bit-interleaved one-sponge-per-wave kernels of sponge_wide_il.h (batches of up to ONE item per SIMD, and every
+// sha3_encrypt / sha3_decrypt of that size) share.
 //
-// BASELINE config 3 as specified leaves 128 messages of 5 MiB per GPU: 256 sponges (tag + keystream), each a strict
-// chain of ~38 553 permutations, on a chip with 1024 SIMDs.  Nothing but the latency of one permutation matters
-// there.  The two-lane form of sponge_fused.h issues 120 VALU instructions per round per sponge pair (~4.8 us per
-// permutation); this kernel spreads a sponge over 25 lanes -- one 64-bit Keccak lane per GPU lane -- so that a round
-// is ~22 VALU instructions plus 14 ds_bpermute_b32 in two dependent LDS round trips (3.16 us per permutation, r03;
-// 3.7-3.8 us with 18 gathers in three trips in r02: tools/probe_wide.hip, profiles/r02_wide_lane_probe.txt,
-// profiles/r03_wide_round_probe.txt).
+// Such batches are nothing but serial chains -- the reference's own benches and tests hash ONE 5 MiB message at a time,
+// BASELINE config 3 as specified leaves 128 messages per GPU -- and only the latency of one permutation matters.  The
+// two-lane form of sponge_kernels_k2.h issues 120 VALU instructions per round (~4.8 us per permutation); here a round is
+// ~22 VALU instructions plus 14 ds_bpermute_b32 in two dependent LDS round trips (3.0 us per permutation; 3.7-3.8 us with
+// 18 gathers in three trips in r02: tools/probe_wide.hip, profiles/r02_wide_lane_probe.txt, profiles/r03_wide_round_probe.txt).
 //
-//   lanes  0..24   tag sponge        kmac_xof(ka, m, 8 tag_len, "..A")       Keccak lane i = x + 5y in GPU lane i
-//   lanes 32..56   keystream sponge  kmac_xof(ke, "", |m|, "..E") XOR m      same layout at lane offset 32
+//   lanes  0..24   item 2k        Keccak lane i = x + 5y in GPU lane i
+//   lanes 32..56   item 2k + 1    same layout at lane offset 32
 //   theta   column parity: 4 + 4 gathers from rows y+1..y+4, then C[x-1], C[x+1]: whole-wave DPP rotations by one lane
-//   rho     the lane's own rotation amount: v_alignbit_b32 with a VGPR shift, selects for >= 32 and for 0
+//   rho     the lane's own rotation amount: two 64-bit shifts by VGPR amounts
 //   pi+chi  B[x], B[x+1], B[x+2] gathered straight from the rho output (pi folded into the gather index): 3 + 3
-// Message blocks need no staging: GPU lane i < RW loads word i of the block (both sponges read the same 8 RW bytes),
-// the keystream lanes XOR and store, the tag lanes absorb.  Same FusedParams, framing restrictions (rate-aligned
-// KMAC framing, 8-byte aligned messages) and decrypt protocol as sponge_fused.h, bit-identical results; the launcher
-// picks this kernel when the batch is small enough that every wave still has a SIMD (almost) to itself.
+// (r02-r04 also had a sha3_encrypt kernel in this form, tag and keystream sponge side by side in one wave; the two-wave kernel
+// of sponge_wide_il.h is 1.03-1.24x faster at every batch size it was taken for and replaced it in r05.)
 #pragma once
 #include "sponge_fused.h"
 
@@ -158,171 +157,6 @@ __device__ __forceinline__ void wide_permute(uint32_t &lo, uint32_t &hi, const W
     lo = wide_bperm(w.self, lo);
     hi = wide_bperm(w.self, hi);
     wide_permute_impl(lo, hi, w, std::make_integer_sequence<int, 24>{});
-}
-
-template <int RW>
-__global__ __launch_bounds__(64) CAPY_WAVES_PER_SIMD(1) void sponge_wide_crypt_kernel(const FusedParams fp)
-{
-    constexpr uint32_t RB = RW * 8;
-    const uint32_t lane = threadIdx.x, role = lane >> 5, i = lane & 31;  // role 0 = tag sponge, 1 = keystream sponge
-    const bool word_lane = i < (uint32_t)RW;                              // this lane owns word i of every block
-    const uint64_t slot = blockIdx.x;
-    if (slot >= fp.n) return;
-    const uint64_t item = fp.order ? (uint64_t)fp.order[slot] : slot;
-    const WideIdx w = wide_setup();
-
-    // the generic stream machinery (sponge_params.h) describes both sponges: tag = head || msg || 00 01 04 || pad,
-    // keystream = head || 00 01 04 || pad
-    SpongeParams p;
-    p.pre = nullptr;
-    p.pre_len = 0;
-    p.key_offsets = nullptr;
-    p.key_len = fp.key_len;
-    p.hdr_len = fp.hdr_len;
-    p.hdr0 = fp.hdr0;
-    p.hdr1 = fp.hdr1;
-    p.head_len = fp.head_len;
-    p.suffix = 0x040100ULL;
-    p.suffix_len = 3;
-    p.fips_pad = 0;
-    p.stride_bytes = RB;
-
-    uint64_t tgt_len;
-    uint8_t *msg;
-    if (fp.offsets) {
-        const uint64_t o0 = fp.offsets[item];
-        tgt_len = fp.lens ? fp.lens[item] : fp.offsets[item + 1] - o0;
-        msg = fp.msgs + o0;
-    } else {
-        tgt_len = fp.uniform_len;
-        msg = fp.msgs + item * fp.msg_stride;
-    }
-    ItemCtx c;
-    c.msg = msg;
-    c.key = fp.keka + item * fp.keka_stride + (role == 0 ? fp.ka_offset : 0);
-    c.key_len = fp.key_len;
-    c.hdr_len = fp.hdr_len;
-    c.hdr0 = fp.hdr0;
-    c.hdr1 = fp.hdr1;
-    c.head_len = fp.head_len;
-    c.len = 0;  // the keystream sponge's view; the tag sponge's message blocks are absorbed directly below
-    c.suffix = p.suffix;
-    {
-        const uint64_t total = (uint64_t)fp.head_len + 3;
-        const uint32_t rem = (uint32_t)(total % RB);
-        c.pad80 = rem != 0;
-        c.padded = rem ? total + (RB - rem) : total;
-    }
-    const uint32_t hb = fp.head_len / RB;
-
-    uint32_t lo = 0, hi = 0;
-#pragma unroll
-    for (int k = 0; k < 25; k++) {
-        const uint64_t v = role ? fp.init_ks[k] : fp.init_tag[k];
-        if (i == (uint32_t)k) {
-            lo = (uint32_t)v;
-            hi = (uint32_t)(v >> 32);
-        }
-    }
-    auto absorb = [&](uint64_t v) {
-        lo ^= (uint32_t)v;
-        hi ^= (uint32_t)(v >> 32);
-    };
-
-    // ---- heads of both sponges, then the keystream sponge's only other block (00 01 04 || pad); the tag lanes keep
-    // their state across that step (the permutation is wave-wide)
-    for (uint32_t b = 0; b < hb; b++) {
-        if (word_lane) absorb(stream_word(p, c, (uint64_t)b * RB + 8 * i));
-        wide_permute(lo, hi, w);
-    }
-    {
-        const uint32_t klo = lo, khi = hi;
-        if (word_lane && role == 1) absorb(stream_word(p, c, (uint64_t)hb * RB + 8 * i));
-        wide_permute(lo, hi, w);
-        if (role == 0) {
-            lo = klo;
-            hi = khi;
-        }
-    }
-    // from here on the keystream sponge's state IS keystream block 0
-
-    // ---- full blocks: one pass, block t+1 in flight while block t is permuted
-    const uint32_t nfull = (uint32_t)(tgt_len / RB);
-    const uint32_t partner = 4 * (lane ^ 32);
-    uint8_t *my = msg + 8 * i;
-    uint64_t pf = 0;
-    if (nfull && word_lane) pf = load_global_u64(my);
-    for (uint32_t t = 0; t < nfull; t++) {
-        const uint64_t in = pf;
-        if (t + 1 < nfull && word_lane) pf = load_global_u64(my + (uint64_t)(t + 1) * RB);
-        const uint64_t out = in ^ (((uint64_t)hi << 32) | lo);  // meaningful in the keystream lanes
-        if (word_lane && role == 1) store_global_u64(my + (uint64_t)t * RB, out);
-        uint64_t plain = in;
-        if (fp.decrypt) {  // wave-uniform: the tag sponge absorbs the PLAINTEXT = what the keystream lanes just produced
-            const uint32_t pl = wide_bperm(partner, (uint32_t)out), ph = wide_bperm(partner, (uint32_t)(out >> 32));
-            plain = ((uint64_t)ph << 32) | pl;
-        }
-        if (word_lane && role == 0) absorb(plain);
-        wide_permute(lo, hi, w);
-    }
-
-    // ---- tail: fewer than RB message bytes remain.  The keystream lanes XOR and store them and hand the plaintext
-    // words to the tag lanes through a lane exchange (never through memory another lane has just written).
-    const uint64_t pos = (uint64_t)nfull * RB;
-    const uint32_t left = (uint32_t)(tgt_len - pos);
-    uint64_t tail_plain = 0;
-    {
-        uint64_t in = 0, vmask = 0;
-        const uint32_t at = 8 * i;
-        if (word_lane && at < left) {
-            in = load_global_u64(my + pos);  // reads at most 7 bytes past the end of an 8-byte aligned message
-            const uint32_t nvalid = left - at < 8 ? left - at : 8;
-            vmask = nvalid >= 8 ? ~0ULL : ((1ULL << (8 * nvalid)) - 1ULL);
-            in &= vmask;
-        }
-        const uint64_t out = (in ^ (((uint64_t)hi << 32) | lo)) & vmask;
-        if (word_lane && role == 1 && at < left) {
-            if (vmask == ~0ULL) {
-                store_global_u64(my + pos, out);
-            } else {
-                for (uint32_t b = 0; b < 8 && at + b < left; b++) my[pos + b] = (uint8_t)(out >> (8 * b));
-            }
-        }
-        const uint64_t mine = fp.decrypt ? out : in;
-        const uint32_t pl = wide_bperm(partner, (uint32_t)mine), ph = wide_bperm(partner, (uint32_t)(mine >> 32));
-        tail_plain = ((uint64_t)ph << 32) | pl;  // tag lane i: plaintext word i of the tail (zero beyond `left`)
-    }
-    {
-        // tag sponge: plaintext tail || 00 01 04 || 0* [80]   (1 or 2 blocks); the keystream state is no longer needed
-        const uint32_t tl = left + 3;
-        const uint32_t cnt = (tl + RB - 1) / RB;
-        const bool pad80 = (tl % RB) != 0;
-        for (uint32_t j = 0; j < cnt; j++) {
-            if (word_lane && role == 0) {
-                uint64_t v = j == 0 ? tail_plain : 0;
-#pragma unroll
-                for (int b = 0; b < 8; b++) {
-                    const uint32_t rel = j * RB + 8 * i + b;
-                    uint64_t byte = 0;
-                    if (rel >= left && rel - left < 3) byte = (0x040100u >> (8 * (rel - left))) & 0xff;
-                    if (pad80 && rel + 1 == cnt * RB) byte |= 0x80;
-                    v |= byte << (8 * b);
-                }
-                absorb(v);
-            }
-            wide_permute(lo, hi, w);
-        }
-    }
-
-    // ---- tag
-    if (role == 0 && 8 * i + 8 <= fp.tag_len) {
-        uint8_t *o = fp.tags + item * fp.tag_stride + 8 * i;
-        const uint64_t v = ((uint64_t)hi << 32) | lo;
-        if ((((uintptr_t)o) & 7) == 0)
-            store_global_u64(o, v);
-        else
-            for (int b = 0; b < 8; b++) o[b] = (uint8_t)(v >> (8 * b));
-    }
 }
 
 }  // namespace capy

@@ -135,9 +135,11 @@ int capy_debug_last_curve_kernel(int *variable_base, int *fixed_base);
 /* Test hook: which sponge kernel / schedule the calling thread's last digest or encrypt / decrypt launch took, and in how many
  * launches of the data pass (phases, time slices).  kind: 1 one lane per sponge (latency-tuned), 2 two lanes per sponge,
  * 3 rotating one-/two-lane schedule, 4 one lane per sponge (issue-tuned), 5 wave-quantisation split, 6 one wave per item,
- * 7 uniform-framing kernel, 8 rotating-occupancy schedule, 9 uniform-framing kernel in time slices; sha3_encrypt / decrypt and
- * the other symmetric halves: 20 four lanes per item, 21 one wave per item, 22 four lanes per item in time slices, 23 one lane
- * per sponge (two lanes per item), 24 the same in time slices, 25 the same on the rotating-occupancy schedule, 26 two passes;
+ * 7 uniform-framing kernel, 8 rotating-occupancy schedule, 9 uniform-framing kernel in time slices, 10 one wave per item with
+ * bit-interleaved Keccak lanes; sha3_encrypt / decrypt and
+ * the other symmetric halves: 20 four lanes per item, (21 one wave per item: r02-r04, replaced by 27), 22 four lanes per item in time slices, 23 one lane
+ * per sponge (two lanes per item), 24 the same in time slices, 25 the same on the rotating-occupancy schedule, 26 two passes,
+ * 27 two waves per item with bit-interleaved Keccak lanes;
  * 0 = none yet.  Lets the tests assert that the path they mean to cover is the one that ran. */
 int capy_debug_last_sponge_kernel(int *kind, int *launches);
 /* Test hook for the CPU pinning of the per-device workers (pure host arithmetic, no GPU needed): parses `local_cpulist`
@@ -395,7 +397,9 @@ int capy_set_sponge_lanes(int lanes);
  * 6 sponge_wide_digest_kernel<RW> (two items per wave: batches of up to two items per SIMD, any message length),
  * 7 sponge_uniform_kernel<RW> (more than 128 items per SIMD, wave-uniform framing: csrc/sponge_uniform.h; long messages just
  *   above a whole number of waves per SIMD run as a sequence of time-sliced launches of it, still reported as 7),
- * 8 sponge_rot_kernel<RW> launched *phases times (between 64 and 128 items per SIMD, long messages: csrc/sponge_rot.h). */
+ * 8 sponge_rot_kernel<RW> launched *phases times (between 64 and 128 items per SIMD, long messages: csrc/sponge_rot.h),
+ * 10 sponge_il_digest_kernel<RW> (one item per wave, bit-interleaved Keccak lanes: batches of up to one item per SIMD;
+ *   csrc/sponge_wide_il.h). */
 int capy_sha3_launch_plan(int d, size_t n, uint64_t uniform_len, uint64_t msg_stride, int *kind, int *phases);
 /* Fill a device buffer with the harness PRNG (SplitMix64 counter mode, seed + 8-byte word index). */
 int capy_fill_random_dev(uint8_t *dst, uint64_t nbytes, uint64_t seed, void *stream);

@@ -30,14 +30,15 @@ def O():
     return oracle
 
 
-@pytest.fixture(autouse=True, params=[1, 2, 1 | (1 << 16), 2 | (1 << 8), 2 | (32 << 8), 1 | (64 << 8)],
+@pytest.fixture(autouse=True, params=[1, 2, 1 | (1 << 16), 2 | (1 << 8), 2 | (32 << 8), 1 | (64 << 8), 2 | (32 << 8) | (1 << 21)],
                 ids=["lane-per-sponge", "two-lanes-per-sponge", "lane-per-sponge,two-pass-encrypt",
-                     "two-lanes,no-uniform-addressing", "wave-per-item-kernels", "lane-per-sponge,lds-staged-loads"])
+                     "two-lanes,no-uniform-addressing", "wave-per-item-kernels", "lane-per-sponge,lds-staged-loads",
+                     "wave-per-item-kernels,two-items-per-wave-digests"])
 def sponge_lanes(request):
     """Every test runs against both sponge kernels (sponge_kernels.h / sponge_kernels_k2.h), with the fused
     one-pass encrypt kernel (sponge_fused.h) on and off, with the wave-uniform addressing path off, and with the
-    one-wave-per-item kernels (sponge_wide.h: encrypt / decrypt and digests) forced for every batch of up to 4096 items
-    they can take, and with the wave-cooperative loads through LDS of round 1 (debug bit 6; the default is per-lane loads)."""
+    one-wave-per-item kernels (sponge_wide_il.h: bit-interleaved, encrypt / decrypt and digests; with bit 21 the
+    two-items-per-wave digest kernel of sponge_wide.h instead) forced for every batch of up to 4096 items they can take, and with the wave-cooperative loads through LDS of round 1 (debug bit 6; the default is per-lane loads)."""
     from capycrypt_amd import _lib
 
     global _CURRENT_LANES

@@ -210,8 +210,8 @@ while time.time() - t0 < budget:
         print("# %4.0f s: %s plans %s" % (last - t0, {k: v[0] for k, v in stats.items()}, dict(sorted(plans.items()))), flush=True)
 print("# fuzz_shapes seed %d, %.0f s on %s" % (seed, time.time() - t0, lib.capy_version().decode()))
 print("# capy_sha3_launch_plan kinds taken by the automatic choice (see include/capyhip.h):", dict(sorted(plans.items())))
-print("# sha3_encrypt schedules taken by the automatic choice (capy_debug_last_sponge_kernel: 20 / 21 / 22 four lanes per item, one wave per "
-      "item, four lanes in slices; 23 / 24 / 25 one lane per sponge: one launch, slices, rotating occupancy; 26 two passes):", dict(sorted(crypt_kinds.items())))
+print("# sha3_encrypt schedules taken by the automatic choice (capy_debug_last_sponge_kernel: 20 / 22 four lanes per item, the same in "
+      "slices; 23 / 24 / 25 one lane per sponge: one launch, slices, rotating occupancy; 26 two passes; 27 two waves per item):", dict(sorted(crypt_kinds.items())))
 for k in sorted(stats):
     print("%-30s calls %5d   failures %d" % (k, stats[k][0], stats[k][1]))
 print("# total calls %d, failures %d" % (sum(v[0] for v in stats.values()), len(failures)))

@@ -300,6 +300,29 @@ def wide_split():
     return L
 
 
+def wide_interleaved():
+    """ONE sponge per wave with every 64-bit Keccak lane BIT-INTERLEAVED (r05): GPU lanes 0..24 hold the even bits, 32..56 the
+    odd bits.  A 64-bit rotation is then a 32-bit rotation of each half by a lane constant, with the halves changing places for
+    odd amounts -- which the pi gather's index absorbs.  Only theta's rol(C[x+1], 1) still needs the other half: one
+    v_permlane32_swap of two copies + a select.  12 VALU + 7 ds_bpermute per round."""
+    L = []
+    full = "row_mask:0xf bank_mask:0xf"
+    for k in range(4):
+        L.append(f"ds_bpermute_b32 v{10 + k}, v{40 + k}, v8")
+    L.append("s_waitcnt lgkmcnt(0)")
+    L += ["v_bitop3_b32 v18, v8, v10, v11 bitop3:0x96", "v_bitop3_b32 v18, v18, v12, v13 bitop3:0x96"]
+    L += ["s_nop 1", f"v_mov_b32_dpp v20, v18 wave_ror:1 {full}", f"v_mov_b32_dpp v22, v18 wave_rol:1 {full}",
+          f"v_mov_b32_dpp v23, v18 wave_rol:1 {full}",
+          "s_nop 1", "v_permlane32_swap_b32 v22, v23", "v_bitop3_b32 v22, v22, v23, v38 bitop3:0xca",
+          "v_alignbit_b32 v24, v22, v22, v46"]
+    L += ["v_bitop3_b32 v26, v8, v20, v24 bitop3:0x96", "v_alignbit_b32 v26, v26, v26, v47"]
+    for k in range(3):
+        L.append(f"ds_bpermute_b32 v{10 + k}, v{48 + k}, v26")
+    L.append("s_waitcnt lgkmcnt(0)")
+    L += ["v_bitop3_b32 v8, v10, v11, v12 bitop3:0xd2", "v_xor_b32 v8, v8, v36"]
+    return L
+
+
 kernels = []  # (ident, label, lines, count)
 for i, op in enumerate(OPS):
     lines = block(op, 512)
@@ -311,7 +334,8 @@ for i, (label, spec) in enumerate(MIXES.items()):
 for ident, label, fn in (("wide0", "wide round today (18 bpermute, 3 trips) x8 [rounds]", wide_today),
                          ("wide1", "wide round proposed (DPP + permlane swaps, 2 bpermute) x8 [rounds]", wide_proposed),
                          ("wide2", "wide round, trip 2 by wave_ror/rol DPP (14 bpermute, 2 trips) x8 [rounds]", wide_dpp_theta),
-                         ("wide3", "one sponge per wave, lo/hi words in the wave's halves (7 bpermute, 2 permlane32_swap) x8 [rounds]", wide_split)):
+                         ("wide3", "one sponge per wave, lo/hi words in the wave's halves (7 bpermute, 2 permlane32_swap) x8 [rounds]", wide_split),
+                         ("wide4", "one sponge per wave, bit-interleaved halves (7 bpermute, 1 permlane32_swap, 12 VALU) x8 [rounds]", wide_interleaved)):
     kernels.append((ident, label, fn() * 8, 8))  # count = rounds per trip: the table then reads ns and cycles PER ROUND
 
 out = []
