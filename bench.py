@@ -834,7 +834,7 @@ def main():
     kname = {1: "sponge_kernel<17, false, 0>", 2: "sponge_kernel_k2<17, 0>", 3: "sponge_mixed_kernel<17>",
              4: "sponge_kernel<17, true, 0>",
              5: "sponge_kernel<17, false, 0> head + remainder (wave-quantisation split)",
-             6: "sponge_wide_digest_kernel<17>", 7: "sponge_uniform_kernel<17>", 8: "sponge_rot_kernel<17>"}[kind.value]
+             10: "sponge_il_digest_kernel<17>", 7: "sponge_uniform_kernel<17>", 8: "sponge_rot_kernel<17>"}[kind.value]
     launches = phases.value if kind.value != 5 else 1  # a split launch is priced as one step-long launch
 
     # HBM traffic of the dominant kernel: PMC counters cannot be collected from inside the timed process, so the

@@ -33,7 +33,7 @@ double debug_knob(const char *key, double dflt)
         static const char *known[] = {"fused_max", "wide_max", "mixed_ratio", "uniform_waves", "ed448_pair", "ed448_wave_max",
                                       "host_overlap", "host_arena", "worker_affinity", "rot", "rot_ratio", "ed448_quad_min", "ed448_quad_max",
                                       "ed448_duo_min", "ed448_duo_max", "ed448_quad_ct_max", "ed448_peel", "fused_slices", "uniform_slices",
-                                      "fused1_min", "fused1_form", "fused1_waves", "fused1_direct", "fused1_slices", "fused1_rot", "fused1_ratio", "fused1_turns", "fused1_store", "fused1_lone_direct", "fused1_level", "ed448_duo_ct", "wide_il"};
+                                      "fused1_min", "fused1_form", "fused1_waves", "fused1_direct", "fused1_slices", "fused1_rot", "fused1_ratio", "fused1_turns", "fused1_store", "fused1_lone_direct", "fused1_level", "ed448_duo_ct"};
         const char *e = getenv("CAPY_DEBUG");
         std::string txt = e ? e : "";
         size_t pos = 0;

@@ -1,5 +1,5 @@
 // sponge_fused.h — sha3_encrypt / sha3_decrypt in ONE pass over the message, four lanes per item: batches of up to 32 items per SIMD
-// (beyond: one lane per sponge, sponge_fused1.h; up to one item per SIMD: one wave per item, sponge_wide.h).
+// (beyond: one lane per sponge, sponge_fused1.h; up to one item per SIMD: two waves per item, sponge_wide_il.h).
 //
 // The reference computes, per message (src/sha3/encryptable.rs:39-42 and :71-75),
 //     t = kmac_xof(ka, m, 512, "SKA")          -- absorbs the whole plaintext

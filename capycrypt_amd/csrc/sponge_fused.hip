@@ -1,6 +1,5 @@
 // sponge_fused.hip — instances of sponge_fused_crypt_kernel<RW> (see sponge_fused.h)
 #include "sponge_fused.h"
-#include "sponge_wide.h"
 #include "sponge_launch.h"
 
 namespace capy {
@@ -34,21 +33,6 @@ hipError_t launch_sponge_fused(int rw, const FusedParams &fp, hipStream_t s)
     case 17: hipLaunchKernelGGL(sponge_fused_crypt_kernel<17>, grid, block, 0, s, fp); break;
     case 19: hipLaunchKernelGGL(sponge_fused_crypt_kernel<19>, grid, block, 0, s, fp); break;
     case 21: hipLaunchKernelGGL(sponge_fused_crypt_kernel<21>, grid, block, 0, s, fp); break;
-    default: return hipErrorInvalidValue;
-    }
-    return hipGetLastError();
-}
-
-hipError_t launch_sponge_wide_digest(int rw, const SpongeParams &p, hipStream_t s)
-{
-    const dim3 grid((unsigned)((p.n + 1) / 2)), block(64);
-    switch (rw) {
-    case 9: hipLaunchKernelGGL(sponge_wide_digest_kernel<9>, grid, block, 0, s, p); break;
-    case 13: hipLaunchKernelGGL(sponge_wide_digest_kernel<13>, grid, block, 0, s, p); break;
-    case 17: hipLaunchKernelGGL(sponge_wide_digest_kernel<17>, grid, block, 0, s, p); break;
-    case 18: hipLaunchKernelGGL(sponge_wide_digest_kernel<18>, grid, block, 0, s, p); break;
-    case 19: hipLaunchKernelGGL(sponge_wide_digest_kernel<19>, grid, block, 0, s, p); break;
-    case 21: hipLaunchKernelGGL(sponge_wide_digest_kernel<21>, grid, block, 0, s, p); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -25,11 +25,9 @@ hipError_t launch_sponge_fused(int rw, const FusedParams &fp, hipStream_t s);
 // the same with ONE lane per sponge, two lanes per item, for chip-filling batches (sponge_fused1.h); fp.one_lane = the instance
 hipError_t launch_sponge_fused1(int rw, const FusedParams &fp, hipStream_t s);
 hipError_t launch_sponge_fused1_rot(int rw, const FusedParams &fp, unsigned cus, hipStream_t s);
-// digests of very small batches of long messages: two items per wave, a sponge spread over 25 lanes (sponge_wide.h);
-// rw in {9, 13, 17, 18, 19, 21}, digest mode only, no raw prefix bytes
-hipError_t launch_sponge_wide_digest(int rw, const SpongeParams &p, hipStream_t s);
-// the same with ONE item per wave and bit-interleaved Keccak lanes (sponge_wide_il.h): the shortest permutation, for batches
-// of at most one item per SIMD; the crypt form takes two waves per item (rw in {17, 19, 21}, the shapes of fp.wide)
+// very small batches: one item per wave, the sponge spread over the wave's lanes with bit-interleaved Keccak lanes
+// (sponge_wide_il.h).  Digests: rw in {9, 13, 17, 18, 19, 21}, digest mode only, no raw prefix bytes; the crypt form takes two
+// waves per item (rw in {17, 19, 21}, fp.wide)
 hipError_t launch_sponge_il_digest(int rw, const SpongeParams &p, hipStream_t s);
 hipError_t launch_sponge_il_crypt(int rw, const FusedParams &fp, hipStream_t s);
 // chip-full digest / XOF launches with wave-uniform framing (sponge_uniform.h); rw in {9, 13, 17, 18, 19, 21};

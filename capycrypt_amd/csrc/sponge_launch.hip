@@ -172,11 +172,11 @@ void note_kernel(int kind, int launches)
 //                    latency-tuned instance
 
 static std::atomic<bool> g_mixed_enabled{true};
-// largest batch that takes the one-wave-per-item encrypt kernel: one wave per SIMD (the digest kernel holds two items per
-// wave, so twice as many).  Measured r03 with the DPP theta (profiles/r03_wide_round_probe.txt): at one wave per SIMD the
-// wave-per-item kernels still win 1.2-1.3x (1024 x 5 MiB encrypt 0.163 s vs 0.211, 2048 x 5 MiB digest 0.164 vs 0.198),
-// at 1.5 waves per SIMD they lose (0.88x).  CAPY_DEBUG=wide_max=N overrides
 
+// largest batch that takes the wave-per-item encrypt kernel (sponge_wide_il.h, two waves per item): one item per SIMD; the
+// digest kernel (one wave per item) takes twice as many -- two waves per SIMD either way.  profiles/r05_wide_interleaved.txt:
+// 1024 x 5 MiB encrypt 0.156 s against 0.207 for the four-lane kernel (1280: 0.198, 1536: 0.237); 2048 x 5 MiB SHA3-256 0.149
+// against 0.197 for the two-lane kernel (3072: 0.228).  CAPY_DEBUG=wide_max=N overrides
 // SIMDs of the current device (4 per CU)
 unsigned device_simds()
 {
@@ -407,7 +407,7 @@ static int uniform_waves()
 }
 
 // The conditions under which launch_sponge() takes the uniform-framing kernel (sponge_uniform.h) / the wave-per-item
-// digest kernel (sponge_wide.h) -- shared with sponge_plan(), so that capy_sha3_launch_plan reports the kernel that
+// digest kernel (sponge_wide_il.h) -- shared with sponge_plan(), so that capy_sha3_launch_plan reports the kernel that
 // really runs.  p.order must already hold the device-side processing order if one is used.  Debug bit 7: never.
 static bool uniform_kernel_ok(int rw, const SpongeParams &p, int forced, unsigned dbg, size_t simds)
 {
@@ -426,9 +426,8 @@ static bool uniform_kernel_ok(int rw, const SpongeParams &p, int forced, unsigne
 static bool wide_digest_ok(int rw, const SpongeParams &p, int forced, unsigned dbg)
 {
     const bool shape_ok = p.out_mode == 0 && p.pre_len == 0 && p.stride_bytes == (uint32_t)rw * 8 && !p.resume_state && !p.head_state;
-    // any message length: measured r03 (profiles/r03_small_calls.txt), KMACXOF256 of 64 B / 1 KiB / 16 KiB messages at
-    // n <= 2048: 0.029 -> 0.015, 0.066 -> 0.038, 0.645 -> 0.394 ms against the two-lane kernel (r02 took this kernel for
-    // messages of at least 64 KiB only)
+    // any message length: measured r03 with that round's wave-per-item kernel (profiles/r03_small_calls.txt), KMACXOF256 of
+    // 64 B / 1 KiB / 16 KiB messages at n <= 2048: 0.029 -> 0.015, 0.066 -> 0.038, 0.645 -> 0.394 ms against the two-lane kernel
     return shape_ok && (((dbg & 32) && p.n <= 4096) ||
                         (forced == 0 && !(dbg & 16) && p.n <= 2 * wide_max_items()));
 }
@@ -489,19 +488,6 @@ static int try_launch_uniform_sliced(int rw, const SpongeParams &p, int forced, 
     return 1;
 }
 
-// One item per wave with bit-interleaved Keccak lanes (sponge_wide_il.h) where the two-items-per-wave kernel would leave SIMDs
-// idle anyway: at most one item per SIMD.  Debug bit 11 / CAPY_DEBUG=wide_il=0: never (A/B and tests: the kernel of
-// sponge_wide.h, which otherwise only runs between one and two items per SIMD, then takes these batches too).
-static bool wide_il_enabled(unsigned dbg)
-{
-    static const bool on = debug_knob("wide_il", 1) != 0;
-    return on && !(dbg & 2048);
-}
-static bool il_digest_ok(int rw, const SpongeParams &p, int forced, unsigned dbg)
-{
-    return wide_digest_ok(rw, p, forced, dbg) && wide_il_enabled(dbg) && (p.n <= wide_max_items() || ((dbg & 32) && p.n <= 4096));
-}
-
 static int sponge_plan(int rw, const SpongeParams &p, int *phases)
 {
     const int forced = g_lanes_per_sponge.load();
@@ -509,8 +495,7 @@ static int sponge_plan(int rw, const SpongeParams &p, int *phases)
     *phases = 1;
     MixedPlan m;
     const unsigned dbg = g_debug_flags.load();
-    if (il_digest_ok(rw, p, forced, dbg)) return 10;
-    if (wide_digest_ok(rw, p, forced, dbg)) return 6;
+    if (wide_digest_ok(rw, p, forced, dbg)) return 10;
     if (uniform_kernel_ok(rw, p, forced, dbg, simds)) return 7;
     if ((forced == 3 || (forced == 0 && g_mixed_enabled.load())) && mixed_plan(rw, p, forced == 3, m)) {
         *phases = (int)m.P;
@@ -615,14 +600,12 @@ static int launch_sponge(int rw, const SpongeParams &p, hipStream_t s)
         note_kernel(7, 1);
         return CAPY_OK;
     }
-    // Very small digest batches of long messages: one sponge per 25 lanes (sponge_wide.h), 1.3x the two-lane kernel per
-    // permutation while every wave has most of a SIMD pair's LDS bandwidth to itself (n / 2 waves <= SIMDs / 2).
-    // Debug bit 4 / 5: never / always.
+    // Very small digest batches: one wave per item (sponge_wide_il.h), 2.5 us per permutation against 4.8 for the two-lane
+    // kernel; up to two waves per SIMD (SHA3-256 of 5 MiB messages: 0.097 s for up to 256 items, 0.111 at 1024, 0.149 at 2048;
+    // two-lane kernel 0.197).  Debug bit 4 / 5: never / for up to 4096 items.
     int kind = 1;
-    if (il_digest_ok(rw, p2, forced, q.debug_flags))
+    if (wide_digest_ok(rw, p2, forced, q.debug_flags))
         kind = 10, e = launch_sponge_il_digest(rw, p2, s);
-    else if (wide_digest_ok(rw, p2, forced, q.debug_flags))
-        kind = 6, e = launch_sponge_wide_digest(rw, p2, s);
     else if (forced == 2 || ((forced == 0 || forced == 3) && p.n <= 32 * simds))
         kind = 2, e = launch_sponge_k2(rw, (int)p.out_mode, p2, s);
     // ragged batches stay on the latency-tuned instance at every size: its ragged path keeps the source pointers in
@@ -898,8 +881,7 @@ int capy_set_sponge_lanes(int lanes)
 {
     // undocumented A/B switches in the high bits; bit 18 of the argument = debug bit 8 (no paired latency-tuned instance)
     // bit 19 = debug bit 9 (blocked two-lane round in forced two-lane launches); bit 20 = debug bit 10 (SPONGE_BLOCK_OUT)
-    // bit 21 = debug bit 11 (the wave-per-item kernels of sponge_wide.h instead of the bit-interleaved ones of sponge_wide_il.h)
-    g_debug_flags.store((((unsigned)lanes >> 8) & 0xff) | ((((unsigned)lanes >> 18) & 15) << 8));
+    g_debug_flags.store((((unsigned)lanes >> 8) & 0xff) | ((((unsigned)lanes >> 18) & 7) << 8));
     g_fused_enabled.store((((unsigned)lanes >> 16) & 1) == 0);  // bit 16: disable the fused encrypt kernel
     g_mixed_enabled.store((((unsigned)lanes >> 17) & 1) == 0);  // bit 17: disable the mixed one/two-lane schedule
     lanes &= 0xff;

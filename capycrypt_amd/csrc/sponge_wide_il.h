@@ -1,33 +1,59 @@
-// sponge_wide_il.h — the one-wave-per-sponge kernels with BIT-INTERLEAVED Keccak lanes: the shortest permutation this
-// library has, for batches so small that nothing but the latency of one permutation matters (BASELINE config 3 as
-// specified: 128 messages of 5 MiB per GPU; the reference's own benches and tests: ONE 5 MiB message at a time,
-// benches/benchmark_sha3.rs:11-19, tests/integration_tests.rs:62-81).
+// sponge_wide_il.h — one WAVE per sponge, the 1600-bit state spread over the wave's lanes with BIT-INTERLEAVED Keccak lanes:
+// the shortest permutation this library has, for batches so small that nothing but the latency of one permutation matters
+// (BASELINE config 3 as specified: 128 messages of 5 MiB per GPU; the reference's own benches and tests: ONE 5 MiB message
+// at a time, benches/benchmark_sha3.rs:11-19, tests/integration_tests.rs:62-81).  The lane-per-sponge kernels need 4320
+// dependent-issue VALU instructions per permutation (7.4 us in a lone wave), the two-lane form 2880 (4.8 us).
 //
-// sponge_wide.h puts one 64-bit Keccak lane into one GPU lane (two VGPRs) and two sponges into a wave: 22 VALU + 14
-// ds_bpermute per round, 337 cycles.  Here a wave holds ONE sponge and a Keccak lane is split by bit parity:
+// r02-r04 (sponge_wide.h, gone): one 64-bit Keccak lane per GPU lane in two VGPRs, two sponges per wave (lanes 0..24 and
+// 32..56): 22 VALU + 14 ds_bpermute per round in two dependent LDS round trips, 3.0 us per permutation.  Here a wave holds ONE
+// sponge and a Keccak lane is split by bit parity:
 //   GPU lanes  0..24   the even bits (0, 2, .. 62) of Keccak lane i = x + 5y, as one 32-bit word
 //   GPU lanes 32..56   the odd bits
-// A 64-bit rotation by r is then a 32-bit rotation of each half by a lane constant -- r = 2k: both halves by k; r = 2k + 1:
-// the odd half by k + 1 BECOMES the even half, the even half by k becomes the odd one -- and that exchange costs nothing:
-// the pi gather simply reads the other half's lane.  Every bitwise step works on a half alone; only theta's
-// rol(C[x+1], 1) needs the partner half of a DIFFERENT lane's value: one v_permlane32_swap_b32 (new on gfx950) of two
-// copies + a select.  Per round: 12 VALU + 7 ds_bpermute in the same two LDS round trips,
-//   247 cycles with one wave per CU, 282 with one per SIMD (sponge_wide.h: 337 / 442) -- timing skeletons,
-//   tools/gen_valu_census.py wide4, profiles/r05_wide_interleaved.txt.
-// Message words enter and leave through a 16-instruction bit (de)interleave per 32-bit half and one more lane swap; both
-// sit beside the permutation's dependency chain (the next block is converted while the LDS gathers of this one are in flight).
+//   theta   column parity: 4 gathers from rows y+1..y+4 of the same half; C[x-1], C[x+1] by whole-wave DPP rotations by one
+//           lane (C does not depend on y, so lane i -+ 1 of the x + 5y layout always holds C[x -+ 1]; four idle lanes mirror
+//           the lanes the rotations wrap to)
+//   rho     a 64-bit rotation by r is a 32-bit rotation of each half by a lane constant -- r = 2k: both halves by k;
+//           r = 2k + 1: the odd half by k + 1 BECOMES the even half, the even half by k becomes the odd one -- and that
+//           exchange costs nothing: the pi gather simply reads the other half's lane
+//   pi+chi  B[x], B[x+1], B[x+2] gathered straight from the rho output (pi and the half exchange folded into the index)
+// Every bitwise step works on a half alone; only theta's rol(C[x+1], 1) needs the partner half of a DIFFERENT lane's value:
+// one v_permlane32_swap_b32 (new on gfx950) of two copies + a select.  Per round 12 VALU + 7 ds_bpermute in the same two LDS
+// round trips: 2.5 us per permutation (250 cycles per round; timing skeletons tools/gen_valu_census.py wide2 / wide4:
+// 337 -> 247 cycles; profiles/r05_wide_interleaved.txt).
+// Message words enter and leave through a 16-instruction bit (de)interleave per 32-bit half and one more lane swap.
 //
-//   sponge_il_digest_kernel<RW>          one item per wave (n <= SIMDs; beyond, two items per wave: sponge_wide.h)
-//   sponge_il_crypt_kernel<RW, DECRYPT>  one item per 128-lane workgroup: wave 0 = tag sponge, wave 1 = keystream sponge.
+//   sponge_il_digest_kernel<RW>          one item per wave; taken for up to two items per SIMD
+//   sponge_il_crypt_kernel<RW, DECRYPT>  one item per 128-lane workgroup: wave 0 = tag sponge, wave 1 = keystream sponge;
+//                                        taken for up to one item per SIMD.
 //                                        The message is turned in place, so only the keystream wave reads and writes it;
 //                                        it hands each plaintext block to the tag wave through 512 B of LDS, one
 //                                        s_barrier per block, the tag wave two blocks behind so that neither waits.
-// Same SpongeParams / FusedParams, framing and results as the kernels of sponge_wide.h (tests: every wide-kernel test runs on
-// both forms; tests/test_gpu_wide_il.py).
+// SpongeParams / FusedParams and their framing as in the other kernels; bit-identical results (tests/test_gpu_wide_il.py, and
+// the whole of tests/test_gpu_sponge.py with these kernels forced).
 #pragma once
-#include "sponge_wide.h"
+#include "sponge_fused.h"
 
 namespace capy {
+
+__device__ __forceinline__ uint32_t wide_bperm(uint32_t byte_index, uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_ds_bpermute((int)byte_index, (int)v);
+}
+// bitwise select: (m & a) | (~m & b), one v_bitop3_b32 (truth table 0xCA with the mask as first operand)
+__device__ __forceinline__ uint32_t wide_sel(uint32_t m, uint32_t a, uint32_t b) { return __builtin_amdgcn_bitop3_b32(m, a, b, 0xCA); }
+// whole-wave rotations by one lane (DPP_WF_RR1 / DPP_WF_RL1): lane i <- lane i - 1 (lane 0 <- lane 63) / lane i <- lane i + 1
+// (every lane has a source, so there is no "old" value to keep: mov_dpp, not update_dpp with a zero to materialise)
+__device__ __forceinline__ uint32_t wave_ror1(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x13C, 0xF, 0xF, false); }
+__device__ __forceinline__ uint32_t wave_rol1(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x134, 0xF, 0xF, false); }
+__device__ __forceinline__ uint32_t wide_rho(uint32_t i)
+{
+    // rho offsets indexed x + 5y (FIPS 202 table 2; the table of CAPY_RHO in keccak_dev.h)
+    uint32_t r = 0;
+#pragma unroll
+    for (int k = 0; k < 25; k++) r = i == (uint32_t)k ? (uint32_t)CAPY_RHO(k) : r;
+    return r;
+}
+
 
 // even / odd bits of a 64-bit constant (round constants, compile time)
 __host__ __device__ constexpr uint32_t il_bits(uint64_t v, int parity)
@@ -67,7 +93,7 @@ __device__ __forceinline__ void il_rc_fill(IlIdx &w, bool lane0, uint32_t e, std
     ((w.rc[Rs] = il_rc<Rs>(lane0, e)), ...);
 }
 
-// Idle lanes mirror as in sponge_wide.h (wide_setup): 63 -> (4, 0) of the even half, 25 -> (0, 0) even, 31 -> (4, 0) odd,
+// The idle lanes MIRROR a lane (same index registers, so they compute the same values): 63 -> (4, 0) of the even half, 25 -> (0, 0) even, 31 -> (4, 0) odd,
 // 57 -> (0, 0) odd -- the lanes theta's whole-wave rotations wrap to; the others mirror (4, 4) and are never read.
 __device__ __forceinline__ IlIdx il_setup()
 {
@@ -228,7 +254,10 @@ __global__ __launch_bounds__(64) void sponge_il_digest_kernel(const SpongeParams
     const uint32_t nb = (uint32_t)(c.padded / RB), hb = c.head_len / RB;
     const bool msg_aligned = (((uintptr_t)c.msg) & 7) == 0;
     uint32_t nfull = (msg_aligned && p.absorb_body) ? (uint32_t)(c.len / RB) : 0;  // body blocks loaded directly
-    if (nfull && hb + nfull == nb) nfull--;  // the last absorb block always takes the generic step (sponge_wide.h)
+    // An item's LAST absorb block always takes the generic step.  It is a directly loadable body block only when the stream ends
+    // on a block boundary with no suffix behind the body (cshake with N = S = "": the caller-framed trailer, suffix_len = 0) --
+    // the corner in which r03's wave-per-item kernel squeezed from a stale state (found by tools/fuzz_soak.py in r04).
+    if (nfull && hb + nfull == nb) nfull--;
 
     auto half_of = [&](uint64_t v) { return e ? (uint32_t)(v >> 32) : (uint32_t)v; };
     uint32_t a;

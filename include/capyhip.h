@@ -134,7 +134,8 @@ int capy_debug_secret_scratch_nonzero(void *stream, uint64_t *nonzero_bytes);
 int capy_debug_last_curve_kernel(int *variable_base, int *fixed_base);
 /* Test hook: which sponge kernel / schedule the calling thread's last digest or encrypt / decrypt launch took, and in how many
  * launches of the data pass (phases, time slices).  kind: 1 one lane per sponge (latency-tuned), 2 two lanes per sponge,
- * 3 rotating one-/two-lane schedule, 4 one lane per sponge (issue-tuned), 5 wave-quantisation split, 6 one wave per item,
+ * 3 rotating one-/two-lane schedule, 4 one lane per sponge (issue-tuned), 5 wave-quantisation split, (6 two items per wave:
+ * r02-r04, replaced by 10),
  * 7 uniform-framing kernel, 8 rotating-occupancy schedule, 9 uniform-framing kernel in time slices, 10 one wave per item with
  * bit-interleaved Keccak lanes; sha3_encrypt / decrypt and
  * the other symmetric halves: 20 four lanes per item, (21 one wave per item: r02-r04, replaced by 27), 22 four lanes per item in time slices, 23 one lane
@@ -383,8 +384,8 @@ int capy_key_decrypt_batch_dev_ex(int d, size_t n, const uint8_t *pws, size_t pw
 
 /* ------------------------------------------------------------------ measurement helpers */
 
-/* Tuning / test knob: GPU lanes per sponge. 0 = automatic (a wave per item or per two items for batches of at most
- * one / two items per SIMD, 2 lanes for batches of at most 32 items per SIMD, the rotating one-/two-lane schedule for uniform
+/* Tuning / test knob: GPU lanes per sponge. 0 = automatic (a wave per item for digest batches of at most two items
+ * per SIMD, 2 lanes for batches of at most 32 items per SIMD, the rotating one-/two-lane schedule for uniform
  * digest batches between 32 and 64 items per SIMD, else 1), 1 or 2 = forced, 3 = the rotating schedule wherever it is
  * eligible. Results are identical either way. Process-wide and not synchronised with calls in flight: set it before
  * the threads that use the library start, not while they run. */
@@ -394,12 +395,11 @@ int capy_set_sponge_lanes(int lanes);
  * (so that a profile can be read against the right kernel name): *kind = 1 sponge_kernel<RW,false,0>,
  * 2 sponge_kernel_k2<RW,0>, 3 sponge_mixed_kernel<RW> launched *phases times, 4 sponge_kernel<RW,true,0>,
  * 5 a full-chip head on sponge_kernel<RW,false,0> plus a remainder on kind 2 or 3 (*phases = launches in all),
- * 6 sponge_wide_digest_kernel<RW> (two items per wave: batches of up to two items per SIMD, any message length),
  * 7 sponge_uniform_kernel<RW> (more than 128 items per SIMD, wave-uniform framing: csrc/sponge_uniform.h; long messages just
  *   above a whole number of waves per SIMD run as a sequence of time-sliced launches of it, still reported as 7),
  * 8 sponge_rot_kernel<RW> launched *phases times (between 64 and 128 items per SIMD, long messages: csrc/sponge_rot.h),
- * 10 sponge_il_digest_kernel<RW> (one item per wave, bit-interleaved Keccak lanes: batches of up to one item per SIMD;
- *   csrc/sponge_wide_il.h). */
+ * 10 sponge_il_digest_kernel<RW> (one item per wave, bit-interleaved Keccak lanes: batches of up to two items per SIMD, any
+ *   message length; csrc/sponge_wide_il.h).  (6 was the two-items-per-wave kernel of r02-r04.) */
 int capy_sha3_launch_plan(int d, size_t n, uint64_t uniform_len, uint64_t msg_stride, int *kind, int *phases);
 /* Fill a device buffer with the harness PRNG (SplitMix64 counter mode, seed + 8-byte word index). */
 int capy_fill_random_dev(uint8_t *dst, uint64_t nbytes, uint64_t seed, void *stream);

@@ -30,10 +30,9 @@ def _lengths(rng, n, d):
     return out
 
 
-@pytest.mark.parametrize("lanes", [0, 1, 2, 2 | (1 << 8), 1 | (1 << 16), 32 << 8, 64 << 8, 1 | (64 << 8) | (1 << 16), (32 << 8) | (1 << 21)],
+@pytest.mark.parametrize("lanes", [0, 1, 2, 2 | (1 << 8), 1 | (1 << 16), 32 << 8, 64 << 8, 1 | (64 << 8) | (1 << 16)],
                          ids=["auto", "one-lane", "two-lane", "two-lane,no-uniform", "one-lane,two-pass",
-                              "auto,wave-per-item-kernels", "auto,lds-staged-loads", "one-lane,two-pass,lds-staged-loads",
-                              "auto,wave-per-item-kernels,two-items-per-wave-digests"])
+                              "auto,wave-per-item-kernels", "auto,lds-staged-loads", "one-lane,two-pass,lds-staged-loads"])
 @pytest.mark.parametrize("seed", list(range(1, 1 + int(os.environ.get("CAPY_FUZZ_SEEDS", "8")))))  # soak: raise it
 def test_sponge_fuzz_against_oracle(lanes, seed):
     from capycrypt_amd import _lib, ops

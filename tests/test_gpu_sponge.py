@@ -30,15 +30,14 @@ def O():
     return oracle
 
 
-@pytest.fixture(autouse=True, params=[1, 2, 1 | (1 << 16), 2 | (1 << 8), 2 | (32 << 8), 1 | (64 << 8), 2 | (32 << 8) | (1 << 21)],
+@pytest.fixture(autouse=True, params=[1, 2, 1 | (1 << 16), 2 | (1 << 8), 2 | (32 << 8), 1 | (64 << 8)],
                 ids=["lane-per-sponge", "two-lanes-per-sponge", "lane-per-sponge,two-pass-encrypt",
-                     "two-lanes,no-uniform-addressing", "wave-per-item-kernels", "lane-per-sponge,lds-staged-loads",
-                     "wave-per-item-kernels,two-items-per-wave-digests"])
+                     "two-lanes,no-uniform-addressing", "wave-per-item-kernels", "lane-per-sponge,lds-staged-loads"])
 def sponge_lanes(request):
     """Every test runs against both sponge kernels (sponge_kernels.h / sponge_kernels_k2.h), with the fused
     one-pass encrypt kernel (sponge_fused.h) on and off, with the wave-uniform addressing path off, and with the
-    one-wave-per-item kernels (sponge_wide_il.h: bit-interleaved, encrypt / decrypt and digests; with bit 21 the
-    two-items-per-wave digest kernel of sponge_wide.h instead) forced for every batch of up to 4096 items they can take, and with the wave-cooperative loads through LDS of round 1 (debug bit 6; the default is per-lane loads)."""
+    wave-per-item kernels (sponge_wide_il.h: encrypt / decrypt and digests) forced for every batch of up to 4096 items
+    they can take, and with the wave-cooperative loads through LDS of round 1 (debug bit 6; the default is per-lane loads)."""
     from capycrypt_amd import _lib
 
     global _CURRENT_LANES
@@ -1051,9 +1050,9 @@ def test_uniform_framing_kernel_matches_generic_kernel(capy, O, sponge_lanes, d)
 
 
 def test_wave_per_item_digest_pairs_of_unequal_length(capy, O, sponge_lanes):
-    """sponge_wide_digest_kernel holds two items per wave and switches between a tight body loop (every half either in
-    its directly loaded body blocks or finished) and the generic step.  Unsorted device batches (no length sort on this
-    path) whose wave partners differ wildly -- long next to empty, one block next to thousands, aligned next to unaligned
+    """The wave-per-item digest kernel switches between a tight body loop over directly loaded blocks and the generic step
+    (r03-r04: two items per wave, each half in its own phase; since r05 one item per wave, sponge_il_digest_kernel).  Unsorted
+    device batches (no length sort on this path) whose neighbours differ wildly -- long next to empty, one block next to thousands, aligned next to unaligned
     offsets, an odd item count -- must still give hashlib's digests (SHA3-256) and the oracle's (SHA3-512: the reference's
     135 mod 136 suffix rule applies at every d), with the kernel forced (debug bit 5)."""
     import hashlib

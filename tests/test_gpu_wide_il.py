@@ -13,10 +13,9 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-IL_DIGEST, WIDE_DIGEST, IL_CRYPT, FOUR_LANES = 10, 6, 27, 20
+IL_DIGEST, TWO_LANES, IL_CRYPT, FOUR_LANES = 10, 2, 27, 20
 FORCE_WIDE = 32 << 8  # debug bit 5: the wave-per-item kernels for every batch of up to 4096 items
 NEVER_WIDE = 16 << 8  # debug bit 4
-OLD_DIGEST = 1 << 21  # debug bit 11: the two-items-per-wave digest kernel of sponge_wide.h instead
 
 
 @pytest.fixture(scope="module")
@@ -157,14 +156,14 @@ def test_sha3_one_item_per_wave_equals_the_other_kernels(env, d):
             stride = (ln + 7) // 8 * 8 + 8
             msgs = _rand(env, n * stride + 64, 40 + n + ln)
             outs = {}
-            for name, lanes in (("il", 0), ("wide", OLD_DIGEST), ("lane", 1)):
+            for name, lanes in (("il", 0), ("two", 2), ("lane", 1)):
                 _lib.check(lib.capy_set_sponge_lanes(lanes))
                 out = torch.zeros(n * (d // 8) + 8, dtype=torch.uint8, device="cuda")
                 _lib.check(lib.capy_sha3_batch_dev(d, n, msgs.data_ptr(), None, ln, stride, out.data_ptr(), None))
                 torch.cuda.synchronize()
                 outs[name] = (out, _last(lib))
-            assert outs["il"][1] == IL_DIGEST and outs["wide"][1] == WIDE_DIGEST
-            assert torch.equal(outs["il"][0], outs["wide"][0]) and torch.equal(outs["il"][0], outs["lane"][0])
+            assert outs["il"][1] == IL_DIGEST and outs["two"][1] == TWO_LANES
+            assert torch.equal(outs["il"][0], outs["two"][0]) and torch.equal(outs["il"][0], outs["lane"][0])
             assert int(outs["il"][0][n * (d // 8):].sum()) == 0
             for i in (0, n - 1):  # the oracle, not hashlib: the reference's pad rule differs from FIPS 202 at some lengths (sponge.rs:23-33)
                 assert bytes(outs["il"][0][i * (d // 8):(i + 1) * (d // 8)].cpu().numpy()) == O.sha3(bytes(msgs[i * stride:i * stride + ln].cpu().numpy()), d)
@@ -181,7 +180,7 @@ def test_kmac_xof_long_squeezes_and_unaligned_outputs(env):
                 stride = (ln + 7) // 8 * 8 + 8
                 msgs, keys = _rand(env, n * stride + 64, 60 + n + ln), _rand(env, n * 32, 61 + n)
                 outs = {}
-                for name, lanes in (("il", 0), ("wide", OLD_DIGEST), ("lane", 1)):
+                for name, lanes in (("il", 0), ("two", 2), ("lane", 1)):
                     _lib.check(lib.capy_set_sponge_lanes(lanes))
                     out = torch.zeros(n * ol + 16, dtype=torch.uint8, device="cuda")
                     _lib.check(lib.capy_kmac_xof_batch_dev(d, n, keys.data_ptr(), 32, 32, None, msgs.data_ptr(), None, ln, stride, 8 * ol, b"T", 1,
@@ -189,7 +188,7 @@ def test_kmac_xof_long_squeezes_and_unaligned_outputs(env):
                     torch.cuda.synchronize()
                     outs[name] = (out, _last(lib))
                 assert outs["il"][1] == IL_DIGEST
-                assert torch.equal(outs["il"][0], outs["wide"][0]) and torch.equal(outs["il"][0], outs["lane"][0])
+                assert torch.equal(outs["il"][0], outs["two"][0]) and torch.equal(outs["il"][0], outs["lane"][0])
                 assert int(outs["il"][0][0]) == 0 and int(outs["il"][0][1 + n * ol:].sum()) == 0
                 i = n - 1
                 want = O.kmac_xof(bytes(keys[i * 32:(i + 1) * 32].cpu().numpy()), bytes(msgs[i * stride:i * stride + ln].cpu().numpy()), 8 * ol, b"T", d)
@@ -199,10 +198,10 @@ def test_kmac_xof_long_squeezes_and_unaligned_outputs(env):
 
 
 def test_launch_plan_reports_the_kernel(env):
-    """capy_sha3_launch_plan: one item per wave up to one item per SIMD, two items per wave up to two, then two lanes per sponge"""
+    """capy_sha3_launch_plan: one item per wave up to two items per SIMD, then two lanes per sponge"""
     _lib, lib, _, torch = env
     S = _simds(torch)
     kind, phases = C.c_int(0), C.c_int(0)
-    for n, want in ((1, 10), (S, 10), (S + 1, 6), (2 * S, 6), (2 * S + 1, 2)):
+    for n, want in ((1, 10), (S, 10), (S + 1, 10), (2 * S, 10), (2 * S + 1, 2)):
         _lib.check(lib.capy_sha3_launch_plan(256, n, 1 << 20, (1 << 20) + 8, C.byref(kind), C.byref(phases)))
         assert (kind.value, phases.value) == (want, 1), (n, kind.value)

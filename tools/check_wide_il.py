@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
-"""GPU check and timing of the bit-interleaved one-wave-per-sponge kernels (csrc/sponge_wide_il.h) against the digest kernel
-of csrc/sponge_wide.h (capy_set_sponge_lanes bit 21 = debug bit 11 switches back to it), the four-lane fused encrypt kernel, the
-two-pass form and the oracle.
+"""GPU check and timing of the bit-interleaved one-wave-per-sponge kernels (csrc/sponge_wide_il.h) against the two-lane digest
+kernel, the four-lane fused encrypt kernel, the two-pass form and the oracle.
 
   python3 tools/check_wide_il.py            correctness: digests (sha3, kmac_xof), sha3_encrypt / sha3_decrypt, forged tags
   python3 tools/check_wide_il.py time       seconds per call: config 3 as specified and the reference's one-message shapes
@@ -20,7 +19,7 @@ from capycrypt_amd import _lib  # noqa: E402
 lib = _lib.lib()
 sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 rng = random.Random(7)
-OLD = 1 << 21  # digests: the two-items-per-wave kernel of sponge_wide.h; encrypt / decrypt: together with NOWIDE the four-lane kernel
+OLD = 2  # digests: the two-lane kernel
 NOWIDE = 16 << 8  # debug bit 4: never a wave-per-item kernel
 
 
@@ -107,7 +106,7 @@ def check():
                 outs[name] = (out, last_kind())
             _lib.check(lib.capy_set_sponge_lanes(0))
             ok = torch.equal(outs["il"][0], outs["wide"][0]) and torch.equal(outs["il"][0], outs["lane"][0])
-            if not ok or outs["il"][1][0] != 10 or outs["wide"][1][0] != 6:
+            if not ok or outs["il"][1][0] != 10 or outs["wide"][1][0] != 2:
                 bad += 1
                 print("FAIL sha3" if not ok else "KIND sha3", d, n, ln, outs["il"][1], outs["wide"][1], flush=True)
     for d in (256, 512):
@@ -146,7 +145,7 @@ def timeit(fn, prep=None, reps=3):
 def timing():
     ln = 5 * 1024 * 1024
     stride = ln + 128
-    print("# seconds per call, best of 3; il = sponge_wide_il.h (default); other = the four-lane fused kernel (encrypt / decrypt), the two-items-per-wave kernel of sponge_wide.h (digests); D512 / SHA3-256, 5 MiB messages")
+    print("# seconds per call, best of 3; il = sponge_wide_il.h (default); other = the four-lane fused kernel (encrypt / decrypt), the two-lane kernel (digests); D512 / SHA3-256, 5 MiB messages")
     print("# n | sha3_encrypt il (kind) | wide (kind) | ratio | sha3_decrypt il | wide | ratio | SHA3-256 il | wide | ratio")
     for n in [int(x) for x in os.environ.get("NS", "1,16,128,256,512,1024,2048").split(",")]:
         pws, zs, m = rand(n * 32, 1), rand(n * 512, 2), rand(n * stride, 3)
@@ -160,7 +159,8 @@ def timing():
         row = []
         for fn, prep in ((enc, None), (dec, enc), (dig, None)):
             ts = []
-            for lanes in (0, OLD if fn is dig else NOWIDE):
+            force = (32 << 8) if os.environ.get("FORCE") else 0  # FORCE=1: the wave-per-item kernels for up to 4096 items
+            for lanes in (force, OLD if fn is dig else NOWIDE):
                 _lib.check(lib.capy_set_sponge_lanes(lanes))
                 t = timeit(fn, prep)
                 ts.append((t, last_kind()[0]))
@@ -171,7 +171,29 @@ def timing():
         print("%5d | %s" % (n, " | ".join(row)), flush=True)
 
 
+def small():
+    """short messages: the kernel's set-up (index registers, round constants) against the two-lane kernel's"""
+    print("# KMACXOF256, 32-byte keys, 64 bytes out; ms per call (200 calls back to back, best of 3): n | message bytes | il | two-lane | ratio")
+    for n in (1, 128, 1024, 2048):
+        for ln in (64, 1024, 16384):
+            stride = ln + 8
+            msgs, keys = rand(n * stride, 5), rand(n * 32, 6)
+            out = torch.zeros(n * 64, dtype=torch.uint8, device="cuda")
+            ts = []
+            for lanes in (0, 2):
+                _lib.check(lib.capy_set_sponge_lanes(lanes))
+                fn = lambda: [_lib.check(lib.capy_kmac_xof_batch_dev(256, n, keys.data_ptr(), 32, 32, None, msgs.data_ptr(), None, ln, stride, 512,  # noqa: E731
+                                                                      b"T", 1, out.data_ptr(), 64, sp)) for _ in range(200)]
+                fn()
+                ts.append((timeit(fn) / 200 * 1e3, last_kind()[0]))
+            _lib.check(lib.capy_set_sponge_lanes(0))
+            print("%5d | %6d | %.4f (%d) | %.4f (%d) | %.2f" % (n, ln, ts[0][0], ts[0][1], ts[1][0], ts[1][1], ts[1][0] / ts[0][0]), flush=True)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "small":
+        small()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "time":
         timing()
         sys.exit(0)
