@@ -113,7 +113,7 @@ int capy_set_devices(const int *ids, int n);
 int capy_get_devices(int *ids, int capacity);
 /* The minimum-shard rule: a sharded call uses only as many of the listed devices (the first ones) as leave each at least
  * `n` items; default 1.  Small batches are latency-bound -- one device runs 1024 messages of 5 MiB through sha3_encrypt in
- * 1.4 x the time it needs for 128, and 32 768 Ed448 multiplications in 0.19 x the time of 262 144 -- so cutting them finer
+ * 1.6 x the time it needs for 128, and 32 768 Ed448 multiplications in 0.19 x the time of 262 144 -- so cutting them finer
  * buys nothing and costs a PCIe hop per device; INTEGRATION.md section 5 lists the batch sizes per operation from which a
  * second device pays.  Process-wide; n = 0 restores the default. */
 int capy_set_min_items_per_device(size_t n);

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Latency of very small batches of long messages (what the reference's own benches and tests do: ONE 5 MiB message,
 benches/benchmark_sha3.rs, benchmark_e448_512.rs, tests/integration_tests.rs): SHA3-256, KMACXOF256 tag, Schnorr
-sign + verify for n = 1 .. 2048 messages of 5 MiB, device buffers, with the wave-per-item kernels (sponge_wide.h) off
+sign + verify for n = 1 .. 2048 messages of 5 MiB, device buffers, with the wave-per-item kernels (sponge_wide_il.h; sponge_wide.h until r04) off
 and on.  Run on the GPU box: python tools/bench_small_batches.py > gpurun_out/r02_small_batches.txt"""
 import ctypes as C
 import hashlib

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """sha3_encrypt D512 over n x 5 MiB messages, n small: the four-lanes-per-item kernel (sponge_fused.h) against the
-one-wave-per-item kernel (sponge_wide.h).  CAPY_DEBUG=wide_max is read once per process, so the debug bits of
+wave-per-item kernel (sponge_wide_il.h: two waves per item; sponge_wide.h until r04).  CAPY_DEBUG=wide_max is read once per process, so the debug bits of
 capy_set_sponge_lanes select the kernel here (bit 4: never wide, bit 5: always wide).
 Run on the GPU box: python tools/bench_wide.py > gpurun_out/r02_wide_vs_fused.txt"""
 import ctypes as C
