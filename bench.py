@@ -410,11 +410,39 @@ def config5(cx, n=1 << 16, msg_len=1024):
     assert all_ok and bad == [f], "config 5: verification"
     sample = [(pws_h.raw[64 * i:64 * i + 64], msgs_h.raw[msg_len * i:msg_len * (i + 1)], bytes(pubs_h[112 * i:112 * i + 112]),
                bytes(h_h[56 * i:56 * i + 56]), bytes(z_h[56 * i:56 * i + 56])) for i in (0, n - 1)]
+    # the same three calls on DEVICE-resident inputs and outputs (the *_dev forms): what the kernels do without the PCIe legs
+    torch = cx.torch
+    up = lambda buf: torch.frombuffer(bytearray(bytes(buf)), dtype=torch.uint8).to(cx.dev)  # noqa: E731
+    msgs_d, pws_d = up(msgs_h.raw), up(pws_h.raw)
+    pubs_d, h_d, z_d = (torch.zeros(n * k, dtype=torch.uint8, device=cx.dev) for k in (112, 56, 56))
+    st_d = torch.full((n,), 7, dtype=torch.int32, device=cx.dev)
+
+    def steady_dev(fn):
+        _lib.check(fn())
+        torch.cuda.synchronize()
+        best = 1e9
+        for _ in range(3):
+            cx.barrier()
+            t0 = time.perf_counter()
+            _lib.check(fn())
+            torch.cuda.synchronize()
+            best = min(best, cx.reduce_max(time.perf_counter() - t0))
+        return best
+
+    dk = steady_dev(lambda: lib.capy_keypair_batch_dev(512, n, pws_d.data_ptr(), 64, None, pubs_d.data_ptr(), cx.sp))
+    ds = steady_dev(lambda: lib.capy_schnorr_sign_batch_dev(512, n, pws_d.data_ptr(), 64, None, msgs_d.data_ptr(), None, msg_len, msg_len,
+                                                            h_d.data_ptr(), z_d.data_ptr(), cx.sp))
+    dv = steady_dev(lambda: lib.capy_schnorr_verify_batch_dev(512, n, pubs_d.data_ptr(), msgs_d.data_ptr(), None, msg_len, msg_len,
+                                                              h_d.data_ptr(), z_d.data_ptr(), st_d.data_ptr(), cx.sp))
+    same = bool(torch.equal(pubs_d, up(pubs_h)) and torch.equal(h_d, up(h_h)) and torch.equal(z_d, up(z_h)) and not bool(st_d.any().item()))
+    assert same, "config 5: device-buffer forms differ from the host-buffer forms"
     res = {"what": "Schnorr D512, %d x %d-byte messages per GPU, host-buffer C ABI (PCIe inclusive), constant-address lookups for the "
                    "secret scalars (the default)" % (n, msg_len),
            "items_per_gpu": n, "keypair_seconds": tk, "sign_seconds": ts, "verify_seconds": tv,
            "first_call_seconds": {"keypair": tk0, "sign": ts0, "verify": tv0},
-           "all_verified": all_ok, "one_flipped_byte_fails_alone": bad == [f]}
+           "all_verified": all_ok, "one_flipped_byte_fails_alone": bad == [f],
+           "device_resident": {"what": "the same calls through the *_dev entry points: inputs and outputs in HBM, no PCIe leg",
+                               "keypair_seconds": dk, "sign_seconds": ds, "verify_seconds": dv, "outputs_equal_host_abi": same}}
     return derive_config5(res, cx.world), sample
 
 
@@ -422,6 +450,8 @@ def derive_config5(res, world):
     n = res["items_per_gpu"]
     for k in ("keypair", "sign", "verify"):
         res[k + "_per_s"] = world * n / res[k + "_seconds"]
+        if "device_resident" in res:
+            res["device_resident"][k + "_per_s"] = world * n / res["device_resident"][k + "_seconds"]
     res["first_call_per_s"] = {k: n / v for k, v in res["first_call_seconds"].items()}
     return res
 
