@@ -22,8 +22,8 @@
 // 337 -> 247 cycles; profiles/r05_wide_interleaved.txt).
 // Message words enter and leave through a 16-instruction bit (de)interleave per 32-bit half and one more lane swap.
 //
-//   sponge_il_digest_kernel<RW>          one item per wave; taken for up to two items per SIMD
-//   sponge_il_crypt_kernel<RW, DECRYPT>  one item per 128-lane workgroup: wave 0 = tag sponge, wave 1 = keystream sponge;
+//   sponge_il_digest_kernel<RW, LONE>    one item per wave; taken for up to two items per SIMD
+//   sponge_il_crypt_kernel<RW, DECRYPT, LONE>  one item per 128-lane workgroup: wave 0 = tag sponge, wave 1 = keystream sponge;
 //                                        taken for up to one item per SIMD.
 //                                        The message is turned in place, so only the keystream wave reads and writes it;
 //                                        it hands each plaintext block to the tag wave through 512 B of LDS, one
@@ -32,6 +32,7 @@
 // the whole of tests/test_gpu_sponge.py with these kernels forced).
 #pragma once
 #include "sponge_fused.h"
+#include "occupancy.h"
 
 namespace capy {
 
@@ -221,8 +222,10 @@ __device__ __forceinline__ void il_store_u32(uint8_t *q, uint32_t v) { *reinterp
 
 // ---------------------------------------------------------------------------------------------------------------
 // Digests: MODE 0 of sponge_kernels.h, one item per wave.  GPU lane (i, half) absorbs / squeezes 32 bits of word i.
-template <int RW>
-__global__ __launch_bounds__(64) void sponge_il_digest_kernel(const SpongeParams p)
+// LONE = the launch holds at most one wave per SIMD: compiled so that a second wave of this kernel does not fit beside it
+// (occupancy.h: behind a launch whose waves end staggered the dispatcher otherwise doubles waves up on the SIMDs that free first).
+template <int RW, bool LONE>
+__global__ __launch_bounds__(64) CAPY_WAVES_PER_SIMD(LONE ? 1 : 8) void sponge_il_digest_kernel(const SpongeParams p)
 {
     constexpr uint32_t RB = RW * 8;
     const uint32_t lane = threadIdx.x, e = lane >> 5, i = lane & 31;
@@ -308,8 +311,8 @@ __global__ __launch_bounds__(64) void sponge_il_digest_kernel(const SpongeParams
 // ---------------------------------------------------------------------------------------------------------------
 // sha3_encrypt / sha3_decrypt and the other symmetric halves: the protocol, parameters and restrictions of
 // sponge_wide_crypt_kernel (rate-aligned KMAC framing, 8-byte aligned messages), two waves per item.
-template <int RW, bool DECRYPT>
-__global__ __launch_bounds__(128) void sponge_il_crypt_kernel(const FusedParams fp)
+template <int RW, bool DECRYPT, bool LONE>
+__global__ __launch_bounds__(128) CAPY_WAVES_PER_SIMD(LONE ? 1 : 8) void sponge_il_crypt_kernel(const FusedParams fp)
 {
     constexpr uint32_t RB = RW * 8;
     __shared__ uint32_t hand[2][64];         // plaintext blocks on their way from the keystream wave to the tag wave
