@@ -310,7 +310,7 @@ __global__ __launch_bounds__(64) CAPY_WAVES_PER_SIMD(LONE ? 1 : 8) void sponge_i
 
 // ---------------------------------------------------------------------------------------------------------------
 // sha3_encrypt / sha3_decrypt and the other symmetric halves: the protocol, parameters and restrictions of
-// sponge_wide_crypt_kernel (rate-aligned KMAC framing, 8-byte aligned messages), two waves per item.
+// four-lane kernel of sponge_fused.h (rate-aligned KMAC framing, 8-byte aligned messages), two waves per item.
 template <int RW, bool DECRYPT, bool LONE>
 __global__ __launch_bounds__(128) CAPY_WAVES_PER_SIMD(LONE ? 1 : 8) void sponge_il_crypt_kernel(const FusedParams fp)
 {
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(128) CAPY_WAVES_PER_SIMD(LONE ? 1 : 8) void sponge_
         }
     }
     const uint32_t d = il_out(a, w);
-    if (at + 8 - 4 * e <= fp.tag_len) {  // whole 8-byte words of the tag, as in sponge_wide_crypt_kernel
+    if (at + 8 - 4 * e <= fp.tag_len) {  // whole 8-byte words of the tag, as in the other fused kernels
         uint8_t *o = fp.tags + item * fp.tag_stride + at;
         if ((((uintptr_t)o) & 3) == 0)
             il_store_u32(o, d);
