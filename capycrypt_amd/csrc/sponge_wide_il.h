@@ -309,7 +309,7 @@ __global__ __launch_bounds__(64) CAPY_WAVES_PER_SIMD(LONE ? 1 : 8) void sponge_i
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// sha3_encrypt / sha3_decrypt and the other symmetric halves: the protocol, parameters and restrictions of
+// sha3_encrypt / sha3_decrypt and the other symmetric halves: the protocol, parameters and restrictions of the
 // four-lane kernel of sponge_fused.h (rate-aligned KMAC framing, 8-byte aligned messages), two waves per item.
 template <int RW, bool DECRYPT, bool LONE>
 __global__ __launch_bounds__(128) CAPY_WAVES_PER_SIMD(LONE ? 1 : 8) void sponge_il_crypt_kernel(const FusedParams fp)
