@@ -146,9 +146,11 @@ static std::atomic<bool> g_fused_enabled{true};
 bool fused_enabled() { return g_fused_enabled.load(); }
 // what the last symmetric_crypt_dev / launch_sponge call of this thread ran (capy_debug_last_sponge_kernel): kind =
 //   digest launches  1 one-lane latency-tuned, 2 two-lane, 3 rotating one-/two-lane schedule, 4 one-lane issue-tuned, 5 wave-quantisation
-//                    split, 6 wave-per-item, 7 uniform-framing kernel, 8 rotating-occupancy schedule, 9 uniform-framing kernel in time slices
-//   encrypt/decrypt  20 four lanes per item, 21 one wave per item, 22 four lanes per item in time slices, 23 one lane per sponge,
-//                    24 one lane per sponge in time slices, 25 one lane per sponge on the rotating-occupancy schedule, 26 two passes
+//                    split, 7 uniform-framing kernel, 8 rotating-occupancy schedule, 9 uniform-framing kernel in time slices, 10 one wave
+//                    per item (bit-interleaved Keccak lanes); 6 was the two-items-per-wave kernel of r02-r04
+//   encrypt/decrypt  20 four lanes per item, 22 four lanes per item in time slices, 23 one lane per sponge, 24 one lane per sponge
+//                    in time slices, 25 one lane per sponge on the rotating-occupancy schedule, 26 two passes, 27 two waves per
+//                    item (bit-interleaved Keccak lanes); 21 was the one-wave-per-item kernel of r02-r04
 // launches = kernel launches of the data pass (phases / slices)
 static thread_local int t_last_kind = 0, t_last_launches = 0;
 void last_kernel(int *kind, int *launches)
@@ -164,6 +166,7 @@ void note_kernel(int kind, int launches)
 
 
 // Kernel choice by batch size relative to the device's SIMD count S (1024 on MI355X; measured crossovers, profiles/):
+//   n <= 2 S         one wave per sponge, bit-interleaved Keccak lanes (sponge_wide_il.h)
 //   n <= 32 S        two lanes per sponge, at most one wave per SIMD
 //   32 S < n < 64 S  rotating one-lane / two-lane schedule when eligible (sponge_mixed.h), else one lane
 //   n <= 128 S       one lane per sponge, latency-tuned instance; uniform batches above 64 S are launched as a
