@@ -481,7 +481,7 @@ __global__ __launch_bounds__(128) CAPY_WAVES_PER_SIMD(LONE ? 1 : 8) void sponge_
         }
     }
     const uint32_t d = il_out(a, w);
-    if (at + 8 - 4 * e <= fp.tag_len) {  // whole 8-byte words of the tag, as in the other fused kernels
+    if (at + 4 <= fp.tag_len) {  // tag lengths are multiples of 4 (the launcher's fused_shape)
         uint8_t *o = fp.tags + item * fp.tag_stride + at;
         if ((((uintptr_t)o) & 3) == 0)
             il_store_u32(o, d);
