@@ -22,9 +22,12 @@ def _rand(nbytes, seed):
 
 
 def test_config1_full_hbm_batch_is_batch_size_independent():
-    """As many 5 MiB messages as bench.py hashes (54 528, or what fits): every digest of a sampled sub-batch, hashed
-    again on its own (a different kernel choice: two-lane instead of the rotating schedule), must be identical, and
-    three digests are checked with hashlib."""
+    """As many 5 MiB messages as bench.py hashes (54 528, or what fits): EVERY digest must equal the one a second kernel family
+    computes over the same resident batch (one lane per sponge in one launch instead of the rotating one-/two-lane schedule in
+    phase launches; asserted through capy_debug_last_sponge_kernel), a sampled sub-batch hashed again on its own (a third
+    choice: two lanes per sponge) must be identical, and three digests are checked with hashlib."""
+    import ctypes as C
+
     import torch
 
     from capycrypt_amd import _lib
@@ -37,6 +40,20 @@ def test_config1_full_hbm_batch_is_batch_size_independent():
     msgs = _rand(n * stride, 0xCA9C0001)
     dig = torch.zeros(n * 32, dtype=torch.uint8, device="cuda")
     _lib.check(lib.capy_sha3_batch_dev(256, n, msgs.data_ptr(), None, MIB5, stride, dig.data_ptr(), None))
+    kind, launches = C.c_int(0), C.c_int(0)
+    lib.capy_debug_last_sponge_kernel(C.byref(kind), C.byref(launches))
+    first = (kind.value, launches.value)
+    dig_all = torch.zeros(n * 32, dtype=torch.uint8, device="cuda")
+    try:
+        _lib.check(lib.capy_set_sponge_lanes(1))
+        _lib.check(lib.capy_sha3_batch_dev(256, n, msgs.data_ptr(), None, MIB5, stride, dig_all.data_ptr(), None))
+        lib.capy_debug_last_sponge_kernel(C.byref(kind), C.byref(launches))
+    finally:
+        _lib.check(lib.capy_set_sponge_lanes(0))
+    torch.cuda.synchronize()
+    assert kind.value == 1 and launches.value == 1 and (n != 54528 or first[0] == 3), (first, kind.value, launches.value)
+    assert torch.equal(dig, dig_all)
+    del dig_all
     sub0, m = n - 1500, 1024  # a window reaching into the last groups of the schedule
     dig2 = torch.zeros(m * 32, dtype=torch.uint8, device="cuda")
     _lib.check(lib.capy_sha3_batch_dev(256, m, msgs.data_ptr() + sub0 * stride, None, MIB5, stride, dig2.data_ptr(), None))
