@@ -409,14 +409,19 @@ __device__ __forceinline__ uint32_t fused1_body(const FusedParams &fp, uint32_t 
     const Fused1Item it = fused1_item(fp, grp, lane2);
     const uint32_t role = lane2 & 1;
     const uint64_t pos = it.tgt_len / RB * RB;
-    const uint32_t left = (uint32_t)(it.tgt_len - pos);
-    const uint32_t tl = left + 3;
+    const uint32_t left_all = (uint32_t)(it.tgt_len - pos);
+    const uint32_t tl = left_all + 3;
     const uint32_t cnt = it.active ? (tl + RB - 1) / RB : 0;  // 1 or 2 blocks: tail || 00 01 04 || 0* [80]
     const bool pad80 = (tl % RB) != 0;
     const uint32_t max_cnt = wave_max_u32(cnt);
 #pragma unroll 1
     for (uint32_t j = 0; j < max_cnt; j++) {
         const bool mine = j < cnt;
+        // `left` goes through an empty asm in every trip: the RW byte masks below would otherwise be hoisted out of this loop of
+        // one or two trips as 2 RW loop-invariant registers, which the 128-register instance spilled (r05: 23-62 VGPRs of
+        // scratch in FORM 4; tests/test_kernel_resources.py now holds every instance of this kernel to zero)
+        uint32_t left = left_all;
+        asm volatile("" : "+v"(left));
 #pragma unroll
         for (int w = 0; w < RW; w++) {
             const uint32_t at = 8 * w;
@@ -497,7 +502,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // One launch: wave w works on wave-group w (sl_groups == 0), or -- time slices, as in sponge_fused.h -- on wave-group
 // (sl_launch * gridDim.x + w) mod sl_groups for at most sl_blocks full blocks, progress in sl_done, states in sl_state.
 template <int RW, int FORM, bool DECRYPT>
-__global__ __launch_bounds__(64, (FORM == 1 ? 1 : (FORM == 2 ? CAPY_F1_FORM2_WAVES : CAPY_F1_LB))) CAPY_WAVES_PER_SIMD(FORM == 1 ? 1 : (FORM == 2 ? CAPY_F1_FORM2_WAVES : 4)) void sponge_fused1_kernel(const FusedParams fp)
+// Occupancy is pinned from both sides by amdgpu_waves_per_eu(min, max) alone (a second __launch_bounds__ argument next to
+// it left the descriptor at the registers used: 160 for FORM 1 / 2, so that three waves fitted a SIMD -- ADVICE r5): min caps
+// the registers the compiler may use, max pads the count in the kernel descriptor so that one more wave of THIS kernel does not
+// fit.  FORM 1: exactly one wave per SIMD (>= 257 VGPRs in the descriptor), FORM 2: exactly two (>= 171), FORM 4: four (<= 128).
+__global__ __launch_bounds__(64)
+    __attribute__((amdgpu_waves_per_eu((FORM == 1 ? 1 : (FORM == 2 ? CAPY_F1_FORM2_WAVES : CAPY_F1_LB)),
+                                       (FORM == 1 ? 1 : (FORM == 2 ? CAPY_F1_FORM2_WAVES : 4))))) void
+    sponge_fused1_kernel(const FusedParams fp)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_lds[FUSED1_LDS_WAVE];
     fused1_lds_u8 *lds = (fused1_lds_u8 *)s_lds;

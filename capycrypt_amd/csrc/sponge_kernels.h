@@ -82,7 +82,10 @@ __device__ __forceinline__ uint64_t state_word(const KState &a, int w) { return 
 // does not fit on the SIMD (CAPY_WAVES_PER_SIMD below) -- behind a launch whose waves end staggered the dispatcher otherwise
 // doubles waves up on the SIMDs that happen to be free and the launch takes up to twice as long (profiles/r04_placement.txt).
 template <int RW, bool FULLCHIP, int MODE, int WAVES = (FULLCHIP ? CAPY_FULLCHIP_WAVES : 1), bool PAIRED = false>
-__global__ __launch_bounds__(64, WAVES) CAPY_WAVES_PER_SIMD(WAVES == 1 ? 1 : 8) void sponge_kernel(const SpongeParams p)
+// (the register cap and the pin both through amdgpu_waves_per_eu(min, max): a second __launch_bounds__ argument beside the
+// attribute left the WAVES = 1 instances of the small rates, SHA3-384 / SHA3-512, at the 216 / 248 registers they use -- two
+// waves fitted; tests/test_kernel_resources.py reads the kernel descriptors)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES == 1 ? 1 : 8))) void sponge_kernel(const SpongeParams p)
 {
     constexpr uint32_t RB = RW * 8;
     __shared__ uint64_t s_stage[64 * RW];

@@ -1,0 +1,144 @@
+"""Register / scratch / occupancy facts of every gfx950 kernel in libcapyhip.so, asserted from the code objects inside the
+shared library (no GPU needed): tools/kernel_resources.py reads each kernel's metadata note and kernel descriptor.
+
+Why: DESIGN.md called kernels spill-free that were not, a `__launch_bounds__` argument silently
+undid an occupancy pin, and nothing in the suite would have noticed a compiler or source change that doubled a kernel's
+scratch.  Two layers:
+  * policy  -- properties the launchers and DESIGN.md rely on, written out below (which families must have no scratch at all,
+              which instances must fit exactly one / two / four waves of themselves on a SIMD, how much the known spillers may spill);
+  * golden  -- the whole table, tests/golden/kernel_resources.json: ANY change of vgpr / scratch / spill / LDS / waves per SIMD
+              of ANY kernel fails until the table is regenerated on purpose (`python tools/kernel_resources.py --write`) and the
+              diff is read.
+"""
+import json
+import os
+import re
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import kernel_resources as KR  # noqa: E402
+
+CHECKED = ("vgpr_count", "agpr_count", "private_segment_fixed_size", "vgpr_spill_count", "sgpr_spill_count",
+           "group_segment_fixed_size", "vgpr_alloc", "max_waves_per_simd")
+
+
+@pytest.fixture(scope="module")
+def table():
+    if not os.path.exists(KR.LIB):
+        pytest.fail("capycrypt_amd/libcapyhip.so is missing: run __graft_entry__.build() first")
+    return KR.kernel_table()
+
+
+# ---- policy ------------------------------------------------------------------------------------------------------------
+# kernel families whose every instance must run without scratch memory (no spills, no stack).  These are the families whose
+# registers hold KEYED sponge state or plaintext (scratch is not covered by the workspace scrub) and the headline kernels.
+NO_SCRATCH = [
+    r"capy::sponge_fused1_kernel<",       # one-lane fused encrypt: r05 shipped FORM 4 with 23-62 spilled VGPRs (fixed r06)
+    r"capy::sponge_fused1_rot_kernel<",
+    r"capy::sponge_fused_crypt_kernel<",  # four-lane fused encrypt
+    r"capy::sponge_il_crypt_kernel<",     # two waves per item
+    r"capy::sponge_il_digest_kernel<",
+    r"capy::sponge_mixed_kernel<",        # the headline (bench.py)
+    r"capy::sponge_rot_kernel<",
+    r"capy::sponge_kernel_k2<",
+    r"capy::sponge_uniform_kernel<\d+, false>",  # config 2 and the chip-full digests (the SLICED instance is bounded below)
+    r"capy::sponge_kernel<\d+, false, \d, 1, false>",  # the latency-tuned one-lane instance (one wave per SIMD)
+]
+# known spillers: an upper bound each (VGPRs spilled), so that growth fails even if someone regenerates the golden table
+# without looking.  DESIGN.md §4 lists these as the kernels that use scratch.
+SPILL_BOUND = [
+    (r"capy::sponge_uniform_kernel<\d+, true>", 48),       # SLICED instance, 128 VGPRs
+    (r"capy::sponge_kernel<\d+, true, \d, 3, false>", 144),  # generic issue-tuned instance (rolled, 168 VGPRs)
+    (r"capy::sponge_kernel<\d+, false, \d, 2, true>", 64),  # paired latency-tuned instance (256 VGPRs)
+    (r"capy::vb2_kernel", 96),
+    (r"capy::vb_kernel$", 44),
+    (r"capy::vb_ct_kernel$", 44),
+    (r"capy::dsm_kernel$", 140),
+    (r"capy::fb2_kernel<false, true>", 70),
+    (r"capy::fb_ct7_pair_kernel<true>", 104),
+    (r"capy::gtab_tw_pack_kernel", 150),                    # one-time table build
+]
+# exact occupancy pins (waves of the kernel itself that fit on one SIMD, from the kernel descriptor)
+WAVES = [
+    (r"capy::sponge_fused1_kernel<\d+, 1, ", 1),
+    (r"capy::sponge_fused1_kernel<\d+, 2, ", 2),
+    (r"capy::sponge_fused1_kernel<\d+, 4, ", 4),
+    (r"capy::sponge_fused1_rot_kernel<", 2),
+    (r"capy::sponge_rot_kernel<", 2),
+    (r"capy::sponge_mixed_kernel<", 1),
+    (r"capy::sponge_fused_crypt_kernel<\d+, (true|false), 0>", 1),
+    (r"capy::sponge_il_crypt_kernel<\d+, (true|false), true>", 1),
+    (r"capy::sponge_il_digest_kernel<\d+, true>", 1),
+    (r"capy::sponge_kernel<\d+, false, \d, 1, false>", 1),
+    (r"capy::sponge_kernel_k2<\d+, \d, [01]>", 1),
+    (r"capy::vb_kernel_1w", 1), (r"capy::vb_ct_kernel_1w", 1), (r"capy::dsm_kernel_1w", 1),
+    (r"capy::vb_quad_kernel", 1), (r"capy::dsm_quad_kernel", 1), (r"capy::vb_duo_kernel", 1), (r"capy::vb_duo_ct_kernel", 1),
+    (r"capy::dsm_duo_kernel", 1),
+    (r"capy::vb2_kernel", 2),
+    (r"capy::sponge_uniform_kernel<\d+, true>", 4),
+]
+# at least this many (the register budget the kernel was tuned at; the small rates use fewer registers and fit more)
+MIN_WAVES = [
+    (r"capy::sponge_uniform_kernel<", 4),
+    (r"capy::sponge_kernel<\d+, true, \d, 3, false>", 3),
+    (r"capy::sponge_kernel<\d+, false, \d, 2, true>", 2),
+]
+
+
+def _match(table, pattern):
+    names = [n for n in table if re.search(pattern, n)]
+    assert names, "no kernel matches %r: the policy list is stale" % pattern
+    return names
+
+
+def test_families_that_must_not_touch_scratch(table):
+    bad = []
+    for pat in NO_SCRATCH:
+        for n in _match(table, pat):
+            r = table[n]
+            if r["private_segment_fixed_size"] or r["vgpr_spill_count"]:  # (SGPR spills go to VGPR lanes, not to memory)
+                bad.append((n, r["private_segment_fixed_size"], r["vgpr_spill_count"]))
+    assert not bad, "kernels that must be scratch-free use scratch (name, bytes per lane, spilled VGPRs): %r" % bad
+
+
+def test_known_spillers_stay_within_their_bounds(table):
+    listed = set()
+    for pat, bound in SPILL_BOUND:
+        for n in _match(table, pat):
+            listed.add(n)
+            assert table[n]["vgpr_spill_count"] <= bound, (n, table[n]["vgpr_spill_count"], bound)
+    # every kernel that spills VGPRs is on one of the two lists: a NEW spiller fails here
+    unlisted = [n for n in table if table[n]["vgpr_spill_count"] and n not in listed]
+    assert not unlisted, "kernels spill VGPRs without an entry in SPILL_BOUND: %r" % [(n, table[n]["vgpr_spill_count"]) for n in unlisted]
+
+
+def test_occupancy_pins_hold_in_the_kernel_descriptors(table):
+    bad = []
+    for pat, waves in WAVES:
+        for n in _match(table, pat):
+            if table[n]["max_waves_per_simd"] != waves:
+                bad.append((n, table[n]["vgpr_alloc"], table[n]["max_waves_per_simd"], waves))
+    for pat, waves in MIN_WAVES:
+        for n in _match(table, pat):
+            if table[n]["max_waves_per_simd"] < waves:
+                bad.append((n, table[n]["vgpr_alloc"], table[n]["max_waves_per_simd"], ">= %d" % waves))
+    assert not bad, "(kernel, VGPRs in the descriptor, waves that fit, waves wanted): %r" % bad
+
+
+# ---- golden table --------------------------------------------------------------------------------------------------------
+def test_resource_table_matches_the_committed_one(table):
+    with open(KR.GOLDEN) as f:
+        golden = json.load(f)["kernels"]
+    missing = sorted(set(golden) - set(table))
+    extra = sorted(set(table) - set(golden))
+    diffs = []
+    for n in sorted(set(golden) & set(table)):
+        for k in CHECKED:
+            if golden[n].get(k) != table[n].get(k):
+                diffs.append("%s: %s %s -> %s" % (n, k, golden[n].get(k), table[n].get(k)))
+    assert not (missing or extra or diffs), (
+        "kernel resources changed (committed -> built).  Read the diff, then `python tools/kernel_resources.py --write`.\n"
+        "gone: %r\nnew: %r\n%s" % (missing, extra, "\n".join(diffs)))

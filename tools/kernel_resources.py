@@ -61,6 +61,36 @@ def _kernel_notes(elf):
             p = d + (descsz + 3) // 4 * 4
 
 
+def _kernel_descriptors(elf):
+    """{kernel name: VGPRs allocated per lane according to the kernel descriptor (<name>.kd, compute_pgm_rsrc1 bits 0-5,
+    granule 8 on gfx90a+)} -- the number the dispatcher uses: 512 // it waves of the kernel fit on a SIMD.  amdgpu_waves_per_eu's
+    upper bound pads THIS count, not the .vgpr_count of the metadata note."""
+    shoff, = struct.unpack_from("<Q", elf, 0x28)
+    shentsize, shnum = struct.unpack_from("<HH", elf, 0x3A)
+    secs = []
+    for i in range(shnum):
+        sh = shoff + i * shentsize
+        sh_type, = struct.unpack_from("<I", elf, sh + 4)
+        addr, off, size, link = struct.unpack_from("<QQQI", elf, sh + 0x10)
+        secs.append((sh_type, addr, off, size, link))
+    out = {}
+    for sh_type, addr, off, size, link in secs:
+        if sh_type not in (2, 11):  # SHT_SYMTAB / SHT_DYNSYM
+            continue
+        str_off = secs[link][2]
+        for p in range(off, off + size, 24):
+            st_name, _info, _other, _shndx, st_value, st_size = struct.unpack_from("<IBBHQQ", elf, p)
+            end = elf.index(b"\0", str_off + st_name)
+            name = elf[str_off + st_name:end].decode()
+            if not name.endswith(".kd") or st_size != 64:
+                continue
+            for _t, a, o, sz, _l in secs:
+                if a <= st_value < a + sz and _t == 1:
+                    rsrc1, = struct.unpack_from("<I", elf, o + st_value - a + 48)
+                    out[name[:-3]] = ((rsrc1 & 63) + 1) * 8
+    return out
+
+
 def demangle(names):
     out = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True).stdout.split("\n")
     return [o.replace("void ", "", 1).split("(")[0] if o else n for o, n in zip(out, names)]
@@ -72,8 +102,12 @@ def kernel_table(path=LIB):
         blob = f.read()
     rows = {}
     for elf in _code_objects(blob):
+        kd = _kernel_descriptors(elf)
         for k in _kernel_notes(elf):
             rows[k[".name"]] = {f: int(k.get("." + f, 0)) for f in FIELDS}
+            alloc = kd.get(k[".name"], 0)
+            rows[k[".name"]]["vgpr_alloc"] = alloc
+            rows[k[".name"]]["max_waves_per_simd"] = min(8, 512 // alloc) if alloc else 0
     names = sorted(rows)
     table = {}
     for mangled, pretty in zip(names, demangle(names)):
@@ -91,12 +125,12 @@ def main():
             f.write("\n")
         print("wrote %s: %d kernels" % (GOLDEN, len(table)))
         return
-    print("%-96s %4s %4s %4s %7s %6s %6s" % ("kernel", "vgpr", "agpr", "sgpr", "scratch", "vspill", "lds"))
+    print("%-96s %4s %4s %4s %7s %6s %6s %5s %5s" % ("kernel", "vgpr", "agpr", "sgpr", "scratch", "vspill", "lds", "alloc", "waves"))
     for name in sorted(table):
         r = table[name]
-        print("%-96s %4d %4d %4d %7d %6d %6d" % (name[:96], r["vgpr_count"], r["agpr_count"], r["sgpr_count"],
-                                               r["private_segment_fixed_size"], r["vgpr_spill_count"],
-                                               r["group_segment_fixed_size"]))
+        print("%-96s %4d %4d %4d %7d %6d %6d %5d %5d" % (name[:96], r["vgpr_count"], r["agpr_count"], r["sgpr_count"],
+                                                       r["private_segment_fixed_size"], r["vgpr_spill_count"],
+                                                       r["group_segment_fixed_size"], r["vgpr_alloc"], r["max_waves_per_simd"]))
     spilled = [n for n in table if table[n]["vgpr_spill_count"]]
     print("# %d kernels, %d with spilled VGPRs, %d with scratch" % (len(table), len(spilled),
                                                                    sum(1 for n in table if table[n]["private_segment_fixed_size"])))
