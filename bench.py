@@ -482,9 +482,10 @@ def run_config_leg(fn, derive, cx, max_reduce, **kw):
         res, sample = fn(cx, **kw)
     except Exception as e:  # an assertion of the leg, or an error return of the library
         err = "%s: %s" % (type(e).__name__, e)
-    if max_reduce is None:  # one rank
-        if err:
-            raise RuntimeError(err)
+    if max_reduce is None:  # one rank: a failing secondary leg must not cost the record its headline -- the line
+        if err:             # carries {"error": ...} for the leg and main() exits non-zero AFTER printing it
+            print("bench.py: config leg failed: " + err, file=sys.stderr, flush=True)
+            return {"error": err}, None
         return res, sample
     leaves = _seconds_leaves(res) if res is not None else []
     vec = [1.0 if err else 0.0, float(len(leaves))] + [v for _, v in leaves]
@@ -1004,6 +1005,9 @@ def main():
         print(json.dumps(res), flush=True)
     if use_dist:
         dist.destroy_process_group()
+    # a failed secondary leg is loud, but only after the line (with the headline and the leg's {"error": ...}) is out
+    if rank == 0 and any(isinstance(v, dict) and "error" in v for v in cfg_res.values()):
+        sys.exit(4)
 
 
 if __name__ == "__main__":

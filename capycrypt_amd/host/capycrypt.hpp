@@ -67,10 +67,13 @@ inline void check_abi()
 }
 inline void check(int rc)
 {
-    check_abi();
     if (rc == CAPY_ERR_UNSUPPORTED_SECPARAM) throw OperationError("UnsupportedSecurityParameter");
     if (rc != CAPY_OK) throw std::runtime_error(std::string("libcapyhip: ") + capy_last_error());
 }
+// Every library call of this header goes through CAPY_CALL: the ABI check runs BEFORE the call (the comma operator sequences
+// it), so a library with an older ABI is never entered with arguments it would read differently (it ran inside
+// check(rc), i.e. after the first call).
+#define CAPY_CALL(expr) (::capycrypt::detail::check_abi(), ::capycrypt::detail::check(expr))
 inline const uint8_t *ptr(const Bytes &b)
 {
     static const uint8_t dummy = 0;
@@ -104,7 +107,7 @@ inline Bytes kmac_xof(const Bytes &k, const Bytes &x, size_t l, const std::strin
 {
     Bytes out(l / 8);
     const uint64_t off[2] = {0, x.size()};
-    detail::check(capy_kmac_xof_batch((int)d, 1, detail::ptr(k), k.size(), nullptr, detail::ptr(x), off, l,
+    CAPY_CALL(capy_kmac_xof_batch((int)d, 1, detail::ptr(k), k.size(), nullptr, detail::ptr(x), off, l,
                                       (const uint8_t *)s.data(), s.size(), detail::ptr(out)));
     return out;
 }
@@ -138,7 +141,7 @@ struct KeyPair {  // src/ecc/keypair.rs:11-22
         KeyPair kp;
         kp.owner = owner;
         kp.pub_key.resize(112);
-        detail::check(capy_keypair_batch_ex((int)d, 1, detail::ptr(pw), pw.size(), nullptr, kp.pub_key.data(), detail::opts()));
+        CAPY_CALL(capy_keypair_batch_ex((int)d, 1, detail::ptr(pw), pw.size(), nullptr, kp.pub_key.data(), detail::opts()));
         kp.priv_key = pw;
         char buf[32];
         std::time_t t = std::time(nullptr);
@@ -164,7 +167,7 @@ struct Message {  // src/lib.rs:63-94; every operation is in place, as in the re
     {  // src/sha3/hashable.rs:19-21; leaves suffix + pad appended to msg like shake() does (:25-29, sponge.rs:13-14)
         const uint64_t off[2] = {0, msg.size()};
         digest.assign((size_t)dd / 8, 0);
-        detail::check(capy_sha3_batch((int)dd, 1, detail::ptr(msg), off, digest.data()));
+        CAPY_CALL(capy_sha3_batch((int)dd, 1, detail::ptr(msg), off, digest.data()));
         msg.push_back((136 - msg.size() % 136) == 1 ? 0x86 : 0x06);
         const size_t r = (1600 - 2 * (size_t)dd) / 8;
         if (msg.size() % r) {
@@ -185,7 +188,7 @@ struct Message {  // src/lib.rs:63-94; every operation is in place, as in the re
         Bytes z = z_inject ? *z_inject : get_random_bytes(512);
         const uint64_t off[2] = {0, msg.size()};
         digest.assign(64, 0);
-        detail::check(capy_sha3_encrypt_batch((int)dd, 1, detail::ptr(pw), pw.size(), nullptr, z.data(), detail::ptr(msg), off,
+        CAPY_CALL(capy_sha3_encrypt_batch((int)dd, 1, detail::ptr(pw), pw.size(), nullptr, z.data(), detail::ptr(msg), off,
                                               digest.data()));
         sym_nonce = z;
     }
@@ -198,7 +201,7 @@ struct Message {  // src/lib.rs:63-94; every operation is in place, as in the re
         const uint64_t off[2] = {0, msg.size()};
         int32_t status = 0;
         Bytes tag = digest;
-        detail::check(capy_sha3_decrypt_batch((int)*d, 1, detail::ptr(pw), pw.size(), nullptr, sym_nonce->data(),
+        CAPY_CALL(capy_sha3_decrypt_batch((int)*d, 1, detail::ptr(pw), pw.size(), nullptr, sym_nonce->data(),
                                               detail::ptr(msg), off, tag.data(), &status));
         if (status != CAPY_ITEM_OK) throw OperationError("SHA3DecryptionFailure");
     }
@@ -208,7 +211,7 @@ struct Message {  // src/lib.rs:63-94; every operation is in place, as in the re
     {  // src/ecc/signable.rs:40-57
         const uint64_t off[2] = {0, msg.size()};
         Signature s{Bytes(56), Bytes(56)};
-        detail::check(capy_schnorr_sign_batch_ex((int)dd, 1, detail::ptr(key.priv_key), key.priv_key.size(), nullptr,
+        CAPY_CALL(capy_schnorr_sign_batch_ex((int)dd, 1, detail::ptr(key.priv_key), key.priv_key.size(), nullptr,
                                               detail::ptr(msg), off, s.h.data(), s.z.data(), detail::opts()));
         sig = s;
         d = dd;
@@ -221,7 +224,7 @@ struct Message {  // src/lib.rs:63-94; every operation is in place, as in the re
             throw OperationError("SignatureVerificationFailure");
         const uint64_t off[2] = {0, msg.size()};
         int32_t status = 0;
-        detail::check(capy_schnorr_verify_batch_ex((int)*d, 1, pub_key.data(), detail::ptr(msg), off, sig->h.data(),
+        CAPY_CALL(capy_schnorr_verify_batch_ex((int)*d, 1, pub_key.data(), detail::ptr(msg), off, sig->h.data(),
                                                 sig->z.data(), &status, detail::opts()));
         if (status != CAPY_ITEM_OK) throw OperationError("SignatureVerificationFailure");
     }
@@ -234,7 +237,7 @@ struct Message {  // src/lib.rs:63-94; every operation is in place, as in the re
         const uint64_t off[2] = {0, msg.size()};
         Point z(112);
         digest.assign(56, 0);
-        detail::check(capy_key_encrypt_batch_ex((int)dd, 1, pub_key.data(), k.data(), detail::ptr(msg), off, z.data(),
+        CAPY_CALL(capy_key_encrypt_batch_ex((int)dd, 1, pub_key.data(), k.data(), detail::ptr(msg), off, z.data(),
                                              digest.data(), detail::opts()));
         asym_nonce = z;
     }
@@ -246,7 +249,7 @@ struct Message {  // src/lib.rs:63-94; every operation is in place, as in the re
         const uint64_t off[2] = {0, msg.size()};
         int32_t status = 0;
         Bytes tag = digest;
-        detail::check(capy_key_decrypt_batch_ex((int)*d, 1, detail::ptr(pw), pw.size(), nullptr, asym_nonce->data(),
+        CAPY_CALL(capy_key_decrypt_batch_ex((int)*d, 1, detail::ptr(pw), pw.size(), nullptr, asym_nonce->data(),
                                              detail::ptr(msg), off, tag.data(), &status, detail::opts()));
         if (status != CAPY_ITEM_OK) throw OperationError("KeyDecryptionError");
     }
@@ -302,7 +305,7 @@ inline void compute_sha3_hash_many(const std::vector<Message *> &ms, SecParam dd
     detail::Packed p = detail::pack_msgs(ms);
     const size_t dl = (size_t)dd / 8;
     Bytes dig(ms.size() * dl + 1);
-    detail::check(capy_sha3_batch((int)dd, ms.size(), detail::ptr(p.data), p.offs.data(), dig.data()));
+    CAPY_CALL(capy_sha3_batch((int)dd, ms.size(), detail::ptr(p.data), p.offs.data(), dig.data()));
     for (size_t i = 0; i < ms.size(); i++) {
         Bytes &m = ms[i]->msg;  // the caller-visible suffix + pad mutation, as compute_sha3_hash
         ms[i]->digest.assign(dig.begin() + i * dl, dig.begin() + (i + 1) * dl);
@@ -323,7 +326,7 @@ inline void compute_tagged_hash_many(const std::vector<Message *> &ms, const std
     detail::Packed p = detail::pack_msgs(ms), k = detail::pack_bytes(pws);
     const size_t dl = (size_t)dd / 8;
     Bytes out(ms.size() * dl + 1);
-    detail::check(capy_kmac_xof_batch((int)dd, ms.size(), detail::ptr(k.data), 0, k.offs.data(), detail::ptr(p.data),
+    CAPY_CALL(capy_kmac_xof_batch((int)dd, ms.size(), detail::ptr(k.data), 0, k.offs.data(), detail::ptr(p.data),
                                       p.offs.data(), (size_t)dd, (const uint8_t *)s.data(), s.size(), out.data()));
     for (size_t i = 0; i < ms.size(); i++) ms[i]->digest.assign(out.begin() + i * dl, out.begin() + (i + 1) * dl);
 }
@@ -340,7 +343,7 @@ inline void sha3_encrypt_many(const std::vector<Message *> &ms, const std::vecto
         zs.insert(zs.end(), z.begin(), z.end());
     }
     Bytes tags(ms.size() * 64 + 1);
-    detail::check(capy_sha3_encrypt_batch((int)dd, ms.size(), detail::ptr(k.data), 0, k.offs.data(), detail::ptr(zs),
+    CAPY_CALL(capy_sha3_encrypt_batch((int)dd, ms.size(), detail::ptr(k.data), 0, k.offs.data(), detail::ptr(zs),
                                           detail::ptr(p.data), p.offs.data(), tags.data()));
     detail::unpack_msgs(p, ms);
     for (size_t i = 0; i < ms.size(); i++) {
@@ -367,7 +370,7 @@ inline std::vector<bool> sha3_decrypt_many(const std::vector<Message *> &ms, con
         tags.insert(tags.end(), t.begin(), t.end());
     }
     std::vector<int32_t> st(ms.size(), CAPY_ITEM_FAIL);
-    detail::check(capy_sha3_decrypt_batch((int)*ms[0]->d, ms.size(), detail::ptr(k.data), 0, k.offs.data(), zs.data(),
+    CAPY_CALL(capy_sha3_decrypt_batch((int)*ms[0]->d, ms.size(), detail::ptr(k.data), 0, k.offs.data(), zs.data(),
                                           detail::ptr(p.data), p.offs.data(), tags.data(), st.data()));
     std::vector<bool> ok(ms.size());
     for (size_t i = 0; i < ms.size(); i++) {
@@ -381,7 +384,7 @@ inline std::vector<KeyPair> keypair_new_many(const std::vector<Bytes> &pws, cons
 {
     detail::Packed k = detail::pack_bytes(pws);
     Bytes pubs(pws.size() * 112 + 1);
-    detail::check(capy_keypair_batch_ex((int)dd, pws.size(), detail::ptr(k.data), 0, k.offs.data(), pubs.data(), detail::opts()));
+    CAPY_CALL(capy_keypair_batch_ex((int)dd, pws.size(), detail::ptr(k.data), 0, k.offs.data(), pubs.data(), detail::opts()));
     std::vector<KeyPair> out(pws.size());
     const std::string now = detail::now_string();
     for (size_t i = 0; i < pws.size(); i++) {
@@ -399,7 +402,7 @@ inline void sign_many(const std::vector<Message *> &ms, const std::vector<const 
     detail::Packed p = detail::pack_msgs(ms);
     detail::Packed k = detail::pack(keys.begin(), keys.end(), [](const KeyPair *kp) -> const Bytes & { return kp->priv_key; });
     Bytes h(ms.size() * 56 + 1), z(ms.size() * 56 + 1);
-    detail::check(capy_schnorr_sign_batch_ex((int)dd, ms.size(), detail::ptr(k.data), 0, k.offs.data(), detail::ptr(p.data),
+    CAPY_CALL(capy_schnorr_sign_batch_ex((int)dd, ms.size(), detail::ptr(k.data), 0, k.offs.data(), detail::ptr(p.data),
                                           p.offs.data(), h.data(), z.data(), detail::opts()));
     for (size_t i = 0; i < ms.size(); i++) {
         ms[i]->sig = Signature{Bytes(h.begin() + 56 * i, h.begin() + 56 * (i + 1)), Bytes(z.begin() + 56 * i, z.begin() + 56 * (i + 1))};
@@ -428,7 +431,7 @@ inline std::vector<bool> verify_many(const std::vector<Message *> &ms, const std
         z.insert(z.end(), c.begin(), c.end());
     }
     std::vector<int32_t> st(ms.size(), CAPY_ITEM_FAIL);
-    detail::check(capy_schnorr_verify_batch_ex((int)*ms[0]->d, ms.size(), pk.data(), detail::ptr(p.data), p.offs.data(), h.data(),
+    CAPY_CALL(capy_schnorr_verify_batch_ex((int)*ms[0]->d, ms.size(), pk.data(), detail::ptr(p.data), p.offs.data(), h.data(),
                                             z.data(), st.data(), detail::opts()));
     std::vector<bool> ok(ms.size());
     for (size_t i = 0; i < ms.size(); i++) ok[i] = wellformed[i] && st[i] == CAPY_ITEM_OK;
@@ -449,7 +452,7 @@ inline void key_encrypt_many(const std::vector<Message *> &ms, const std::vector
         ks.insert(ks.end(), k.begin(), k.end());
     }
     Bytes zs(ms.size() * 112 + 1), tags(ms.size() * 56 + 1);
-    detail::check(capy_key_encrypt_batch_ex((int)dd, ms.size(), detail::ptr(pk), detail::ptr(ks), detail::ptr(p.data),
+    CAPY_CALL(capy_key_encrypt_batch_ex((int)dd, ms.size(), detail::ptr(pk), detail::ptr(ks), detail::ptr(p.data),
                                          p.offs.data(), zs.data(), tags.data(), detail::opts()));
     detail::unpack_msgs(p, ms);
     for (size_t i = 0; i < ms.size(); i++) {
@@ -476,7 +479,7 @@ inline std::vector<bool> key_decrypt_many(const std::vector<Message *> &ms, cons
         tags.insert(tags.end(), t.begin(), t.end());
     }
     std::vector<int32_t> st(ms.size(), CAPY_ITEM_FAIL);
-    detail::check(capy_key_decrypt_batch_ex((int)*ms[0]->d, ms.size(), detail::ptr(k.data), 0, k.offs.data(), zs.data(),
+    CAPY_CALL(capy_key_decrypt_batch_ex((int)*ms[0]->d, ms.size(), detail::ptr(k.data), 0, k.offs.data(), zs.data(),
                                          detail::ptr(p.data), p.offs.data(), tags.data(), st.data(), detail::opts()));
     std::vector<bool> ok(ms.size());
     for (size_t i = 0; i < ms.size(); i++) {
