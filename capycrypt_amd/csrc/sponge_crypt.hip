@@ -75,13 +75,19 @@ void tag_compare_launch(const uint8_t *a, uint64_t a_stride, const uint8_t *b, u
                        b_stride, status, (uint64_t)n);
 }
 
-// first batch size that takes the one-lane-per-sponge fused kernel: from 32 items per SIMD on there is a sponge for every lane of
+// first batch size that takes the one-lane-per-sponge fused kernel.  Beyond 32 items per SIMD there is a sponge for every lane of
 // the chip (33 000 x 1 MiB: 513 GiB/s on the rotating schedule against 500 for the four-lane form in time slices,
-// profiles/r05_fused_one_lane.txt)
-static size_t fused1_min_items()
+// profiles/r05_fused_one_lane.txt).  r06: UNIFORM batches switch at 24 items per SIMD already -- up to 32 S items the one-lane
+// form is one lone wave per SIMD (on 3/4 of the SIMDs at 24 S) whose launch takes the same 59.8 ms per MiB of message
+// whatever n is, and same-box alternating runs (profiles/r06_fused_32s_ab.txt) put it ahead of the four-lane form at every
+// size from there: 24 576 x 1 MiB 403 against 386 GiB/s, 28 672: 468 / 436, 32 768: 535 / 484 (x 5 MiB 533 / 488; D256
+// 653 / 571), and the four-lane form's dip at 29 696-30 720 items (348-359 GiB/s: two waves on some SIMDs) is gone.  Ragged
+// batches keep 32 S: half as many items per wave wait for a wave's longest message in the four-lane form.
+static size_t fused1_min_items(bool uniform)
 {
     static const long forced = (long)debug_knob("fused1_min", -1);
-    return forced >= 0 ? (size_t)forced : 32 * (size_t)device_simds() + 1;
+    if (forced >= 0) return (size_t)forced;
+    return uniform ? 24 * (size_t)device_simds() : 32 * (size_t)device_simds() + 1;
 }
 
 // The plan of the rotating-occupancy schedule for the one-lane fused kernel: bundles of 128 items (four waves), C compute units,
@@ -138,7 +144,9 @@ static int fused1_launch(int rw, FusedParams &fp, const MsgView &m, hipStream_t 
     // up to two waves per SIMD: the unrolled blocked round with the next block prefetched; beyond: the rolled round at three
     // or four waves per SIMD
     static const int forced_form = (int)debug_knob("fused1_form", 0);
-    fp.one_lane = groups <= 2 * simds ? 2 : 4;
+    // at most one wave per SIMD (r06: the batches just below and at 32 items per SIMD): the lone-wave instance -- compiled so that
+    // a second wave does not fit, plain unrolled round, per-lane stores (lone_direct below)
+    fp.one_lane = groups <= simds ? 1 : (groups <= 2 * simds ? 2 : 4);
     if (forced_form == 1 || forced_form == 2 || forced_form == 4) fp.one_lane = (uint32_t)forced_form;
     fp.cap_waves = 0;
     if (fp.one_lane == 4) {
@@ -283,9 +291,10 @@ int symmetric_crypt_dev(bool encrypt, int d, size_t n, const uint8_t *keka, size
     const Framing ff = cshake_framing(d);
     const bool fused_shape = fused_enabled() && ff.stride == (uint32_t)ff.rw * 8 && m.aligned8 && m.msgs != nullptr &&
                              tag_len <= 64 && (tag_len & 3) == 0;
-    // More than 32 items per SIMD: one lane per sponge (sponge_fused1.h), at every larger batch size; up to there, four lanes per
-    // item (sponge_fused.h).  CAPY_DEBUG=fused1_min=N moves the boundary (A/B, tests).
-    const bool one_lane = fused_shape && n >= fused1_min_items() && (key_len & 7) == 0 && (((uintptr_t)keka | keka_stride) & 7) == 0;
+    // From 24 (uniform) / 32 (ragged) items per SIMD: one lane per sponge (sponge_fused1.h), at every larger batch size; up to
+    // there, four lanes per item (sponge_fused.h).  CAPY_DEBUG=fused1_min=N moves the boundary (A/B, tests).
+    const bool one_lane = fused_shape && n >= fused1_min_items(!m.offsets && !m.order) && (key_len & 7) == 0 &&
+                          (((uintptr_t)keka | keka_stride) & 7) == 0;
     const bool fused_ok = fused_shape && (one_lane || n <= fused_max_items());
     if (fused_ok) {
         FusedParams fp;

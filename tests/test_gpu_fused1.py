@@ -122,6 +122,44 @@ def test_single_launch_two_waves_per_simd(env):
     _round_trip(env, 512, 64 * S, 136 * 9 + 50, 136 * 9 + 56, 8, ONE_LANE)
 
 
+def test_lone_wave_form_takes_uniform_batches_from_24_items_per_simd(env):
+    """r06 (the 10 % step at n = 32 S).  Up to 32 items per SIMD the one-lane form is ONE lone wave per SIMD
+    (FORM 1: compiled so that a second wave does not fit, per-lane stores) and beats the four-lane form from 24 items per SIMD on
+    (profiles/r06_fused_32s_ab.txt), so UNIFORM batches switch there: 24 S and 32 S take kind 23 in one launch, 24 S - 1 still the
+    four-lane kernel (kind 20).  Each against the two-pass form over the whole buffer, the oracle on samples, and a decrypt with a
+    forged tag (_round_trip); a partial last wave and a tail at 32 S - 13."""
+    S = _simds(env[3])
+    _round_trip(env, 512, 24 * S, 136 * 9 + 50, 136 * 9 + 56, 8, ONE_LANE)
+    _round_trip(env, 512, 32 * S, 136 * 7 + 3, 136 * 7 + 8, 0, ONE_LANE)
+    _round_trip(env, 256, 32 * S - 13, 168 * 5 + 161, 168 * 6, 8, ONE_LANE)
+    _round_trip(env, 512, 24 * S - 1, 136 * 9 + 50, 136 * 9 + 56, 8, 20)
+
+
+def test_ragged_batches_keep_the_four_lane_form_up_to_32_items_per_simd(env):
+    """... and RAGGED batches do not: half as many items per wave wait for the wave's longest message in the four-lane form.  A
+    host batch of 30 S items of 0 .. 5 blocks: kind 20, equal to the two-pass form and the oracle."""
+    _lib, lib, O, torch = env
+    from capycrypt_amd import ops
+
+    S = _simds(torch)
+    n = 30 * S
+    rng = random.Random(17)
+    msgs = [rng.randbytes(rng.randrange(0, 5 * 136 + 9)) for _ in range(n)]
+    pws = [rng.randbytes(16) for _ in range(n)]
+    zs = [rng.randbytes(512) for _ in range(n)]
+    res = {}
+    try:
+        for name, lanes in (("auto", 0), ("two-pass", 1 | (1 << 16))):
+            _lib.check(lib.capy_set_sponge_lanes(lanes))
+            res[name] = ops.sha3_encrypt_batch(pws, zs, msgs, 512) + (_last(lib)[0],)
+    finally:
+        _lib.check(lib.capy_set_sponge_lanes(0))
+    assert res["auto"][2] == 20 and res["two-pass"][2] == TWO_PASS, (res["auto"][2], res["two-pass"][2])
+    assert res["auto"][:2] == res["two-pass"][:2]
+    for i in (0, n - 1, rng.randrange(n)):
+        assert (res["auto"][0][i], res["auto"][1][i]) == O.sha3_encrypt(pws[i], zs[i], msgs[i], 512), i
+
+
 def test_single_launch_four_waves_per_simd_short_messages(env):
     """more than two waves per SIMD, messages too short for slices: the rolled 128-register instance, D256 (two-part filing)"""
     S = _simds(env[3])
