@@ -13,6 +13,7 @@ import argparse
 import ctypes as C
 import json
 import os
+import re
 import sys
 import time
 
@@ -674,6 +675,42 @@ def main():
     stream = torch.cuda.current_stream()
     sp = C.c_void_p(stream.cuda_stream)
 
+    # ---- where this rank sits (r06): device index, PCI bus id, NUMA node, and the CPUs it pins itself to --
+    # the device's local_cpulist within this process's affinity, the same rule the library's workers follow (capy_device_topology).
+    # Every rank's entry goes into the JSON line, so that a multi-GPU record documents its own topology.  CAPY_BENCH_PIN=0: report only.
+    from capycrypt_amd import sharding
+
+    orig_affinity = os.sched_getaffinity(0)
+    topo = sharding.device_topology(dev_index)
+    cpu_ids = topo.pop("cpu_ids")
+    topo.update(rank=rank, local_rank=local_rank, pinned=False, ranks_on_device=share)
+    if cpu_ids and os.environ.get("CAPY_BENCH_PIN", "1") != "0":
+        try:
+            os.sched_setaffinity(0, cpu_ids)
+            topo["pinned"] = True
+        except OSError:
+            pass
+    topology = [topo]
+    if use_dist and world > 1:
+        # fixed-size integer record per rank: [rank, local_rank, device, numa, pinned, n_cpus, domain, bus, dev, fn, 16 x 32-bit CPU mask words]
+        m = re.match(r"([0-9a-f]+):([0-9a-f]+):([0-9a-f]+)\.([0-9a-f]+)$", topo["pci_bus_id"])
+        bdf = [int(x, 16) for x in m.groups()] if m else [-1, -1, -1, -1]
+        words = [0] * 16
+        for c in cpu_ids if topo["pinned"] or cpu_ids else []:
+            if c < 512:
+                words[c // 32] |= 1 << (c % 32)
+        rec = torch.tensor([rank, local_rank, dev_index, topo["numa_node"], int(topo["pinned"]), topo["n_cpus"]] + bdf + words,
+                           dtype=torch.int64, device=red_dev)
+        allrec = [torch.zeros_like(rec) for _ in range(world)]
+        dist.all_gather(allrec, rec)
+        topology = []
+        for r in allrec:
+            v = [int(x) for x in r.tolist()]
+            ids = [32 * w + b for w in range(16) for b in range(32) if (v[10 + w] >> b) & 1]
+            topology.append({"rank": v[0], "local_rank": v[1], "device": v[2], "numa_node": v[3], "pinned": bool(v[4]),
+                             "n_cpus": v[5], "pci_bus_id": "%04x:%02x:%02x.%x" % tuple(v[6:10]) if v[6] >= 0 else "",
+                             "cpus": sharding.cpu_list_string(ids), "ranks_on_device": share})
+
     # ---- synthetic inputs resident in HBM
     B = a.batch
     free, _total = torch.cuda.mem_get_info()
@@ -996,7 +1033,9 @@ def main():
                 for e in cfg_res["3"].get("saturating", []):
                     e["frac_of_paired_loop"] = e["device_permutations_per_s"] / world / bare
             res["configs"] = cfg_res
+        res["topology"] = topology
         if not a.no_cpu_baseline and world == 1:
+            os.sched_setaffinity(0, orig_affinity)  # the CPU legs use every core this job may use, not the device's NUMA node
             res["cpu_baseline"] = cpu_baseline(a.cpu_seconds)
             if any(v is not None for v in cfg_samples.values()):
                 res["configs"]["oracle_spot_checks"] = check_config_samples(cfg_samples)

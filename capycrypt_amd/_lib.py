@@ -22,7 +22,7 @@ CAPY_ERR_HIP = -3
 CAPY_ERR_UNSUPPORTED = -4
 CAPY_HARDEN_OFF, CAPY_HARDEN_ALL, CAPY_HARDEN_PROTOCOL = 0, 1, 4
 CAPY_OPT_DEFAULT = -1
-CAPY_ABI_VERSION = 5  # include/capyhip.h: the ABI this binding is written against
+CAPY_ABI_VERSION = 6  # include/capyhip.h: the ABI this binding is written against
 
 
 class CallOptions(C.Structure):
@@ -42,6 +42,7 @@ SIGNATURES = {
     "capy_set_min_items_per_device": (C.c_int, [sz]),
     "capy_debug_affinity_plan": (C.c_int, [C.c_char_p, vp, C.c_int, vp, C.c_int]),
     "capy_device_count": (C.c_int, []),
+    "capy_device_topology": (C.c_int, [C.c_int, vp, sz, vp, vp, C.c_int]),
     "capy_set_device": (C.c_int, [C.c_int]),
     "capy_set_devices": (C.c_int, [vp, C.c_int]),
     "capy_get_devices": (C.c_int, [vp, C.c_int]),

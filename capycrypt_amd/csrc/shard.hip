@@ -173,26 +173,60 @@ static bool affinity_intersection(const char *local_cpulist, const cpu_set_t &ha
     CPU_AND(both, &want, &have);
     return CPU_COUNT(both) > 0;
 }
+// one line of /sys/bus/pci/devices/<bdf>/<leaf> of a device; false when the device has no such file (a container may hide it)
+static bool device_sysfs_line(int device, const char *leaf, char *bdf, size_t bdf_cap, char *line, size_t line_cap)
+{
+    if (hipDeviceGetPCIBusId(bdf, (int)bdf_cap, device) != hipSuccess) {
+        (void)hipGetLastError();
+        bdf[0] = 0;
+        return false;
+    }
+    for (char *c = bdf; *c; c++) *c = (char)tolower(*c);
+    const std::string path = std::string("/sys/bus/pci/devices/") + bdf + "/" + leaf;
+    FILE *f = fopen(path.c_str(), "r");
+    if (!f) return false;
+    const bool ok = fgets(line, (int)line_cap, f) != nullptr;
+    fclose(f);
+    return ok;
+}
+// the CPUs a worker of `device` runs on: local_cpulist of the device intersected with the calling thread's affinity
+static bool device_cpus(int device, char *bdf, size_t bdf_cap, cpu_set_t *both)
+{
+    char line[4096] = {0};
+    cpu_set_t have;
+    if (!device_sysfs_line(device, "local_cpulist", bdf, bdf_cap, line, sizeof line)) return false;
+    if (sched_getaffinity(0, sizeof have, &have) != 0) return false;
+    return affinity_intersection(line, have, both);
+}
 static void pin_to_device_cpus(int device)
 {
     if (debug_knob("worker_affinity", 1) == 0) return;
     char bdf[64] = {0};
-    if (hipDeviceGetPCIBusId(bdf, sizeof bdf, device) != hipSuccess) {
-        (void)hipGetLastError();
-        return;
-    }
-    for (char *c = bdf; *c; c++) *c = (char)tolower(*c);
-    const std::string path = std::string("/sys/bus/pci/devices/") + bdf + "/local_cpulist";
-    FILE *f = fopen(path.c_str(), "r");
-    if (!f) return;
-    char line[4096] = {0};
-    const bool ok = fgets(line, sizeof line, f) != nullptr;
-    fclose(f);
-    cpu_set_t have, both;
-    if (!ok || sched_getaffinity(0, sizeof have, &have) != 0) return;
-    if (affinity_intersection(line, have, &both)) (void)sched_setaffinity(0, sizeof both, &both);
+    cpu_set_t both;
+    if (device_cpus(device, bdf, sizeof bdf, &both)) (void)sched_setaffinity(0, sizeof both, &both);
 }
 }  // namespace
+// capy_device_topology: where a device sits (what the first real multi-GPU record should say about itself)
+int device_topology(int device, char *pci_bus_id, size_t cap, int *numa_node, int *cpus, int capacity)
+{
+    char bdf[64] = {0}, line[256] = {0};
+    cpu_set_t both;
+    CPU_ZERO(&both);
+    const bool pinned = device_cpus(device, bdf, sizeof bdf, &both);
+    if (pci_bus_id && cap) snprintf(pci_bus_id, cap, "%s", bdf);
+    if (numa_node) {
+        char bdf2[64];
+        *numa_node = device_sysfs_line(device, "numa_node", bdf2, sizeof bdf2, line, sizeof line) ? atoi(line) : -1;
+    }
+    if (!pinned) return 0;
+    int k = 0;
+    for (int c = 0; c < CPU_SETSIZE; c++)
+        if (CPU_ISSET(c, &both)) {
+            if (k < capacity && cpus) cpus[k] = c;
+            k++;
+        }
+    return k;
+}
 // test hook (capy_debug_affinity_plan): the same arithmetic on a caller-supplied sysfs string and allowed-CPU list
 int affinity_plan(const char *local_cpulist, const int *allowed, int n_allowed, int *out, int capacity)
 {
@@ -363,7 +397,7 @@ using namespace capy;
 extern "C" {
 
 const char *capy_last_error(void) { return capy::g_err.c_str(); }
-const char *capy_version(void) { return "capyhip 0.5 (gfx950)"; }
+const char *capy_version(void) { return "capyhip 0.6 (gfx950)"; }
 int capy_abi_version(void) { return CAPY_ABI_VERSION; }
 
 int capy_set_min_items_per_device(size_t n)
@@ -377,6 +411,16 @@ int capy_debug_affinity_plan(const char *local_cpulist, const int *allowed_cpus,
     if (!local_cpulist || (!allowed_cpus && n_allowed) || (!out_cpus && capacity) || n_allowed < 0 || capacity < 0)
         return capy::fail(CAPY_ERR_ARG, "null or invalid argument");
     return capy::affinity_plan(local_cpulist, allowed_cpus, n_allowed, out_cpus, capacity);
+}
+
+int capy_device_topology(int device, char *pci_bus_id, size_t pci_capacity, int *numa_node, int *cpus, int capacity)
+{
+    int have = 0;
+    if (hipGetDeviceCount(&have) != hipSuccess || device < 0 || device >= have || capacity < 0 || (capacity && !cpus)) {
+        (void)hipGetLastError();
+        return capy::fail(CAPY_ERR_ARG, "bad device or buffer");
+    }
+    return capy::device_topology(device, pci_bus_id, pci_capacity, numa_node, cpus, capacity);
 }
 
 int capy_device_count(void)

@@ -36,3 +36,35 @@ def sharded_map(fn, items, rank, world):
     """Apply the batched operator `fn` to this rank's slice of `items`; returns (lo, hi, results)."""
     lo, hi = shard_range(len(items), rank, world)
     return lo, hi, fn(items[lo:hi])
+
+
+def cpu_list_string(cpus):
+    """[0, 1, 2, 3, 8, 9] -> "0-3,8-9" (the kernel's cpulist notation)"""
+    out, cpus = [], sorted(cpus)
+    i = 0
+    while i < len(cpus):
+        j = i
+        while j + 1 < len(cpus) and cpus[j + 1] == cpus[j] + 1:
+            j += 1
+        out.append(str(cpus[i]) if i == j else "%d-%d" % (cpus[i], cpus[j]))
+        i = j + 1
+    return ",".join(out)
+
+
+def device_topology(device):
+    """include/capyhip.h: capy_device_topology -- {"device", "pci_bus_id", "numa_node", "cpus" (cpulist string of the CPUs a worker
+    of this device pins itself to: the device's local_cpulist within this process's affinity; "" = no pinning), "n_cpus"}"""
+    import ctypes as C
+
+    from . import _lib
+
+    bdf = C.create_string_buffer(64)
+    numa = C.c_int(-1)
+    cap = 4096
+    cpus = (C.c_int * cap)()
+    n = _lib.lib().capy_device_topology(int(device), bdf, 64, C.byref(numa), cpus, cap)
+    if n < 0:
+        _lib.check(n)
+    ids = list(cpus[:min(n, cap)])
+    return {"device": int(device), "pci_bus_id": bdf.value.decode(), "numa_node": int(numa.value),
+            "cpus": cpu_list_string(ids), "n_cpus": int(n), "cpu_ids": ids}

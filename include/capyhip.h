@@ -91,8 +91,9 @@ typedef struct capy_call_options {
  *   3  r03: capy_ed448_set_hardened / _set_scalar_star / _set_generator, KEM sponge half, key_encrypt / key_decrypt
  *   4  r04: capy_call_options and the *_ex entry points, generator handles, five further *_dev forms;
  *           capy_ed448_set_hardened values 2 and 3 refused (1 = every multiplication again, 4 = the protocol default)
- *   5  r05: capy_abi_version, capy_set_min_items_per_device, capy_debug_last_sponge_kernel, capy_debug_affinity_plan */
-#define CAPY_ABI_VERSION 5
+ *   5  r05: capy_abi_version, capy_set_min_items_per_device, capy_debug_last_sponge_kernel, capy_debug_affinity_plan
+ *   6  r06: capy_device_topology */
+#define CAPY_ABI_VERSION 6
 int capy_abi_version(void);
 const char *capy_last_error(void);
 const char *capy_version(void);
@@ -122,6 +123,13 @@ int capy_set_min_items_per_device(size_t n);
  * shard its midpoint falls in), or NULL (balance by count).  Pure host arithmetic. */
 int capy_shard_plan(size_t n, int n_devices, const uint64_t *byte_offsets, uint64_t *bounds);
 int capy_device_synchronize(void); /* every configured device, else the current one */
+/* Where `device` sits: its PCI bus id ("0000:c1:00.0", empty if unknown) into pci_bus_id, its NUMA node (-1 if the system does
+ * not say) into *numa_node, and the CPUs a worker thread of capy_set_devices pins itself to for it -- the device's
+ * /sys/bus/pci/devices/<bdf>/local_cpulist intersected with the calling thread's affinity mask -- into cpus[0 .. capacity).
+ * Returns the number of such CPUs (it may exceed capacity; 0 = no pinning: sysfs hides the device, or the intersection is empty),
+ * < 0 on a bad argument.  Any pointer may be NULL.  No reference counterpart (the reference runs on the CPU); bench.py prints it
+ * per rank so that a multi-GPU record documents its own topology. */
+int capy_device_topology(int device, char *pci_bus_id, size_t pci_capacity, int *numa_node, int *cpus, int capacity);
 /* Free the calling thread's pooled device scratch on every device (synchronises); also done when the thread ends. */
 int capy_release_workspace(void);
 /* Test hook: how many bytes of the scratch ranges that the calling thread's LAST protocol call declared secret (secret

@@ -151,3 +151,61 @@ def test_staging_buffer_cache_reuse_and_release():
             assert got[i] == O.kmac_xof(keys[i], msgs[i], 512, b"cache", 512), (n, mlen, klen, i)
         if n == 7:
             _lib.check(_lib.lib().capy_release_workspace())
+
+
+def test_every_visible_device_once_each(devices):
+    """r06: capy_set_devices with EVERY visible device exactly once -- one entry on this pool, eight on the
+    real node, the same test -- over the three BASELINE shapes that shard: a config-1-shaped SHA3-256 batch (equal long messages),
+    config 4 (Ed448 variable base on distinct points) and config 5 (key pairs, sign, verify), each compared with the call on
+    device 0 alone; the cut is the one capy_shard_plan announces; every device reports a topology entry (PCI bus id; the CPU set is
+    empty only where sysfs hides the device).  What this cannot prove on one card -- distinct devices, more than one PCIe link,
+    NUMA pinning on a two-socket host -- it will the first time it runs on a node with more."""
+    import torch
+
+    from capycrypt_amd import _lib, ops, sharding
+
+    lib = _lib.lib()
+    ndev = lib.capy_device_count()
+    assert ndev == torch.cuda.device_count() >= 1
+    ids = list(range(ndev))
+    topo = [sharding.device_topology(i) for i in ids]
+    assert len({t["pci_bus_id"] for t in topo}) == ndev and all(t["pci_bus_id"] for t in topo), topo
+    for t in topo:
+        assert t["n_cpus"] == len(t["cpu_ids"]) and set(t["cpu_ids"]) <= set(__import__("os").sched_getaffinity(0))
+    rng = random.Random(0xA11)
+    n1 = 96 * ndev + 5                                  # config-1 shape: equal long messages (5 MiB there, 192 KiB here)
+    msgs1 = [rng.randbytes(192 * 1024) for _ in range(n1)]
+    n4 = 1536 * ndev + 7                                # config 4: distinct (scalar, point) pairs
+    sc = [rng.randbytes(56) for _ in range(n4)]
+    ts = [rng.randbytes(56) for _ in range(n4)]
+    n5 = 640 * ndev + 3                                 # config 5: 1 KiB messages
+    msgs5 = [rng.randbytes(1024) for _ in range(n5)]
+    pws = [rng.randbytes(64) for _ in range(n5)]
+
+    def run():
+        r = {"sha3": ops.sha3_batch(msgs1, 256)}
+        pts = ops.ed448_basemul_batch(ts)
+        r["vb"] = ops.ed448_scalarmul_batch(sc, pts)
+        r["pub"] = ops.keypair_batch(pws, 512)
+        r["sig"] = ops.schnorr_sign_batch(pws, msgs5, 512)
+        sig = list(r["sig"])
+        sig[n5 - 1] = (bytes(56), sig[n5 - 1][1])
+        r["ver"] = ops.schnorr_verify_batch(r["pub"], msgs5, sig, 512)
+        return r
+
+    devices([0])
+    single = run()
+    devices(ids)
+    sharded = run()
+    for k in single:
+        assert sharded[k] == single[k], k
+    assert single["ver"] == [True] * (n5 - 1) + [False]
+    import hashlib
+
+    assert single["sha3"][:4] == [hashlib.sha3_256(m).digest() for m in msgs1[:4]]
+    # the announced cut: contiguous, covers everything, count-balanced for equal messages
+    bounds = (C.c_uint64 * (ndev + 1))()
+    offs = (C.c_uint64 * (n1 + 1))(*[i * 192 * 1024 for i in range(n1 + 1)])
+    _lib.check(lib.capy_shard_plan(n1, ndev, offs, bounds))
+    b = list(bounds)
+    assert b[0] == 0 and b[-1] == n1 and all(0 <= b[i + 1] - b[i] - n1 // ndev <= 1 for i in range(ndev)), b

@@ -547,6 +547,28 @@ def test_bench_config_legs_reduce_once_and_survive_a_failing_rank():
     seen = []
     res, sample = bench.run_config_leg(boom, bench.derive_config2, Cx(), lambda v: seen.append(v) or v)
     assert "round trip failed" in res["error"] and seen and seen[0][0] == 1.0 and len(seen[0]) == 64  # it still took part in the reduction
-    # one rank (no reduction): a failure is raised, not swallowed
-    with pytest.raises(RuntimeError):
-        bench.run_config_leg(boom, bench.derive_config2, Cx(), None)
+    # one rank (no reduction): the leg becomes an error entry too (r06, ADVICE r5: raising here lost the whole record, headline
+    # included); bench.main() prints the line and THEN exits 4
+    res, sample = bench.run_config_leg(boom, bench.derive_config2, Cx(), None)
+    assert "round trip failed" in res["error"] and sample is None
+
+
+def test_device_topology_entry_point_and_cpulist_notation():
+    """r06: capy_device_topology (the PCI bus id / NUMA node / pinned CPU set bench.py prints per rank) refuses a device that does
+    not exist -- which is every device on a box without a GPU -- and the cpulist notation round-trips through the library's own
+    parser (capy_debug_affinity_plan takes the kernel's "a-b,c" form)."""
+    import ctypes as C
+
+    from capycrypt_amd import _lib, sharding
+
+    lib = _lib.lib()
+    have = lib.capy_device_count()
+    assert lib.capy_device_topology(have, None, 0, None, None, 0) == _lib.CAPY_ERR_ARG
+    assert lib.capy_device_topology(-1, None, 0, None, None, 0) == _lib.CAPY_ERR_ARG
+    ids = [0, 1, 2, 3, 8, 9, 11, 64, 65, 66, 200]
+    text = sharding.cpu_list_string(ids)
+    assert text == "0-3,8-9,11,64-66,200" and sharding.cpu_list_string([]) == ""
+    allowed = (C.c_int * 256)(*range(256))
+    out = (C.c_int * 64)()
+    n = lib.capy_debug_affinity_plan(text.encode(), allowed, 256, out, 64)
+    assert list(out[:n]) == ids
