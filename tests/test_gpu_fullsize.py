@@ -122,9 +122,65 @@ def test_config3_per_gpu_share_round_trips():
     assert torch.equal(m2[ok.cuda()], p2[ok.cuda()]) and torch.equal(m2[77], c2[77])
 
 
+def test_config3_as_specified_whole_batch_on_one_gpu():
+    """BASELINE config 3 AS SPECIFIED, all of it on one GPU (r06): 1024 x 5 MiB through sha3_encrypt D512 -- two
+    waves per item, bit-interleaved Keccak lanes (sponge_il_crypt_kernel, kind 27; /root/reference/src/sha3/encryptable.rs:29-45).
+    EVERY tag and EVERY ciphertext byte equal the two-pass form's (tag kernel + keystream kernel: another kernel family
+    altogether), three items equal the oracle's, and sha3_decrypt (:58-83) restores every plaintext byte except the one item whose
+    tag was forged, which keeps its ciphertext."""
+    import ctypes as C
+
+    import torch
+
+    from capycrypt_amd import _lib
+    from oracle import oracle
+
+    lib = _lib.lib()
+    n = 1024
+    plain = _rand(n * MIB5, 0xCA9C0003)
+    pws, zs = _rand(n * 64, 31), _rand(n * 512, 32)
+    outs, kinds = [], []
+    try:
+        for flags in (0, 1 | (1 << 16)):
+            _lib.check(lib.capy_set_sponge_lanes(flags))
+            work = plain.clone()
+            tags = torch.zeros(n * 64, dtype=torch.uint8, device="cuda")
+            _lib.check(lib.capy_sha3_encrypt_batch_dev(512, n, pws.data_ptr(), 64, None, 0, zs.data_ptr(), work.data_ptr(), None, MIB5, MIB5,
+                                                       tags.data_ptr(), None))
+            torch.cuda.synchronize()
+            k, l = C.c_int(0), C.c_int(0)
+            lib.capy_debug_last_sponge_kernel(C.byref(k), C.byref(l))
+            kinds.append(k.value)
+            outs.append((work, tags))
+    finally:
+        _lib.check(lib.capy_set_sponge_lanes(0))
+    assert kinds == [27, 26], kinds  # two waves per item; the two-pass form
+    assert torch.equal(outs[0][1], outs[1][1]), "tags differ from the two-pass form"
+    assert torch.equal(outs[0][0], outs[1][0]), "ciphertexts differ from the two-pass form"
+    work, tags = outs[0]
+    del outs
+    hp, hz, ht = bytes(pws.cpu().numpy()), bytes(zs.cpu().numpy()), bytes(tags.cpu().numpy())
+    for i in (0, 517, n - 1):
+        ect, etag = oracle.sha3_encrypt(hp[64 * i:64 * i + 64], hz[512 * i:512 * i + 512], bytes(plain[i * MIB5:(i + 1) * MIB5].cpu().numpy()), 512)
+        assert bytes(work[i * MIB5:(i + 1) * MIB5].cpu().numpy()) == ect and ht[64 * i:64 * i + 64] == etag, i
+    bad = 700
+    cipher_bad = work[bad * MIB5:(bad + 1) * MIB5].clone()
+    tags[64 * bad + 63] ^= 0x80
+    status = torch.full((n,), 5, dtype=torch.int32, device="cuda")
+    _lib.check(lib.capy_sha3_decrypt_batch_dev(512, n, pws.data_ptr(), 64, None, 0, zs.data_ptr(), work.data_ptr(), None, MIB5, MIB5,
+                                               tags.data_ptr(), status.data_ptr(), None))
+    torch.cuda.synchronize()
+    st = status.cpu().numpy()
+    assert st[bad] == 1 and int(st.sum()) == 1
+    w2, p2 = work.view(n, MIB5), plain.view(n, MIB5)
+    ok = torch.ones(n, dtype=torch.bool, device="cuda")
+    ok[bad] = False
+    assert torch.equal(w2[ok], p2[ok]) and torch.equal(w2[bad], cipher_bad)
+
+
 def test_config3_saturating_batch_fused_paired_kernel(O=None):
-    """Config 3's GPU-saturating variant: 32 768 x 1 MiB through sha3_encrypt -- two waves per SIMD of the fused
-    four-lane kernel on the blocked round with priority (r03).  Every tag must equal the two-pass form's (tag kernel +
+    """Config 3's GPU-saturating variant: 32 768 x 1 MiB through sha3_encrypt -- since r06 one lone wave per SIMD of the
+    one-lane-per-sponge fused kernel (r03-r05: two waves per SIMD of the four-lane kernel).  Every tag must equal the two-pass form's (tag kernel +
     keystream kernel, bit 16 of capy_set_sponge_lanes), every ciphertext byte too; decrypt restores every plaintext byte;
     two items are checked against the oracle."""
     import torch

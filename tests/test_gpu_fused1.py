@@ -77,7 +77,7 @@ def _round_trip(env, d, n, ln, stride, off, want_kind, offsets=None, pl=32, samp
     kind, launches = res["auto"][2]
     assert kind == want_kind, (kind, launches, want_kind)
     assert res["two-pass"][2][0] == TWO_PASS
-    if want_kind != ONE_LANE:
+    if want_kind in (ONE_LANE_SLICED, ONE_LANE_ROT):
         assert launches > 1
     assert torch.equal(res["auto"][1], res["two-pass"][1]), "tags differ from the two-pass form"
     assert torch.equal(res["auto"][0], res["two-pass"][0]), "ciphertexts (or bytes outside the messages) differ from the two-pass form"

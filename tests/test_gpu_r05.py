@@ -106,9 +106,10 @@ def test_keyed_states_of_the_phase_schedules_are_scrubbed(env):
 def test_seeded_differential_soaks(tool):
     """the randomised differential soaks of tools/ (every host-buffer entry point; the *_dev forms with random
     alignments / strides / streams and guard bytes; the sponge launcher's automatic kernel choice against a forced one over big
-    random shapes -- the one-lane fused kernel and its schedules included) as tests: 30 s each, fixed seed, so a failure
-    reproduces with `SECONDS=30 SEED=5 python tools/<tool>`.  The tools print one FAIL line per finding and exit non-zero."""
-    env = dict(os.environ, SECONDS="30", SEED="5")
+    random shapes -- the one-lane fused kernel and its schedules included) as tests: 90 s each (r06: the suite had the room; r05 ran
+    30 s), fixed seed, so a failure reproduces with `SECONDS=90 SEED=5 python tools/<tool>`.  The tools print one FAIL line per
+    finding and exit non-zero."""
+    env = dict(os.environ, SECONDS="90", SEED="5")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool)], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "failures 0" in r.stdout.splitlines()[-1], r.stdout[-4000:] + r.stderr[-2000:]
 
