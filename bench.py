@@ -1025,6 +1025,16 @@ def main():
                                   "peak_note": "1024 SIMDs x clock / 4 cycles per instruction (the issue rate of a stream of 4-cycle "
                                                "instructions; 21 % of this one are simple instructions that can pair, so 1.0 is not a bound)",
                                   "source": "profiles/%s" % pm_file}
+                # A second denominator that does NOT depend on this build's instruction count: the multiply-adds
+                # the ALGORITHM needs -- 90 windows x (5 doublings of 4S + 3M, one product for T, one 8M addition) + the 17-entry
+                # table (16 additions of 9M + 17 products by d) + the division-step inversion, at 192 / 110 v_mad_u64_u32 per
+                # multiplication / squaring of 16 x 28-bit limbs (Karatsuba over the Goldilocks split; the radix is closed:
+                # profiles/r06_ed448_radix32.txt) -- issued at one per 4 cycles per SIMD and nothing else.
+                mads_unit = (90 * 24 + 16 * 9 + 17) * 192 + 90 * 20 * 110 + 44 * 240
+                mad_ceiling = 1024 * clk * 1e9 / 4.0 * 64 / mads_unit  # scalar multiplications/s
+                ed["roofline"].update({"multiply_adds_per_unit_by_formula": mads_unit,
+                                       "multiply_only_ceiling_scalar_mults_per_s": mad_ceiling,
+                                       "frac_of_multiply_only_ceiling": ed["scalar_mults_per_s"] / world / mad_ceiling})
         if cfg_res:
             if valu_live:  # config 2 / 3 against the bare paired permutation loop measured in this run
                 bare = valu_live * 1e9 / 136.0  # permutations/s
