@@ -684,6 +684,10 @@ def main():
     topo = sharding.device_topology(dev_index)
     cpu_ids = topo.pop("cpu_ids")
     topo.update(rank=rank, local_rank=local_rank, pinned=False, ranks_on_device=share)
+    _props = torch.cuda.get_device_properties(dev_index)
+    box = {"device_name": _props.name, "compute_units": _props.multi_processor_count, "hbm_total_GiB": round(_props.total_memory / 2**30, 1),
+           "note": "boxes of the pool differ by 3-7 % on VALU-bound kernels: roofline.valu_ceiling_GBs / valu_ceiling_one_wave_per_simd_GBs "
+                   "are THIS box's bare permutation loops, measured in this run -- compare boxes through them"}
     if cpu_ids and os.environ.get("CAPY_BENCH_PIN", "1") != "0":
         try:
             os.sched_setaffinity(0, cpu_ids)
@@ -1044,6 +1048,7 @@ def main():
                     e["frac_of_paired_loop"] = e["device_permutations_per_s"] / world / bare
             res["configs"] = cfg_res
         res["topology"] = topology
+        res["box"] = box
         if not a.no_cpu_baseline and world == 1:
             os.sched_setaffinity(0, orig_affinity)  # the CPU legs use every core this job may use, not the device's NUMA node
             res["cpu_baseline"] = cpu_baseline(a.cpu_seconds)
