@@ -93,9 +93,9 @@ ROWS = [
      [(ED, r"const bool quad_ct = ct && n > quad_min_items\(\) && n <= quad_ct_max_items\(\)")]),
     ("", "16 S < n <= 32 S secret", r"capy::vb_duo_ct_kernel$", "66", "2, table half in registers and half in LDS", "1.92 ms",
      [(ED, r"quad_ct && duo_ct_on && n > 16 \* dev_simds\(\) && n <= 32 \* dev_simds\(\)")]),
-    ("", "32 S < n <= 64 S per launch (remainders up to 32 S peeled off first)", r"capy::vb_kernel_1w$|capy::vb_ct_kernel_1w$", "1 / 2", "1, one wave per SIMD, up to 350 VGPRs",
+    ("", "32 S < n <= 64 S per launch (remainders up to 32 S peeled off first)", r"capy::vb_kernel_1w$|capy::vb_ct_kernel_1w$", "1 / 2 (public / secret)", "1, one wave per SIMD, up to 350 VGPRs",
      "one chain of 1.27 M instructions per lane: 2.5-2.9 ms", [(ED, r"static size_t one_wave_items\(\) \{ return 64 \* dev_simds\(\); \}"), (ED, r"return x <= quantum / 2 \? x : 0")]),
-    ("", "64 S < n < 256 S", r"capy::vb_kernel$|capy::vb_ct_kernel$", "1 / 2", "1", "v_mad_u64_u32 issue", [(ED, r"hipLaunchKernelGGL\(vb_kernel, grid64\(n\)")]),
+    ("", "64 S < n < 256 S", r"capy::vb_kernel$|capy::vb_ct_kernel$", "1 / 2 (public / secret)", "1", "v_mad_u64_u32 issue", [(ED, r"hipLaunchKernelGGL\(vb_kernel, grid64\(n\)")]),
     ("", "n >= 256 S public (CONFIG 4: 2^18 pairs)", r"capy::vb2_kernel$", "1", "1/2 (two items per lane share one inversion)",
      "v_mad_u64_u32 issue and energy: 27-28.6 M/s = 0.97 of the issue rate of its own stream; the radix question is closed (profiles/r06_ed448_radix32.txt)",
      [(ED, r"return dev_simds\(\) \* 2 \* 128;"), (ED, r"\} else if \(n >= pair_min_items\(\)\) \{\s*\n\s*return vb2_launch")]),
@@ -108,8 +108,8 @@ ROWS = [
      "65 additions, 7-bit windows, constant-address lookups as one-hot products on the matrix cores (a gather, not arithmetic): 0.53 ms at 64 S",
      [(ED, r"if \(ct && !small && CAPY_ED448_FBCT_MFMA\)")]),
     # ---- Ed448 double multiplication (verify: [z]G + [h]V), ed448.hip: dsm_launch
-    ("Ed448 [a]G + [b]P (verify)", "n <= 4 S / <= 16 S / <= 32 S / larger", r"wave::dsm_wave_kernel|capy::dsm_quad_kernel|capy::dsm_duo_kernel|capy::dsm_kernel", "17 / 33 / 65 / 1",
-     "64 / 4 / 2 / 1", "the variable-base loop of the same family, then 39 mixed additions: 0.45 / 1.19 / 1.87 / 2.9 ms",
+    ("Ed448 [a]G + [b]P (verify)", "n <= 4 S / <= 16 S / <= 32 S / <= 64 S per launch / larger", r"wave::dsm_wave_kernel|capy::dsm_quad_kernel|capy::dsm_duo_kernel|capy::dsm_kernel_1w|capy::dsm_kernel$", "17 / 33 / 65 / 1 / 1",
+     "64 / 4 / 2 / 1 / 1", "the variable-base loop of the same family, then 39 mixed additions: 0.45 / 1.19 / 1.87 / 2.9 ms (<= 64 S) / two waves per SIMD beyond",
      [(ED, r"t_last_vb_kernel = duo_range\(n\) \? 1 \+ 64 : \(quad_range\(n\) \? 1 \+ 32 : \(n <= wave_max_items\(\) \? 1 \+ 16 : 1\)\)")]),
 ]
 
@@ -136,7 +136,29 @@ def build():
                     src_cache[fn] = f.read()
             if not re.search(pat, src_cache[fn]):
                 problems.append("%s no longer contains /%s/ (row: %s | %s)" % (fn, pat, call or "...", when))
-        short = sorted({re.sub(r"<.*", "", n.replace("capy::", "")) for n in names})
+        # kernel names in the order of the regex's alternatives (the order the row's "kind" and timings are written in)
+        alts, depth, cur, esc = [], 0, "", False
+        for ch in kre:  # split at top-level '|' only
+            if esc:
+                cur, esc = cur + ch, False
+            elif ch == "\\":
+                cur, esc = cur + ch, True
+            elif ch == "|" and depth == 0:
+                alts.append(cur)
+                cur = ""
+            else:
+                depth += (ch == "(") - (ch == ")")
+                cur += ch
+        alts.append(cur)
+
+        def rank(n):
+            return min([i for i, a in enumerate(alts) if re.search(a, n)] or [len(alts)])
+
+        short = []
+        for n in sorted(names, key=lambda n: (rank(n), n)):
+            b = re.sub(r"<.*", "", n.replace("capy::", ""))
+            if b not in short:
+                short.append(b)
         lines.append("| %s | %s | `%s` | %s | %s | %s | %s | %s | %s |" % (
             call, when, "` / `".join(short), kind, lanes, _rng([table[n]["vgpr_count"] for n in names]),
             _rng([table[n]["private_segment_fixed_size"] for n in names]), _rng([table[n]["max_waves_per_simd"] for n in names]), binds))
